@@ -1,0 +1,559 @@
+"""CPU oracle (numpy, FP64) for the Crazyflie SQP-RTI hot path.  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED: the reference's arithmetic for this path lives in acados / HPIPM / BLASFEO
+(github.com/tmmsartor/acados, branch `crazyflie`, no pinned commit, empty submodule under
+/root/reference/acados; .gitmodules:7-10) and in the git-ignored generated solver
+(`c_generated_code/`).  Neither can be built or imported here, and the reference ships no
+golden vectors or tests for the path.  This file restates the *mathematics* the reference
+pins:
+
+  * ODE + constants ............ crazyflie_controller/scripts/crazyflie_full_model/export_ode_model.py:33-102
+  * OCP (N, Tf, W, bounds) ..... crazyflie_controller/scripts/crazyflie_full_model/generate_c_code.py:41-146
+  * per-step host protocol ..... crazyflie_controller/src/acados_mpc.cpp:427-670
+  * predictor protocol ......... crazyflie_controller/src/acados_estimator.cpp:521-593
+
+and is pinned only by (G1) traj/smooth_step.txt (RK4, dt=0.015 reproduces row k+1 from row k),
+(G2/G3) the hover fixed point / RTI known answer and (G4/G5) file constants, see
+tests/test_oracle_golden.py.  The QP produced by one RTI step is strictly convex, so its
+solution is unique: two independent solvers live here (a dense primal-dual solver on the
+condensed QP, `solve_qp_dense`, and the stage-wise Riccati interior point method that the HIP
+kernels implement, `riccati_ipm`) and are cross-checked through the KKT conditions.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------
+# constants  (export_ode_model.py:34-42, generate_c_code.py:41-59)
+# ----------------------------------------------------------------------------------------
+G0 = 9.8066
+MQ = 33e-3
+IXX = 1.395e-5
+IYY = 1.395e-5
+IZZ = 2.173e-5
+CD = 7.9379e-06
+CT = 3.25e-4
+DQ = 65e-3
+ARM = DQ / 2
+
+NX, NU, NY, NYN = 13, 4, 17, 13
+N_DEFAULT = 50
+TF_DEFAULT = 0.75
+DT = TF_DEFAULT / N_DEFAULT  # 0.015
+HOV_W = float(np.sqrt((MQ * G0) / (4 * CT)))  # generate_c_code.py:58
+U_MIN, U_MAX = 0.0, 22.0  # generate_c_code.py:133-134
+
+# generate_c_code.py:63-84,109
+W_DIAG = np.array([120.0, 100.0, 100.0, 1e-3, 1e-3, 1e-3, 1e-3, 0.7, 1.0, 4.0, 1e-5, 1e-5, 10.0,
+                   0.06, 0.06, 0.06, 0.06])
+Q_DIAG = W_DIAG[:NX].copy()
+R_DIAG = W_DIAG[NX:].copy()
+WN_FACTOR = 50.0
+QN_DIAG = WN_FACTOR * Q_DIAG
+
+
+# ----------------------------------------------------------------------------------------
+# dynamics  (export_ode_model.py:85-101); x = [p(3) q(4: w x y z) vb(3) w(3)], u = krpm(4)
+# ----------------------------------------------------------------------------------------
+def f_expl(x, u):
+    """Continuous-time ODE right-hand side; works on (..., 13), (..., 4) arrays."""
+    x = np.asarray(x, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    q1, q2, q3, q4 = x[..., 3], x[..., 4], x[..., 5], x[..., 6]
+    vbx, vby, vbz = x[..., 7], x[..., 8], x[..., 9]
+    wx, wy, wz = x[..., 10], x[..., 11], x[..., 12]
+    w1, w2, w3, w4 = u[..., 0], u[..., 1], u[..., 2], u[..., 3]
+    out = np.empty(np.broadcast(x[..., 0], u[..., 0]).shape + (NX,))
+    out[..., 0] = vbx * (2 * q1**2 + 2 * q2**2 - 1) - vby * (2 * q1 * q4 - 2 * q2 * q3) + vbz * (2 * q1 * q3 + 2 * q2 * q4)
+    out[..., 1] = vby * (2 * q1**2 + 2 * q3**2 - 1) + vbx * (2 * q1 * q4 + 2 * q2 * q3) - vbz * (2 * q1 * q2 - 2 * q3 * q4)
+    out[..., 2] = vbz * (2 * q1**2 + 2 * q4**2 - 1) - vbx * (2 * q1 * q3 - 2 * q2 * q4) + vby * (2 * q1 * q2 + 2 * q3 * q4)
+    out[..., 3] = -(q2 * wx) / 2 - (q3 * wy) / 2 - (q4 * wz) / 2
+    out[..., 4] = (q1 * wx) / 2 - (q4 * wy) / 2 + (q3 * wz) / 2
+    out[..., 5] = (q4 * wx) / 2 + (q1 * wy) / 2 - (q2 * wz) / 2
+    out[..., 6] = (q2 * wy) / 2 - (q3 * wx) / 2 + (q1 * wz) / 2
+    out[..., 7] = vby * wz - vbz * wy + G0 * (2 * q1 * q3 - 2 * q2 * q4)
+    out[..., 8] = vbz * wx - vbx * wz - G0 * (2 * q1 * q2 + 2 * q3 * q4)
+    out[..., 9] = vbx * wy - vby * wx - G0 * (2 * q1**2 + 2 * q4**2 - 1) + (CT * (w1**2 + w2**2 + w3**2 + w4**2)) / MQ
+    out[..., 10] = -(CT * ARM * (w1**2 + w2**2 - w3**2 - w4**2) - IYY * wy * wz + IZZ * wy * wz) / IXX
+    out[..., 11] = -(CT * ARM * (w1**2 - w2**2 - w3**2 + w4**2) + IXX * wx * wz - IZZ * wx * wz) / IYY
+    out[..., 12] = -(CD * (w1**2 - w2**2 + w3**2 - w4**2) - IXX * wx * wy + IYY * wx * wy) / IZZ
+    return out
+
+
+_SYM_CACHE = {}
+
+
+def sympy_model():
+    """Symbolic restatement (sympy) used to derive the exact Jacobian independently of the
+    hand-written one in the C/HIP code.  Returns (f_lambda, J_lambda) taking 17 scalars."""
+    if "f" in _SYM_CACHE:
+        return _SYM_CACHE["f"], _SYM_CACHE["J"]
+    import sympy as sp
+
+    xs = sp.symbols("xq yq zq q1 q2 q3 q4 vbx vby vbz wx wy wz")
+    us = sp.symbols("w1 w2 w3 w4")
+    xq, yq, zq, q1, q2, q3, q4, vbx, vby, vbz, wx, wy, wz = xs
+    w1, w2, w3, w4 = us
+    g0, mq, Ixx, Iyy, Izz, Cd, Ct, l = G0, MQ, IXX, IYY, IZZ, CD, CT, ARM
+    fx = sp.Matrix([
+        vbx * (2 * q1**2 + 2 * q2**2 - 1) - vby * (2 * q1 * q4 - 2 * q2 * q3) + vbz * (2 * q1 * q3 + 2 * q2 * q4),
+        vby * (2 * q1**2 + 2 * q3**2 - 1) + vbx * (2 * q1 * q4 + 2 * q2 * q3) - vbz * (2 * q1 * q2 - 2 * q3 * q4),
+        vbz * (2 * q1**2 + 2 * q4**2 - 1) - vbx * (2 * q1 * q3 - 2 * q2 * q4) + vby * (2 * q1 * q2 + 2 * q3 * q4),
+        -(q2 * wx) / 2 - (q3 * wy) / 2 - (q4 * wz) / 2,
+        (q1 * wx) / 2 - (q4 * wy) / 2 + (q3 * wz) / 2,
+        (q4 * wx) / 2 + (q1 * wy) / 2 - (q2 * wz) / 2,
+        (q2 * wy) / 2 - (q3 * wx) / 2 + (q1 * wz) / 2,
+        vby * wz - vbz * wy + g0 * (2 * q1 * q3 - 2 * q2 * q4),
+        vbz * wx - vbx * wz - g0 * (2 * q1 * q2 + 2 * q3 * q4),
+        vbx * wy - vby * wx - g0 * (2 * q1**2 + 2 * q4**2 - 1) + (Ct * (w1**2 + w2**2 + w3**2 + w4**2)) / mq,
+        -(Ct * l * (w1**2 + w2**2 - w3**2 - w4**2) - Iyy * wy * wz + Izz * wy * wz) / Ixx,
+        -(Ct * l * (w1**2 - w2**2 - w3**2 + w4**2) + Ixx * wx * wz - Izz * wx * wz) / Iyy,
+        -(Cd * (w1**2 - w2**2 + w3**2 - w4**2) - Ixx * wx * wy + Iyy * wx * wy) / Izz,
+    ])
+    allv = list(xs) + list(us)
+    J = fx.jacobian(allv)
+    _SYM_CACHE["f"] = sp.lambdify(allv, fx, "numpy")
+    _SYM_CACHE["J"] = sp.lambdify(allv, J, "numpy")
+    _SYM_CACHE["Jsym"] = J
+    return _SYM_CACHE["f"], _SYM_CACHE["J"]
+
+
+def jac_sympy(x, u):
+    """13x17 Jacobian [df/dx | df/du] from the sympy model (single point)."""
+    _, J = sympy_model()
+    return np.asarray(J(*list(x), *list(u)), dtype=np.float64).reshape(NX, NX + NU)
+
+
+def jac_fd(x, u, eps=1e-6):
+    """Central finite-difference Jacobian (sanity check only)."""
+    z = np.concatenate([x, u])
+    J = np.zeros((NX, NX + NU))
+    for i in range(NX + NU):
+        zp, zm = z.copy(), z.copy()
+        zp[i] += eps
+        zm[i] -= eps
+        J[:, i] = (f_expl(zp[:NX], zp[NX:]) - f_expl(zm[:NX], zm[NX:])) / (2 * eps)
+    return J
+
+
+# ----------------------------------------------------------------------------------------
+# integrator: classic RK4, one step per shooting interval, with forward
+# variational equations (the role of acados sim_erk + CasADi forw_vde, acados_mpc.cpp:84)
+# ----------------------------------------------------------------------------------------
+def rk4(x, u, dt=DT, steps=1):
+    x = np.asarray(x, dtype=np.float64)
+    h = dt / steps
+    for _ in range(steps):
+        k1 = f_expl(x, u)
+        k2 = f_expl(x + 0.5 * h * k1, u)
+        k3 = f_expl(x + 0.5 * h * k2, u)
+        k4 = f_expl(x + h * k3, u)
+        x = x + (h / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+    return x
+
+
+def rk4_sens(x, u, dt=DT, jac=jac_sympy):
+    """One RK4 step with forward sensitivities.  Returns (Phi, A[13x13], B[13x4])."""
+    x = np.asarray(x, dtype=np.float64)
+    u = np.asarray(u, dtype=np.float64)
+    S0 = np.hstack([np.eye(NX), np.zeros((NX, NU))])  # d x / d [x0 u]
+
+    def stage(xs, Ss):
+        J = jac(xs, u)
+        k = f_expl(xs, u)
+        K = J[:, :NX] @ Ss
+        K[:, NX:] += J[:, NX:]
+        return k, K
+
+    k1, K1 = stage(x, S0)
+    k2, K2 = stage(x + 0.5 * dt * k1, S0 + 0.5 * dt * K1)
+    k3, K3 = stage(x + 0.5 * dt * k2, S0 + 0.5 * dt * K2)
+    k4, K4 = stage(x + dt * k3, S0 + dt * K3)
+    phi = x + (dt / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+    S = S0 + (dt / 6.0) * (K1 + 2 * K2 + 2 * K3 + K4)
+    return phi, S[:, :NX].copy(), S[:, NX:].copy()
+
+
+def predict(x, u, delay=0.06, steps=4):
+    """Delay-compensating predictor (acados_estimator.cpp:573-593): RK4 over `delay`
+    with `steps` sub-steps (4 steps of 0.015)."""
+    return rk4(x, u, dt=delay, steps=steps)
+
+
+# ----------------------------------------------------------------------------------------
+# Gauss-Newton QP of one RTI step (generate_c_code.py:62-146, acados_mpc.cpp:581-594)
+# ----------------------------------------------------------------------------------------
+class StageQP:
+    """Stage-wise data of the RTI QP in step variables (dx, du).
+
+        min  sum_k 1/2 dx'Q dx + q_k'dx + 1/2 du'R du + r_k'du  + 1/2 dx_N'QN dx_N + q_N'dx_N
+        s.t. dx_0 = x0 - xbar_0 ;  dx_{k+1} = A_k dx_k + B_k du_k + b_k
+             lb_k <= du_k <= ub_k        (lb_k = U_MIN - ubar_k, ub_k = U_MAX - ubar_k)
+    """
+
+    def __init__(self, N):
+        self.N = N
+        self.A = np.zeros((N, NX, NX))
+        self.B = np.zeros((N, NX, NU))
+        self.b = np.zeros((N, NX))
+        self.q = np.zeros((N + 1, NX))
+        self.r = np.zeros((N, NU))
+        self.lb = np.zeros((N, NU))
+        self.ub = np.zeros((N, NU))
+        self.dx0 = np.zeros(NX)
+        self.Qd = Q_DIAG.copy()
+        self.Rd = R_DIAG.copy()
+        self.QNd = QN_DIAG.copy()
+
+
+def build_qp(xbar, ubar, x0, yref, yref_e, dt=DT, jac=jac_sympy,
+             u_min=U_MIN, u_max=U_MAX):
+    """xbar (N+1,13), ubar (N,4): current iterate; yref (N,17); yref_e (13)."""
+    N = ubar.shape[0]
+    qp = StageQP(N)
+    for k in range(N):
+        phi, A, B = rk4_sens(xbar[k], ubar[k], dt, jac)
+        qp.A[k], qp.B[k] = A, B
+        qp.b[k] = phi - xbar[k + 1]
+        qp.q[k] = Q_DIAG * (xbar[k] - yref[k, :NX])
+        qp.r[k] = R_DIAG * (ubar[k] - yref[k, NX:])
+        qp.lb[k] = u_min - ubar[k]
+        qp.ub[k] = u_max - ubar[k]
+    qp.q[N] = QN_DIAG * (xbar[N] - yref_e)
+    qp.dx0 = x0 - xbar[0]
+    return qp
+
+
+def condense(qp: StageQP):
+    """Full condensing: dx = G du + g  ->  dense QP in du (4N variables)."""
+    N = qp.N
+    nU = N * NU
+    Gam = np.zeros(((N + 1) * NX, nU))
+    g = np.zeros((N + 1) * NX)
+    g[:NX] = qp.dx0
+    for k in range(N):
+        r0, r1 = k * NX, (k + 1) * NX
+        Gam[r1:r1 + NX, :] = qp.A[k] @ Gam[r0:r1, :]
+        Gam[r1:r1 + NX, k * NU:(k + 1) * NU] += qp.B[k]
+        g[r1:r1 + NX] = qp.A[k] @ g[r0:r1] + qp.b[k]
+    Qbar = np.concatenate([np.tile(qp.Qd, N), qp.QNd])
+    qbar = qp.q.reshape(-1)
+    Rbar = np.tile(qp.Rd, N)
+    H = (Gam.T * Qbar) @ Gam + np.diag(Rbar)
+    h = Gam.T @ (Qbar * g + qbar) + qp.r.reshape(-1)
+    return H, h, Gam, g
+
+
+def solve_qp_dense(qp: StageQP, tol=1e-11, max_iter=100):
+    """Independent high-accuracy solver: primal-dual interior point on the condensed dense QP
+    (numpy Cholesky).  Returns dict(dx, du, lam_l, lam_u, iters)."""
+    H, h, Gam, g = condense(qp)
+    n = H.shape[0]
+    lb = qp.lb.reshape(-1)
+    ub = qp.ub.reshape(-1)
+    v = np.linalg.solve(H, -h)
+    if np.all(v > lb) and np.all(v < ub):
+        lam_l = np.zeros(n)
+        lam_u = np.zeros(n)
+        it = 0
+    else:
+        v = np.clip(v, lb + 0.05 * (ub - lb), ub - 0.05 * (ub - lb))
+        tl, tu = v - lb, ub - v
+        lam_l = np.ones(n)
+        lam_u = np.ones(n)
+        for it in range(1, max_iter + 1):
+            rg = H @ v + h - lam_l + lam_u
+            mu = (lam_l @ tl + lam_u @ tu) / (2 * n)
+            if max(np.abs(rg).max(), (lam_l * tl).max(), (lam_u * tu).max()) < tol or mu < 1e-15:
+                break
+
+            def newton(sig_mu, cl, cu):
+                D = lam_l / tl + lam_u / tu
+                rhs = -rg + (sig_mu - cl) / tl - lam_l - (sig_mu - cu) / tu + lam_u
+                dv = np.linalg.solve(H + np.diag(D), rhs)
+                dtl, dtu = dv, -dv
+                dll = (sig_mu - cl) / tl - lam_l - lam_l * dtl / tl
+                dlu = (sig_mu - cu) / tu - lam_u - lam_u * dtu / tu
+                return dv, dtl, dtu, dll, dlu
+
+            def steplen(dtl, dtu, dll, dlu):
+                a = 1.0
+                for z, dz in ((tl, dtl), (tu, dtu), (lam_l, dll), (lam_u, dlu)):
+                    m = dz < 0
+                    if m.any():
+                        a = min(a, float((-z[m] / dz[m]).min()))
+                return a
+
+            dv, dtl, dtu, dll, dlu = newton(0.0, 0.0, 0.0)
+            a = steplen(dtl, dtu, dll, dlu)
+            mu_aff = ((lam_l + a * dll) @ (tl + a * dtl) + (lam_u + a * dlu) @ (tu + a * dtu)) / (2 * n)
+            sig = (mu_aff / mu) ** 3
+            dv, dtl, dtu, dll, dlu = newton(sig * mu, dll * dtl, dlu * dtu)
+            a = min(1.0, 0.995 * steplen(dtl, dtu, dll, dlu))
+            v = v + a * dv
+            tl, tu = tl + a * dtl, tu + a * dtu
+            lam_l, lam_u = lam_l + a * dll, lam_u + a * dlu
+    dx = (Gam @ v + g).reshape(qp.N + 1, NX)
+    return dict(dx=dx, du=v.reshape(qp.N, NU), lam_l=lam_l.reshape(qp.N, NU),
+                lam_u=lam_u.reshape(qp.N, NU), iters=it)
+
+
+def kkt_residual(qp: StageQP, dx, du, lam_l, lam_u):
+    """Independent optimality check of a candidate QP solution: recovers the costates pi from
+    the backward adjoint recursion and returns the max-norm of (stationarity in du,
+    dynamics, bound violation, complementarity, negative multipliers)."""
+    N = qp.N
+    pi = np.zeros((N + 1, NX))
+    pi[N] = qp.QNd * dx[N] + qp.q[N]
+    for k in range(N - 1, 0, -1):
+        pi[k] = qp.Qd * dx[k] + qp.q[k] + qp.A[k].T @ pi[k + 1]
+    res_g = 0.0
+    res_b = float(np.abs(dx[0] - qp.dx0).max())
+    for k in range(N):
+        rg = qp.Rd * du[k] + qp.r[k] + qp.B[k].T @ pi[k + 1] - lam_l[k] + lam_u[k]
+        res_g = max(res_g, float(np.abs(rg).max()))
+        rb = qp.A[k] @ dx[k] + qp.B[k] @ du[k] + qp.b[k] - dx[k + 1]
+        res_b = max(res_b, float(np.abs(rb).max()))
+    viol = max(float((qp.lb - du).max()), float((du - qp.ub).max()), 0.0)
+    comp = max(float(np.abs(lam_l * (du - qp.lb)).max()), float(np.abs(lam_u * (qp.ub - du)).max()))
+    neg = max(float((-lam_l).max()), float((-lam_u).max()), 0.0)
+    return dict(res_g=res_g, res_b=res_b, viol=viol, comp=comp, neg=neg,
+                max=max(res_g, res_b, viol, comp, neg))
+
+
+# ----------------------------------------------------------------------------------------
+# Stage-wise Riccati interior point (the algorithm the HIP kernels implement; plays the role
+# of HPIPM d_ocp_qp_ipm_solve selected at generate_c_code.py:140).  See DESIGN.md section 4.
+# ----------------------------------------------------------------------------------------
+IPM_DEFAULTS = dict(tol=1e-8, max_iter=50, tau=0.995, thr0=1.0, lam0_min=1e-2)
+
+
+def _riccati_factor(qp, Rhat, rhat, absolute=True):
+    """Backward sweep.  Rhat (N,4) diagonal input Hessian, rhat (N,4) input gradient.
+    absolute=True : full affine problem (q, b, dx0 of the QP)  -> value function 1/2x'Px + p'x
+    absolute=False: homogeneous problem (q = 0, b = 0, dx0 = 0), only rhat drives it.
+    Returns per-stage K (N,4,13), Sinv (N,4,4), d (N,4)."""
+    N = qp.N
+    P = np.diag(qp.QNd)
+    p = qp.q[N].copy() if absolute else np.zeros(NX)
+    K = np.zeros((N, NU, NX))
+    Sinv = np.zeros((N, NU, NU))
+    d = np.zeros((N, NU))
+    for k in range(N - 1, -1, -1):
+        A, B = qp.A[k], qp.B[k]
+        PA, PB = P @ A, P @ B
+        S = np.diag(Rhat[k]) + B.T @ PB
+        G = B.T @ PA
+        hb = p + P @ qp.b[k] if absolute else p
+        rho = rhat[k] + B.T @ hb
+        Si = np.linalg.inv(S)
+        Si = 0.5 * (Si + Si.T)
+        K[k] = Si @ G
+        d[k] = Si @ rho
+        Sinv[k] = Si
+        P = np.diag(qp.Qd) + A.T @ PA - G.T @ K[k]
+        P = 0.5 * (P + P.T)
+        p = A.T @ hb - K[k].T @ rho
+        if absolute:
+            p = p + qp.q[k]
+    return K, Sinv, d
+
+
+def _riccati_forward(qp, K, d, absolute=True):
+    N = qp.N
+    x = qp.dx0.copy() if absolute else np.zeros(NX)
+    xs = np.zeros((N + 1, NX))
+    vs = np.zeros((N, NU))
+    xs[0] = x
+    for k in range(N):
+        v = -K[k] @ x - d[k]
+        x = qp.A[k] @ x + qp.B[k] @ v
+        if absolute:
+            x = x + qp.b[k]
+        vs[k] = v
+        xs[k + 1] = x
+    return xs, vs
+
+
+def _riccati_resolve(qp, K, Sinv, g):
+    """Re-use a factorisation for a new right-hand side g (N,4) on the input rows
+    (homogeneous problem).  Returns d (N,4) for _riccati_forward(absolute=False)."""
+    N = qp.N
+    p = np.zeros(NX)
+    d2 = np.zeros((N, NU))
+    for k in range(N - 1, -1, -1):
+        rho = g[k] + qp.B[k].T @ p
+        d2[k] = Sinv[k] @ rho
+        p = qp.A[k].T @ p - K[k].T @ rho
+    return d2
+
+
+def riccati_ipm(qp: StageQP, **opts):
+    """Mehrotra predictor-corrector on the box-constrained OCP-QP with stage-wise Riccati
+    solves.
+
+    Start = unconstrained minimiser (one absolute Riccati solve); if it satisfies the bounds
+    it is the solution (lam = 0) and is returned.  Otherwise slacks/multipliers are shifted
+    positive and Newton steps are taken in *delta* form: the x-stationarity rows and the
+    dynamics rows of the KKT system hold exactly at the start and the Newton system is linear
+    in them, so their right-hand sides stay zero; the input-stationarity residual r_g scales
+    by (1 - alpha) per step and is carried as data; the slack residual rho = v - lb - t is
+    recomputed locally.  One factorisation + two homogeneous solves per iteration."""
+    o = dict(IPM_DEFAULTS)
+    o.update(opts)
+    N = qp.N
+    nc = 2 * NU * N
+    lb, ub = qp.lb, qp.ub
+    Rd = np.tile(qp.Rd, (N, 1))
+    K, Sinv, d = _riccati_factor(qp, Rd, qp.r, absolute=True)
+    xs, v = _riccati_forward(qp, K, d, absolute=True)
+    info = dict(iters=0, status=0, factorizations=1)
+    if np.all(v >= lb) and np.all(v <= ub):
+        z = np.zeros_like(v)
+        return dict(dx=xs, du=v, lam_l=z, lam_u=z.copy(), **info)
+    tl = np.maximum(v - lb, o["thr0"])
+    tu = np.maximum(ub - v, o["thr0"])
+    viol = max(float(np.maximum(lb - v, 0).max()), float(np.maximum(v - ub, 0).max()))
+    mu0 = max(o["lam0_min"], viol)
+    ll = mu0 / tl
+    lu = mu0 / tu
+    rg = -ll + lu  # R v + r + B'pi = 0 at the unconstrained start
+    status = 2
+    it = 0
+    while True:
+        rl = v - lb - tl
+        ru = ub - v - tu
+        mu = float((ll * tl).sum() + (lu * tu).sum()) / nc
+        res = max(float((ll * tl).max()), float((lu * tu).max()), float(np.abs(rg).max()),
+                  float(np.abs(rl).max()), float(np.abs(ru).max()))
+        if res <= o["tol"]:
+            status = 0
+            break
+        if it >= o["max_iter"]:
+            break
+        it += 1
+        Dl, Du = ll / tl, lu / tu
+        Rhat = Rd + Dl + Du
+        # predictor (sigma = 0, no second-order term)
+        g_aff = rg + ll + Dl * rl - lu - Du * ru
+        K, Sinv, d = _riccati_factor(qp, Rhat, g_aff, absolute=False)
+        info["factorizations"] += 1
+        _, dv_a = _riccati_forward(qp, K, d, absolute=False)
+        dtl_a = dv_a + rl
+        dtu_a = -dv_a + ru
+        dll_a = -ll - Dl * dtl_a
+        dlu_a = -lu - Du * dtu_a
+        a_aff = _steplen(tl, tu, ll, lu, dtl_a, dtu_a, dll_a, dlu_a)
+        mu_aff = float(((ll + a_aff * dll_a) * (tl + a_aff * dtl_a)).sum()
+                       + ((lu + a_aff * dlu_a) * (tu + a_aff * dtu_a)).sum()) / nc
+        sigma = (mu_aff / mu) ** 3
+        smu = sigma * mu
+        # corrector: same factorisation, right-hand side changes on the input rows only
+        cl = dll_a * dtl_a
+        cu = dlu_a * dtu_a
+        g_cor = (cl - smu) / tl - (cu - smu) / tu
+        d2 = _riccati_resolve(qp, K, Sinv, g_cor)
+        _, dv_c = _riccati_forward(qp, K, d2, absolute=False)
+        dv = dv_a + dv_c
+        dtl = dv + rl
+        dtu = -dv + ru
+        dll = (smu - cl) / tl - ll - Dl * dtl
+        dlu = (smu - cu) / tu - lu - Du * dtu
+        a = min(1.0, o["tau"] * _steplen(tl, tu, ll, lu, dtl, dtu, dll, dlu))
+        v = v + a * dv
+        tl, tu = tl + a * dtl, tu + a * dtu
+        ll, lu = ll + a * dll, lu + a * dlu
+        rg = (1.0 - a) * rg
+    info.update(iters=it, status=status)
+    x = qp.dx0.copy()
+    xs = np.zeros((N + 1, NX))
+    xs[0] = x
+    for k in range(N):
+        x = qp.A[k] @ x + qp.B[k] @ v[k] + qp.b[k]
+        xs[k + 1] = x
+    return dict(dx=xs, du=v, lam_l=ll, lam_u=lu, **info)
+
+
+def _steplen(tl, tu, ll, lu, dtl, dtu, dll, dlu):
+    a = 1.0
+    for z, dz in ((tl, dtl), (tu, dtu), (ll, dll), (lu, dlu)):
+        m = dz < 0
+        if m.any():
+            a = min(a, float((-z[m] / dz[m]).min()))
+    return a
+
+
+# ----------------------------------------------------------------------------------------
+# One SQP-RTI step and the closed loop around it (acados_mpc.cpp:427-670)
+# ----------------------------------------------------------------------------------------
+def regulation_yref(N, xyz, uss=HOV_W):
+    """Reference window of the Regulation policy (acados_mpc.cpp:435-454)."""
+    row = np.zeros(NY)
+    row[0:3] = xyz
+    row[3] = 1.0
+    row[13:17] = uss
+    yref = np.tile(row, (N, 1))
+    return yref, row[:NX].copy()
+
+
+def tracking_yref(traj, it, N):
+    """Reference window of the Tracking policy (acados_mpc.cpp:460-485): rows it..it+N."""
+    win = traj[it:it + N + 1]
+    return win[:N].copy(), win[N, :NX].copy()
+
+
+class RTISolver:
+    """SQP real-time iteration: one QP per call, full step, iterate persists, no shift
+    (acados SQP_RTI as configured at generate_c_code.py:140-146; warm start = the persistent
+    nlp_out of acados_mpc.cpp:77).  init='acados' is SURVEY App. D-3 (x_k = codegen x0,
+    u_k = 0); init='hover' sets x_k = first x0, u_k = hover speed."""
+
+    def __init__(self, N=N_DEFAULT, dt=DT, init="acados", qp_solver="riccati_ipm", jac=jac_sympy,
+                 **ipm_opts):
+        self.N, self.dt = N, dt
+        self.x = np.tile(np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0]), (N + 1, 1))
+        self.u = np.zeros((N, NU))
+        self.init = init
+        self.first = True
+        self.qp_solver = qp_solver
+        self.jac = jac
+        self.ipm_opts = ipm_opts
+        self.last_qp = None
+        self.last_sol = None
+
+    def step(self, x0, yref, yref_e):
+        if self.first and self.init == "hover":
+            self.x[:] = x0
+            self.u[:] = HOV_W
+        self.first = False
+        qp = build_qp(self.x, self.u, np.asarray(x0, dtype=np.float64), yref, yref_e, self.dt, self.jac)
+        if self.qp_solver == "riccati_ipm":
+            sol = riccati_ipm(qp, **self.ipm_opts)
+        else:
+            sol = solve_qp_dense(qp)
+            sol["status"] = 0
+        self.x = self.x + sol["dx"]
+        self.u = self.u + sol["du"]
+        self.last_qp, self.last_sol = qp, sol
+        return dict(u0=self.u[0].copy(), u1=self.u[1].copy(), x4=self.x[4].copy(),
+                    status=sol["status"], iters=sol["iters"])
+
+
+def sample_hover_x0(rng, n, center=(0.0, 0.0, 0.4), scale=1.0):
+    """Synthetic perturbed hover states."""
+    pos = np.asarray(center) + scale * rng.uniform(-0.3, 0.3, (n, 3))
+    roll = scale * np.deg2rad(rng.uniform(-10, 10, n))
+    pitch = scale * np.deg2rad(rng.uniform(-10, 10, n))
+    yaw = scale * np.deg2rad(rng.uniform(-20, 20, n))
+    cr, sr, cp, sp_, cy, sy = np.cos(roll / 2), np.sin(roll / 2), np.cos(pitch / 2), np.sin(pitch / 2), np.cos(yaw / 2), np.sin(yaw / 2)
+    qw = cr * cp * cy + sr * sp_ * sy
+    qx = sr * cp * cy - cr * sp_ * sy
+    qy = cr * sp_ * cy + sr * cp * sy
+    qz = cr * cp * sy - sr * sp_ * cy
+    sgn = np.where(qw < 0, -1.0, 1.0)
+    quat = np.stack([qw, qx, qy, qz], axis=1) * sgn[:, None]
+    vel = scale * rng.uniform(-0.5, 0.5, (n, 3))
+    rate = scale * rng.uniform(-1.0, 1.0, (n, 3))
+    return np.concatenate([pos, quat, vel, rate], axis=1)

@@ -1,0 +1,110 @@
+"""ctypes binding of oracle/libcfnmpc_oracle.so (the plain-C CPU restatement).
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never from the product package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcfnmpc_oracle.so")
+
+NX, NU, NY = 13, 4, 17
+
+
+class Opts(C.Structure):
+    _fields_ = [("N", C.c_int), ("dt", C.c_double), ("W", C.c_double * NY), ("WN", C.c_double * NX),
+                ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
+                ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
+                ("lam0_min", C.c_double)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "cfnmpc_ref.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.cfo_rti_step.restype = C.c_int
+        _lib.cfo_qp_solve.restype = C.c_int
+    return _lib
+
+
+def default_opts(N=50, **kw):
+    o = Opts()
+    lib().cfo_default_opts(C.byref(o))
+    o.N = N
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f(x, u):
+    x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+    out = np.empty(NX)
+    lib().cfo_f(_p(x), _p(u), _p(out))
+    return out
+
+
+def jac(x, u):
+    x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+    J = np.empty((NX, NY))
+    lib().cfo_jac(_p(x), _p(u), _p(J))
+    return J
+
+
+def rk4_sens(x, u, dt=0.015):
+    x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+    phi, A, B = np.empty(NX), np.empty((NX, NX)), np.empty((NX, NU))
+    lib().cfo_rk4_sens(_p(x), _p(u), C.c_double(dt), _p(phi), _p(A), _p(B))
+    return phi, A, B
+
+
+def sim(x, u, T=0.06, steps=4):
+    x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+    xn = np.empty_like(x)
+    lib().cfo_sim(C.c_int(x.shape[0]), _p(x), _p(u), C.c_double(T), C.c_int(steps), _p(xn))
+    return xn
+
+
+def rti_step(opts, x_it, u_it, x0, yref, yref_e, nthreads=1):
+    """In-place RTI step on C-contiguous float64 arrays.  Returns (status, iters, res, threads)."""
+    B = x0.shape[0]
+    for a in (x_it, u_it, x0, yref, yref_e):
+        assert a.dtype == np.float64 and a.flags.c_contiguous
+    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); res = np.empty(B)
+    used = lib().cfo_rti_step(C.byref(opts), C.c_int(B), _p(x_it), _p(u_it), _p(x0), _p(yref), _p(yref_e),
+                              _p(status), _p(iters), _p(res), C.c_int(nthreads))
+    return status, iters, res, used
+
+
+def linearise(opts, x_it, u_it, x0, yref, yref_e):
+    N = opts.N
+    A = np.empty((N, NX, NX)); Bm = np.empty((N, NX, NU)); b = np.empty((N, NX))
+    q = np.empty((N + 1, NX)); r = np.empty((N, NU))
+    lib().cfo_linearise(C.byref(opts), _p(x_it), _p(u_it), _p(x0), _p(yref), _p(yref_e), _p(A), _p(Bm), _p(b), _p(q), _p(r))
+    return A, Bm, b, q, r
+
+
+def qp_solve(opts, x_it, u_it, x0, yref, yref_e):
+    N = opts.N
+    dx = np.empty((N + 1, NX)); du = np.empty((N, NU)); ll = np.empty((N, NU)); lu = np.empty((N, NU))
+    it = C.c_int(0); res = C.c_double(0)
+    st = lib().cfo_qp_solve(C.byref(opts), _p(x_it), _p(u_it), _p(x0), _p(yref), _p(yref_e), _p(dx), _p(du), _p(ll), _p(lu), C.byref(it), C.byref(res))
+    return dict(dx=dx, du=du, lam_l=ll, lam_u=lu, status=st, iters=it.value, res=res.value)
