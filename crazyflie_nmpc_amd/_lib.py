@@ -1,0 +1,70 @@
+"""ctypes binding of libcfnmpc.so (include/cfnmpc.h).  Fails loudly when the library is absent:
+the product has no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+NX, NU, NY, NYN = 13, 4, 17, 13
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcfnmpc.so")
+
+# every symbol include/cfnmpc.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "cfnmpc_default_opts", "cfnmpc_create", "cfnmpc_free", "cfnmpc_batch", "cfnmpc_horizon",
+    "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_init_iterate",
+    "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_get_u", "cfnmpc_get_x",
+    "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise",
+    "cfnmpc_version",
+]
+
+
+class Opts(C.Structure):
+    """struct cfnmpc_opts"""
+    _fields_ = [("N", C.c_int), ("dt", C.c_double), ("W", C.c_double * NY), ("WN", C.c_double * NYN),
+                ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
+                ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
+                ("lam0_min", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C crazyflie_nmpc_amd/csrc). "
+            "crazyflie_nmpc_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dbl, i32 = C.c_void_p, C.c_int, C.c_double, C.c_int
+    L.cfnmpc_default_opts.argtypes = [C.POINTER(Opts)]
+    L.cfnmpc_default_opts.restype = None
+    L.cfnmpc_create.argtypes = [C.POINTER(vp), i32, C.POINTER(Opts)]
+    L.cfnmpc_free.argtypes = [vp]
+    L.cfnmpc_batch.argtypes = [vp]
+    L.cfnmpc_horizon.argtypes = [vp]
+    L.cfnmpc_workspace_bytes.argtypes = [vp]
+    L.cfnmpc_workspace_bytes.restype = C.c_ulonglong
+    L.cfnmpc_set_x0.argtypes = [vp, vp, i32, vp]
+    L.cfnmpc_set_yref.argtypes = [vp, vp, vp, i32, vp]
+    L.cfnmpc_init_iterate.argtypes = [vp, i32, vp]
+    L.cfnmpc_set_iterate.argtypes = [vp, vp, vp, i32, vp]
+    L.cfnmpc_get_iterate.argtypes = [vp, vp, vp, i32, vp]
+    L.cfnmpc_solve.argtypes = [vp, i32, vp]
+    L.cfnmpc_get_u.argtypes = [vp, i32, vp, i32, vp]
+    L.cfnmpc_get_x.argtypes = [vp, i32, vp, i32, vp]
+    L.cfnmpc_get_stats.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.cfnmpc_sim.argtypes = [i32, vp, vp, dbl, i32, vp, i32, vp]
+    L.cfnmpc_debug_get_linearisation.argtypes = [vp, vp, vp, vp]
+    L.cfnmpc_debug_linearise.argtypes = [vp, vp]
+    L.cfnmpc_version.restype = C.c_char_p
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int or fn.restype is None or name in ("cfnmpc_version", "cfnmpc_workspace_bytes"):
+            continue
+    _lib = L
+    return L

@@ -1,0 +1,286 @@
+// cfnmpc_api.cpp -- C-ABI of the batch engine (include/cfnmpc.h) over the HIP kernels.
+// Host side only: allocation of the SoA workspace, AoS<->SoA staging, kernel launches.
+// There is no CPU fallback: without a usable HIP device cfnmpc_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/cfnmpc.h"
+#include "cfnmpc_model.hpp"
+#include "cfnmpc_ws.hpp"
+
+struct cfnmpc_solver {
+    cfn::Params P;
+    int device;
+    std::vector<void*> allocs;
+    double* stage_buf;  // device staging buffer for AoS transfers (largest AoS array)
+    size_t stage_doubles;
+    unsigned long long bytes;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            std::fprintf(stderr, "cfnmpc: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_),   \
+                         __FILE__, __LINE__);                                                       \
+            return CFNMPC_EHIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+
+template <typename T>
+int dev_alloc(cfnmpc_solver* s, T** p, size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) return CFNMPC_ENOMEM;
+    if (hipMemset(q, 0, count * sizeof(T)) != hipSuccess) return CFNMPC_EHIP;
+    s->allocs.push_back(q);
+    s->bytes += count * sizeof(T);
+    *p = static_cast<T*>(q);
+    return CFNMPC_OK;
+}
+
+// copy an AoS array [B][S][E] from the caller into an SoA field
+int put_field(cfnmpc_solver* s, const double* src, int on_device, int S, int E, double* soa, hipStream_t st) {
+    const cfn::Params& P = s->P;
+    const size_t n = (size_t)P.B * S * E;
+    const double* dsrc = src;
+    if (!on_device) {
+        if (n > s->stage_doubles) return CFNMPC_EINVAL;
+        HIP_TRY(hipMemcpyAsync(s->stage_buf, src, n * sizeof(double), hipMemcpyHostToDevice, st));
+        dsrc = s->stage_buf;
+    }
+    cfn::launch_aos2soa(P.B, P.Bp, S, E, dsrc, soa, st);
+    HIP_TRY(hipGetLastError());
+    if (!on_device) HIP_TRY(hipStreamSynchronize(st));  // staging buffer is reused
+    return CFNMPC_OK;
+}
+
+// copy stages s0..s0+S-1 of an SoA field into the caller's AoS array [B][S][E]
+int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int s0, int Stot, const double* soa,
+              hipStream_t st) {
+    const cfn::Params& P = s->P;
+    const size_t n = (size_t)P.B * S * E;
+    double* ddst = dst;
+    if (!on_device) {
+        if (n > s->stage_doubles) return CFNMPC_EINVAL;
+        ddst = s->stage_buf;
+    }
+    cfn::launch_soa2aos(P.B, P.Bp, S, E, s0, Stot, soa, ddst, st);
+    HIP_TRY(hipGetLastError());
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(dst, ddst, n * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return CFNMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* cfnmpc_version(void) { return "cfnmpc 0.1 (gfx950, lane-per-instance v1)"; }
+
+void cfnmpc_default_opts(cfnmpc_opts* o) {
+    // generate_c_code.py:41-42,63-84,109,133-134
+    static const double W[CFNMPC_NY] = {120.0, 100.0, 100.0, 1e-3, 1e-3, 1e-3, 1e-3, 0.7, 1.0,
+                                        4.0,   1e-5,  1e-5,  10.0, 0.06, 0.06, 0.06, 0.06};
+    o->N = 50;
+    o->dt = 0.75 / 50;
+    for (int i = 0; i < CFNMPC_NY; i++) o->W[i] = W[i];
+    for (int i = 0; i < CFNMPC_NYN; i++) o->WN[i] = 50.0 * W[i];
+    o->u_min = 0.0;
+    o->u_max = 22.0;
+    o->tol = 1e-8;
+    o->max_iter = 50;
+    o->tau = 0.995;
+    o->thr0 = 1.0;
+    o->lam0_min = 1e-2;
+}
+
+int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
+    if (!out || batch <= 0) return CFNMPC_EINVAL;
+    cfnmpc_opts o;
+    if (opts) o = *opts; else cfnmpc_default_opts(&o);
+    if (o.N < 5 || o.N > 4096 || !(o.dt > 0) || !(o.u_max > o.u_min) || o.max_iter < 0) return CFNMPC_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        std::fprintf(stderr, "cfnmpc: no HIP device available (this library has no CPU path)\n");
+        return CFNMPC_EHIP;
+    }
+    cfnmpc_solver* s = new (std::nothrow) cfnmpc_solver();
+    if (!s) return CFNMPC_ENOMEM;
+    s->bytes = 0;
+    if (hipGetDevice(&s->device) != hipSuccess) { delete s; return CFNMPC_EHIP; }
+    cfn::Params& P = s->P;
+    std::memset(&P, 0, sizeof P);
+    P.B = batch;
+    P.Bp = (batch + 63) / 64 * 64;
+    P.N = o.N;
+    P.dt = o.dt;
+    for (int i = 0; i < 17; i++) P.W[i] = o.W[i];
+    for (int i = 0; i < 13; i++) P.WN[i] = o.WN[i];
+    P.u_min = o.u_min; P.u_max = o.u_max; P.tol = o.tol; P.tau = o.tau; P.thr0 = o.thr0;
+    P.lam0_min = o.lam0_min; P.max_iter = o.max_iter;
+    const size_t Bp = P.Bp, N = P.N;
+    int rc = CFNMPC_OK;
+#define ALLOC(field, cnt) if (rc == CFNMPC_OK) rc = dev_alloc(s, &P.field, (size_t)(cnt) * Bp)
+    ALLOC(xit, (N + 1) * 13); ALLOC(uit, N * 4); ALLOC(x0, 13); ALLOC(yref, N * 17); ALLOC(yref_e, 13);
+    ALLOC(A, N * cfn::A_NNZ); ALLOC(Bm, N * 52); ALLOC(b, N * 13);
+    ALLOC(K, N * 52); ALLOC(Sinv, N * 10); ALLOC(d, N * 4);
+    ALLOC(v, N * 4); ALLOC(tl, N * 4); ALLOC(tu, N * 4); ALLOC(ll, N * 4); ALLOC(lu, N * 4);
+    ALLOC(rg, N * 4); ALLOC(dva, N * 4); ALLOC(dvc, N * 4);
+    ALLOC(status, 1); ALLOC(iters, 1); ALLOC(res, 1);
+#undef ALLOC
+    s->stage_doubles = (size_t)batch * (N + 1) * 17;
+    if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->stage_buf, s->stage_doubles);
+    if (rc != CFNMPC_OK) { cfnmpc_free(s); return rc; }
+    // default iterate = what acados_create() leaves behind
+    cfn::launch_init_iterate(P, CFNMPC_INIT_ACADOS, nullptr);
+    if (hipDeviceSynchronize() != hipSuccess) { cfnmpc_free(s); return CFNMPC_EHIP; }
+    *out = s;
+    return CFNMPC_OK;
+}
+
+int cfnmpc_free(cfnmpc_solver* s) {
+    if (!s) return CFNMPC_EINVAL;
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+    return CFNMPC_OK;
+}
+
+int cfnmpc_batch(const cfnmpc_solver* s) { return s ? s->P.B : CFNMPC_EINVAL; }
+int cfnmpc_horizon(const cfnmpc_solver* s) { return s ? s->P.N : CFNMPC_EINVAL; }
+unsigned long long cfnmpc_workspace_bytes(const cfnmpc_solver* s) { return s ? s->bytes : 0ull; }
+
+int cfnmpc_set_x0(cfnmpc_solver* s, const double* x0, int on_device, void* stream) {
+    if (!s || !x0) return CFNMPC_EINVAL;
+    return put_field(s, x0, on_device, 1, 13, s->P.x0, (hipStream_t)stream);
+}
+
+int cfnmpc_set_yref(cfnmpc_solver* s, const double* yref, const double* yref_e, int on_device, void* stream) {
+    if (!s || !yref || !yref_e) return CFNMPC_EINVAL;
+    int rc = put_field(s, yref, on_device, s->P.N, 17, s->P.yref, (hipStream_t)stream);
+    if (rc != CFNMPC_OK) return rc;
+    return put_field(s, yref_e, on_device, 1, 13, s->P.yref_e, (hipStream_t)stream);
+}
+
+int cfnmpc_init_iterate(cfnmpc_solver* s, int mode, void* stream) {
+    if (!s || (mode != CFNMPC_INIT_ACADOS && mode != CFNMPC_INIT_HOVER)) return CFNMPC_EINVAL;
+    cfn::launch_init_iterate(s->P, mode, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return CFNMPC_OK;
+}
+
+int cfnmpc_set_iterate(cfnmpc_solver* s, const double* x, const double* u, int on_device, void* stream) {
+    if (!s || !x || !u) return CFNMPC_EINVAL;
+    int rc = put_field(s, x, on_device, s->P.N + 1, 13, s->P.xit, (hipStream_t)stream);
+    if (rc != CFNMPC_OK) return rc;
+    return put_field(s, u, on_device, s->P.N, 4, s->P.uit, (hipStream_t)stream);
+}
+
+int cfnmpc_get_iterate(cfnmpc_solver* s, double* x, double* u, int on_device, void* stream) {
+    if (!s || !x || !u) return CFNMPC_EINVAL;
+    int rc = get_field(s, x, on_device, s->P.N + 1, 13, 0, s->P.N + 1, s->P.xit, (hipStream_t)stream);
+    if (rc != CFNMPC_OK) return rc;
+    return get_field(s, u, on_device, s->P.N, 4, 0, s->P.N, s->P.uit, (hipStream_t)stream);
+}
+
+int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
+    if (!s || n_rti < 1) return CFNMPC_EINVAL;
+    for (int it = 0; it < n_rti; it++) {
+        cfn::launch_linearise(s->P, (hipStream_t)stream);
+        cfn::launch_qp(s->P, (hipStream_t)stream);
+    }
+    HIP_TRY(hipGetLastError());
+    return CFNMPC_OK;
+}
+
+int cfnmpc_get_u(cfnmpc_solver* s, int stage, double* u, int on_device, void* stream) {
+    if (!s || !u || stage < 0 || stage >= s->P.N) return CFNMPC_EINVAL;
+    return get_field(s, u, on_device, 1, 4, stage, s->P.N, s->P.uit, (hipStream_t)stream);
+}
+
+int cfnmpc_get_x(cfnmpc_solver* s, int stage, double* x, int on_device, void* stream) {
+    if (!s || !x || stage < 0 || stage > s->P.N) return CFNMPC_EINVAL;
+    return get_field(s, x, on_device, 1, 13, stage, s->P.N + 1, s->P.xit, (hipStream_t)stream);
+}
+
+int cfnmpc_get_stats(cfnmpc_solver* s, int* status, int* qp_iter, double* res, int on_device, void* stream) {
+    if (!s) return CFNMPC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const size_t B = s->P.B;
+    if (status) HIP_TRY(hipMemcpyAsync(status, s->P.status, B * sizeof(int), kind, st));
+    if (qp_iter) HIP_TRY(hipMemcpyAsync(qp_iter, s->P.iters, B * sizeof(int), kind, st));
+    if (res) HIP_TRY(hipMemcpyAsync(res, s->P.res, B * sizeof(double), kind, st));
+    if (!on_device) HIP_TRY(hipStreamSynchronize(st));
+    return CFNMPC_OK;
+}
+
+int cfnmpc_sim(int batch, const double* x, const double* u, double T, int steps, double* xn, int on_device,
+               void* stream) {
+    if (batch <= 0 || !x || !u || !xn || steps < 1 || !(T > 0)) return CFNMPC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (on_device) {
+        cfn::launch_sim(batch, x, u, T, steps, xn, st);
+        HIP_TRY(hipGetLastError());
+        return CFNMPC_OK;
+    }
+    double *dx = nullptr, *du = nullptr, *dn = nullptr;
+    const size_t B = batch;
+    if (hipMalloc((void**)&dx, B * 13 * 8) != hipSuccess || hipMalloc((void**)&du, B * 4 * 8) != hipSuccess ||
+        hipMalloc((void**)&dn, B * 13 * 8) != hipSuccess) {
+        (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dn);
+        return CFNMPC_ENOMEM;
+    }
+    int rc = CFNMPC_OK;
+    if (hipMemcpyAsync(dx, x, B * 13 * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(du, u, B * 4 * 8, hipMemcpyHostToDevice, st) != hipSuccess)
+        rc = CFNMPC_EHIP;
+    if (rc == CFNMPC_OK) {
+        cfn::launch_sim(batch, dx, du, T, steps, dn, st);
+        if (hipMemcpyAsync(xn, dn, B * 13 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            rc = CFNMPC_EHIP;
+    }
+    (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dn);
+    return rc;
+}
+
+int cfnmpc_debug_linearise(cfnmpc_solver* s, void* stream) {
+    if (!s) return CFNMPC_EINVAL;
+    cfn::launch_linearise(s->P, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return CFNMPC_OK;
+}
+
+int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, double* A, double* Bm, double* b) {
+    if (!s || !A || !Bm || !b) return CFNMPC_EINVAL;
+    const cfn::Params& P = s->P;
+    const size_t Bp = P.Bp, N = P.N, B = P.B;
+    std::vector<double> ha(N * cfn::A_NNZ * Bp), hb(N * 52 * Bp), hv(N * 13 * Bp);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(ha.data(), P.A, ha.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hb.data(), P.Bm, hb.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hv.data(), P.b, hv.size() * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < B; i++)
+        for (size_t k = 0; k < N; k++) {
+            double* Ad = A + (i * N + k) * 169;
+            for (int r = 0; r < 13; r++)
+                for (int c = 0; c < 13; c++) {
+                    const int kind = cfn::a_kind(r, c);
+                    Ad[r * 13 + c] = kind == 0 ? 0.0 : (kind == 1 ? 1.0 : ha[(k * cfn::A_NNZ + cfn::a_idx(r, c)) * Bp + i]);
+                }
+            for (int e = 0; e < 52; e++) Bm[(i * N + k) * 52 + e] = hb[(k * 52 + e) * Bp + i];
+            for (int e = 0; e < 13; e++) b[(i * N + k) * 13 + e] = hv[(k * 13 + e) * Bp + i];
+        }
+    return CFNMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,170 @@
+"""Batch solver object over the C-ABI (include/cfnmpc.h).
+
+Mirrors, for B instances, the calls the reference node makes on its single generated solver
+(crazyflie_controller/src/acados_mpc.cpp): acados_create (:225) -> BatchSolver(...);
+lbx/ubx (:581-582) -> set_x0; yref (:590-594) -> set_yref; acados_solve (:611) -> solve;
+ocp_nlp_out_get u/x (:619-625) -> get_u / get_x; status -> stats.
+
+Arrays may be numpy (host, copied) or torch CUDA/HIP tensors (device pointers are handed to
+the library, the work is enqueued on torch's current stream).  torch is plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import NU, NX, NY, Opts
+
+INIT_ACADOS, INIT_HOVER = 0, 1
+
+
+class CfnmpcError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise CfnmpcError(f"{what} failed with code {rc}")
+
+
+def default_opts(**kw) -> Opts:
+    o = Opts()
+    _lib.lib().cfnmpc_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if k in ("W", "WN"):
+            arr = getattr(o, k)
+            for i, x in enumerate(v):
+                arr[i] = float(x)
+        else:
+            setattr(o, k, v)
+    return o
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+def _stream_ptr(a):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
+
+
+def _arg(a, shape, dtype=np.float64):
+    """-> (pointer, on_device, stream, keepalive)"""
+    if _is_torch(a):
+        import torch
+        want = {np.float64: torch.float64, np.int32: torch.int32}[dtype]
+        if not a.is_cuda or a.dtype != want or not a.is_contiguous() or tuple(a.shape) != tuple(shape):
+            raise ValueError(f"expected contiguous device tensor {shape} {want}, got {tuple(a.shape)} {a.dtype}")
+        return C.c_void_p(a.data_ptr()), 1, _stream_ptr(a), a
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    if arr.shape != tuple(shape):
+        raise ValueError(f"expected shape {shape}, got {arr.shape}")
+    return arr.ctypes.data_as(C.c_void_p), 0, C.c_void_p(0), arr
+
+
+class BatchSolver:
+    def __init__(self, batch: int, opts: Opts | None = None, **kw):
+        self._L = _lib.lib()
+        self.opts = opts if opts is not None else default_opts(**kw)
+        self.B = int(batch)
+        self.N = int(self.opts.N)
+        h = C.c_void_p()
+        _check(self._L.cfnmpc_create(C.byref(h), self.B, C.byref(self.opts)), "cfnmpc_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cfnmpc_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self._L.cfnmpc_workspace_bytes(self._h))
+
+    # ---- inputs
+    def set_x0(self, x0):
+        p, dev, st, _k = _arg(x0, (self.B, NX))
+        _check(self._L.cfnmpc_set_x0(self._h, p, dev, st), "cfnmpc_set_x0")
+
+    def set_yref(self, yref, yref_e):
+        p, dev, st, _k = _arg(yref, (self.B, self.N, NY))
+        pe, deve, _st, _k2 = _arg(yref_e, (self.B, NX))
+        if dev != deve:
+            raise ValueError("yref and yref_e must live on the same side")
+        _check(self._L.cfnmpc_set_yref(self._h, p, pe, dev, st), "cfnmpc_set_yref")
+
+    def init_iterate(self, mode=INIT_ACADOS, stream=None):
+        _check(self._L.cfnmpc_init_iterate(self._h, mode, C.c_void_p(stream or 0)), "cfnmpc_init_iterate")
+
+    def set_iterate(self, x, u):
+        p, dev, st, _k = _arg(x, (self.B, self.N + 1, NX))
+        pu, devu, _s, _k2 = _arg(u, (self.B, self.N, NU))
+        assert dev == devu
+        _check(self._L.cfnmpc_set_iterate(self._h, p, pu, dev, st), "cfnmpc_set_iterate")
+
+    # ---- solve
+    def solve(self, n_rti=1, stream=None):
+        _check(self._L.cfnmpc_solve(self._h, int(n_rti), C.c_void_p(stream or 0)), "cfnmpc_solve")
+
+    def linearise_only(self, stream=None):
+        _check(self._L.cfnmpc_debug_linearise(self._h, C.c_void_p(stream or 0)), "cfnmpc_debug_linearise")
+
+    # ---- outputs
+    def get_iterate(self):
+        x = np.empty((self.B, self.N + 1, NX)); u = np.empty((self.B, self.N, NU))
+        _check(self._L.cfnmpc_get_iterate(self._h, x.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_get_iterate")
+        return x, u
+
+    def get_u(self, stage, out=None):
+        if out is None:
+            out = np.empty((self.B, NU))
+        p, dev, st, _k = _arg(out, (self.B, NU))
+        _check(self._L.cfnmpc_get_u(self._h, int(stage), p, dev, st), "cfnmpc_get_u")
+        return out
+
+    def get_x(self, stage, out=None):
+        if out is None:
+            out = np.empty((self.B, NX))
+        p, dev, st, _k = _arg(out, (self.B, NX))
+        _check(self._L.cfnmpc_get_x(self._h, int(stage), p, dev, st), "cfnmpc_get_x")
+        return out
+
+    def stats(self):
+        st = np.empty(self.B, dtype=np.int32); it = np.empty(self.B, dtype=np.int32); rs = np.empty(self.B)
+        _check(self._L.cfnmpc_get_stats(self._h, st.ctypes.data_as(C.c_void_p), it.ctypes.data_as(C.c_void_p),
+                                        rs.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_get_stats")
+        return st, it, rs
+
+    def get_linearisation(self):
+        A = np.empty((self.B, self.N, NX, NX)); Bm = np.empty((self.B, self.N, NX, NU)); b = np.empty((self.B, self.N, NX))
+        _check(self._L.cfnmpc_debug_get_linearisation(self._h, A.ctypes.data_as(C.c_void_p), Bm.ctypes.data_as(C.c_void_p),
+                                                      b.ctypes.data_as(C.c_void_p)), "cfnmpc_debug_get_linearisation")
+        return A, Bm, b
+
+
+def sim(x, u, T=0.06, steps=4, out=None):
+    """Batched predictor / plant step (crazyflie_acados_sim_solve, acados_estimator.cpp:589)."""
+    L = _lib.lib()
+    B = x.shape[0]
+    if _is_torch(x):
+        import torch
+        if out is None:
+            out = torch.empty_like(x)
+        px, _d, st, _k = _arg(x, (B, NX)); pu, _d2, _s, _k2 = _arg(u, (B, NU)); po, _d3, _s3, _k3 = _arg(out, (B, NX))
+        _check(L.cfnmpc_sim(B, px, pu, float(T), int(steps), po, 1, st), "cfnmpc_sim")
+        return out
+    xa = np.ascontiguousarray(x, dtype=np.float64); ua = np.ascontiguousarray(u, dtype=np.float64)
+    if out is None:
+        out = np.empty_like(xa)
+    _check(L.cfnmpc_sim(B, xa.ctypes.data_as(C.c_void_p), ua.ctypes.data_as(C.c_void_p), float(T), int(steps),
+                        out.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_sim")
+    return out

@@ -1,0 +1,110 @@
+/* cfnmpc.h -- batch C-ABI of the MI355X-native Crazyflie SQP-RTI solve engine (libcfnmpc.so).
+ *
+ * This is the batch superset of the reference's generated-solver boundary.
+ * One `cfnmpc_solver` owns B independent NMPC instances (the reference owns exactly one, as
+ * process globals: crazyflie_controller/src/acados_mpc.cpp:76-82).  The acados-named drop-in
+ * (acados_create / acados_solve / ocp_nlp_*_set / ocp_nlp_out_get) lives in
+ * include/acados_solver_crazyflie.h and is this engine with B = 1.
+ *
+ * Conventions
+ *   - plain C, no torch / hip types in signatures; `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream);
+ *   - all arrays are FP64, AoS in the reference node's layouts:
+ *       x  : [B][13]  = xq yq zq qw qx qy qz vbx vby vbz wx wy wz   (acados_mpc.cpp:117-131)
+ *       u  : [B][4]   = w1..w4 [kRPM]                               (acados_mpc.cpp:133-138)
+ *       yref   : [B][N][17], yref_e : [B][13]                        (acados_mpc.cpp:584-594)
+ *   - `on_device` != 0: the pointer is device memory of the solver's GPU (no copy through the
+ *     host); == 0: host memory, copied synchronously;
+ *   - every call returns 0 on success, a negative CFNMPC_E* code otherwise; solver *status*
+ *     per instance follows acados: 0 success, 2 max. iterations, 4 QP failure.
+ *   - there is NO CPU fallback: if no HIP device is usable, cfnmpc_create fails.
+ */
+#ifndef CFNMPC_H
+#define CFNMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFNMPC_NX 13
+#define CFNMPC_NU 4
+#define CFNMPC_NY 17
+#define CFNMPC_NYN 13
+
+#define CFNMPC_OK 0
+#define CFNMPC_EINVAL (-1)  /* bad argument                              */
+#define CFNMPC_EHIP (-2)    /* HIP runtime error / no device             */
+#define CFNMPC_ENOMEM (-3)  /* device allocation failed                  */
+
+#define CFNMPC_INIT_ACADOS 0 /* x_k = [0,0,0,1,0..], u_k = 0 (generate_c_code.py:135) */
+#define CFNMPC_INIT_HOVER 1  /* x_k = current x0, u_k = hover speed                                      */
+
+typedef struct cfnmpc_solver cfnmpc_solver;
+
+/* Replaces the constants baked into the generated solver by
+ * crazyflie_controller/scripts/crazyflie_full_model/generate_c_code.py:41-146. */
+typedef struct cfnmpc_opts {
+    int N;               /* horizon length, generate_c_code.py:42 (50)                     */
+    double dt;           /* shooting interval Tf/N, generate_c_code.py:41-42 (0.015)       */
+    double W[CFNMPC_NY]; /* diag of stage weight W, generate_c_code.py:63-84               */
+    double WN[CFNMPC_NYN]; /* diag of terminal weight W_e = 50 Q, generate_c_code.py:109   */
+    double u_min, u_max; /* input box, generate_c_code.py:133-134 (0, 22)                  */
+    double tol;          /* QP: max-norm tolerance on all residuals (1e-8)                 */
+    int max_iter;        /* QP: interior-point iteration cap (50)                          */
+    double tau;          /* QP: fraction to the boundary (0.995)                           */
+    double thr0;         /* QP: slack floor of the starting point (1.0)                    */
+    double lam0_min;     /* QP: complementarity floor of the starting point (1e-2)         */
+} cfnmpc_opts;
+
+void cfnmpc_default_opts(cfnmpc_opts *opts);
+
+/* acados_create() / acados_free() equivalents (acados_mpc.cpp:225,418) for B instances on the
+ * calling thread's current HIP device. */
+int cfnmpc_create(cfnmpc_solver **out, int batch, const cfnmpc_opts *opts);
+int cfnmpc_free(cfnmpc_solver *s);
+int cfnmpc_batch(const cfnmpc_solver *s);
+int cfnmpc_horizon(const cfnmpc_solver *s);
+/* bytes of device workspace held by the solver */
+unsigned long long cfnmpc_workspace_bytes(const cfnmpc_solver *s);
+
+/* ocp_nlp_constraints_model_set(.., 0, "lbx"/"ubx", x0) equivalent (acados_mpc.cpp:581-582) */
+int cfnmpc_set_x0(cfnmpc_solver *s, const double *x0, int on_device, void *stream);
+/* ocp_nlp_cost_model_set(.., k, "yref", ..) for k = 0..N (acados_mpc.cpp:590-594) */
+int cfnmpc_set_yref(cfnmpc_solver *s, const double *yref, const double *yref_e, int on_device, void *stream);
+/* ocp_nlp_constraints_model_set(.., 0, "lbu"/"ubu", ..) is NOT offered per stage: the box is
+ * the global [u_min, u_max] of cfnmpc_opts (FIXED_U0 is 0 in the reference, acados_mpc.cpp:111). */
+
+/* Iterate (the persistent nlp_out of acados_mpc.cpp:77): initial guess, save / restore. */
+int cfnmpc_init_iterate(cfnmpc_solver *s, int mode, void *stream);
+int cfnmpc_set_iterate(cfnmpc_solver *s, const double *x /*[B][N+1][13]*/, const double *u /*[B][N][4]*/, int on_device, void *stream);
+int cfnmpc_get_iterate(cfnmpc_solver *s, double *x, double *u, int on_device, void *stream);
+
+/* acados_solve() equivalent (acados_mpc.cpp:611): n_rti consecutive SQP-RTI steps
+ * (linearise -> Riccati interior-point QP -> full step) for all B instances, asynchronous on
+ * `stream`.  The reference calls it with one step. */
+int cfnmpc_solve(cfnmpc_solver *s, int n_rti, void *stream);
+
+/* ocp_nlp_out_get(.., stage, "u"/"x", ..) equivalents (acados_mpc.cpp:619-625) */
+int cfnmpc_get_u(cfnmpc_solver *s, int stage, double *u /*[B][4]*/, int on_device, void *stream);
+int cfnmpc_get_x(cfnmpc_solver *s, int stage, double *x /*[B][13]*/, int on_device, void *stream);
+/* status (acados_solve() return value), QP iteration count, nlp_out->inf_norm_res stand-in
+ * (max-norm residual of the last QP).  Any pointer may be NULL. */
+int cfnmpc_get_stats(cfnmpc_solver *s, int *status /*[B]*/, int *qp_iter /*[B]*/, double *res /*[B]*/, int on_device, void *stream);
+
+/* crazyflie_acados_sim_solve() equivalent, batched (acados_estimator.cpp:573-593):
+ * xn = RK4(x, u) over T seconds in `steps` sub-steps.  Stateless. */
+int cfnmpc_sim(int batch, const double *x, const double *u, double T, int steps, double *xn, int on_device, void *stream);
+
+/* Kernel-level access for parity tests (oracle comparison of the linearisation):
+ * copies the stage blocks of the last linearisation, dense row-major:
+ * A [B][N][13][13], Bm [B][N][13][4], b [B][N][13] (host pointers). */
+int cfnmpc_debug_get_linearisation(cfnmpc_solver *s, double *A, double *Bm, double *b);
+/* runs only the linearisation kernel */
+int cfnmpc_debug_linearise(cfnmpc_solver *s, void *stream);
+
+const char *cfnmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFNMPC_H */

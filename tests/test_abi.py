@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/*.h declares.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src)
+    return sorted(set(n for n in names if not n.isupper()))
+
+
+def test_batch_abi_symbols_exported():
+    from crazyflie_nmpc_amd import _lib
+    L = _lib.lib()
+    declared = _declared("cfnmpc.h")
+    assert set(declared) == set(_lib.SYMBOLS), (declared, _lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_default_opts_match_reference_generator():
+    # generate_c_code.py:41-42,63-84,109,133-134
+    from crazyflie_nmpc_amd import default_opts
+    o = default_opts()
+    assert o.N == 50 and abs(o.dt - 0.015) < 1e-15
+    assert list(o.W) == [120.0, 100.0, 100.0, 1e-3, 1e-3, 1e-3, 1e-3, 0.7, 1.0, 4.0, 1e-5, 1e-5, 10.0, 0.06, 0.06, 0.06, 0.06]
+    assert all(abs(a - 50 * b) < 1e-12 for a, b in zip(o.WN, list(o.W)[:13]))
+    assert (o.u_min, o.u_max) == (0.0, 22.0)
+
+
+def test_no_gpu_means_loud_failure():
+    """The product has no CPU fallback: creating a solver without a HIP device must fail."""
+    import pytest
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    from crazyflie_nmpc_amd import BatchSolver
+    from crazyflie_nmpc_amd.solver import CfnmpcError
+    with pytest.raises(CfnmpcError):
+        BatchSolver(4)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "crazyflie_nmpc_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "cfnmpc_oracle" not in txt and "cfnmpc_ref" not in txt and "cref" not in txt.replace("cref_", ""), f
