@@ -15,7 +15,7 @@ SYMBOLS = [
     "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_init_iterate",
     "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_get_u", "cfnmpc_get_x",
     "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise",
-    "cfnmpc_version",
+    "cfnmpc_debug_get_head", "cfnmpc_version",
 ]
 
 
@@ -24,7 +24,7 @@ class Opts(C.Structure):
     _fields_ = [("N", C.c_int), ("dt", C.c_double), ("W", C.c_double * NY), ("WN", C.c_double * NYN),
                 ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
-                ("lam0_min", C.c_double)]
+                ("lam0_min", C.c_double), ("active_horizon", C.c_int)]
 
 
 _lib = None
@@ -59,7 +59,8 @@ def lib():
     L.cfnmpc_get_x.argtypes = [vp, i32, vp, i32, vp]
     L.cfnmpc_get_stats.argtypes = [vp, vp, vp, vp, i32, vp]
     L.cfnmpc_sim.argtypes = [i32, vp, vp, dbl, i32, vp, i32, vp]
-    L.cfnmpc_debug_get_linearisation.argtypes = [vp, vp, vp, vp]
+    L.cfnmpc_debug_get_linearisation.argtypes = [vp, i32, vp, vp, vp]
+    L.cfnmpc_debug_get_head.argtypes = [vp, vp]
     L.cfnmpc_debug_linearise.argtypes = [vp, vp]
     L.cfnmpc_version.restype = C.c_char_p
     for name in SYMBOLS:

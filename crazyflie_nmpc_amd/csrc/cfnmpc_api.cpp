@@ -45,8 +45,9 @@ int dev_alloc(cfnmpc_solver* s, T** p, size_t count) {
     return CFNMPC_OK;
 }
 
-// copy an AoS array [B][S][E] from the caller into an SoA field
-int put_field(cfnmpc_solver* s, const double* src, int on_device, int S, int E, double* soa, hipStream_t st) {
+// copy an AoS array [B][S][E] (external state order) from the caller into a workspace field
+int put_field(cfnmpc_solver* s, const double* src, int on_device, int S, int E, int perm13, double* field,
+              hipStream_t st) {
     const cfn::Params& P = s->P;
     const size_t n = (size_t)P.B * S * E;
     const double* dsrc = src;
@@ -55,15 +56,15 @@ int put_field(cfnmpc_solver* s, const double* src, int on_device, int S, int E, 
         HIP_TRY(hipMemcpyAsync(s->stage_buf, src, n * sizeof(double), hipMemcpyHostToDevice, st));
         dsrc = s->stage_buf;
     }
-    cfn::launch_aos2soa(P.B, P.Bp, S, E, dsrc, soa, st);
+    cfn::launch_put(P.B, S, E, perm13, dsrc, field, st);
     HIP_TRY(hipGetLastError());
     if (!on_device) HIP_TRY(hipStreamSynchronize(st));  // staging buffer is reused
     return CFNMPC_OK;
 }
 
-// copy stages s0..s0+S-1 of an SoA field into the caller's AoS array [B][S][E]
-int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int s0, int Stot, const double* soa,
-              hipStream_t st) {
+// copy stages s0..s0+S-1 of a workspace field into the caller's AoS array [B][S][E]
+int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int perm13, int s0, int Stot,
+              const double* field, hipStream_t st) {
     const cfn::Params& P = s->P;
     const size_t n = (size_t)P.B * S * E;
     double* ddst = dst;
@@ -71,7 +72,7 @@ int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int s0
         if (n > s->stage_doubles) return CFNMPC_EINVAL;
         ddst = s->stage_buf;
     }
-    cfn::launch_soa2aos(P.B, P.Bp, S, E, s0, Stot, soa, ddst, st);
+    cfn::launch_get(P.B, S, E, perm13, s0, Stot, field, ddst, st);
     HIP_TRY(hipGetLastError());
     if (!on_device) {
         HIP_TRY(hipMemcpyAsync(dst, ddst, n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -84,7 +85,7 @@ int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int s0
 
 extern "C" {
 
-const char* cfnmpc_version(void) { return "cfnmpc 0.1 (gfx950, lane-per-instance v1)"; }
+const char* cfnmpc_version(void) { return "cfnmpc 0.2 (gfx950, 16-lane row groups, DPP broadcast Riccati)"; }
 
 void cfnmpc_default_opts(cfnmpc_opts* o) {
     // generate_c_code.py:41-42,63-84,109,133-134
@@ -101,6 +102,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->tau = 0.995;
     o->thr0 = 1.0;
     o->lam0_min = 1e-2;
+    o->active_horizon = 1;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
@@ -120,22 +122,27 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     cfn::Params& P = s->P;
     std::memset(&P, 0, sizeof P);
     P.B = batch;
-    P.Bp = (batch + 63) / 64 * 64;
+    P.NW = (batch + 3) / 4;
     P.N = o.N;
     P.dt = o.dt;
     for (int i = 0; i < 17; i++) P.W[i] = o.W[i];
     for (int i = 0; i < 13; i++) P.WN[i] = o.WN[i];
     P.u_min = o.u_min; P.u_max = o.u_max; P.tol = o.tol; P.tau = o.tau; P.thr0 = o.thr0;
     P.lam0_min = o.lam0_min; P.max_iter = o.max_iter;
-    const size_t Bp = P.Bp, N = P.N;
+    P.active_horizon = o.active_horizon ? 1 : 0;
+    const size_t NW = P.NW, N = P.N;
     int rc = CFNMPC_OK;
-#define ALLOC(field, cnt) if (rc == CFNMPC_OK) rc = dev_alloc(s, &P.field, (size_t)(cnt) * Bp)
-    ALLOC(xit, (N + 1) * 13); ALLOC(uit, N * 4); ALLOC(x0, 13); ALLOC(yref, N * 17); ALLOC(yref_e, 13);
-    ALLOC(A, N * cfn::A_NNZ); ALLOC(Bm, N * 52); ALLOC(b, N * 13);
-    ALLOC(K, N * 52); ALLOC(Sinv, N * 10); ALLOC(d, N * 4);
-    ALLOC(v, N * 4); ALLOC(tl, N * 4); ALLOC(tu, N * 4); ALLOC(ll, N * 4); ALLOC(lu, N * 4);
-    ALLOC(rg, N * 4); ALLOC(dva, N * 4); ALLOC(dvc, N * 4);
-    ALLOC(status, 1); ALLOC(iters, 1); ALLOC(res, 1);
+#define ALLOC(field, cnt) if (rc == CFNMPC_OK) rc = dev_alloc(s, &P.field, (size_t)(cnt))
+    ALLOC(xit, NW * (N + 1) * cfn::SZ_V13); ALLOC(uit, NW * 4 * N * 4); ALLOC(x0, NW * cfn::SZ_V13);
+    ALLOC(yref, NW * N * cfn::SZ_Y); ALLOC(yref_e, NW * cfn::SZ_V13);
+    ALLOC(AR, NW * N * cfn::SZ_A); ALLOC(AC, NW * N * cfn::SZ_A);
+    ALLOC(BR, NW * N * cfn::SZ_B); ALLOC(BC, NW * N * cfn::SZ_B); ALLOC(b, NW * N * cfn::SZ_V13);
+    ALLOC(KP, NW * N * cfn::SZ_K); ALLOC(KR, NW * N * cfn::SZ_K); ALLOC(Sinv, NW * N * cfn::SZ_S);
+    ALLOC(d, NW * 4 * N * 4); ALLOC(Pchk, NW * cfn::N_CHK * cfn::SZ_P);
+    ALLOC(v, NW * 4 * N * 4); ALLOC(tl, NW * 4 * N * 4); ALLOC(tu, NW * 4 * N * 4); ALLOC(ll, NW * 4 * N * 4);
+    ALLOC(lu, NW * 4 * N * 4); ALLOC(rg, NW * 4 * N * 4); ALLOC(dva, NW * 4 * N * 4); ALLOC(dvc, NW * 4 * N * 4);
+    ALLOC(Rh, NW * 4 * N * 4); ALLOC(g, NW * 4 * N * 4); ALLOC(dx, NW * (N + 1) * cfn::SZ_V13);
+    ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4);
 #undef ALLOC
     s->stage_doubles = (size_t)batch * (N + 1) * 17;
     if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->stage_buf, s->stage_doubles);
@@ -160,14 +167,14 @@ unsigned long long cfnmpc_workspace_bytes(const cfnmpc_solver* s) { return s ? s
 
 int cfnmpc_set_x0(cfnmpc_solver* s, const double* x0, int on_device, void* stream) {
     if (!s || !x0) return CFNMPC_EINVAL;
-    return put_field(s, x0, on_device, 1, 13, s->P.x0, (hipStream_t)stream);
+    return put_field(s, x0, on_device, 1, 13, 1, s->P.x0, (hipStream_t)stream);
 }
 
 int cfnmpc_set_yref(cfnmpc_solver* s, const double* yref, const double* yref_e, int on_device, void* stream) {
     if (!s || !yref || !yref_e) return CFNMPC_EINVAL;
-    int rc = put_field(s, yref, on_device, s->P.N, 17, s->P.yref, (hipStream_t)stream);
+    int rc = put_field(s, yref, on_device, s->P.N, 17, 1, s->P.yref, (hipStream_t)stream);
     if (rc != CFNMPC_OK) return rc;
-    return put_field(s, yref_e, on_device, 1, 13, s->P.yref_e, (hipStream_t)stream);
+    return put_field(s, yref_e, on_device, 1, 13, 1, s->P.yref_e, (hipStream_t)stream);
 }
 
 int cfnmpc_init_iterate(cfnmpc_solver* s, int mode, void* stream) {
@@ -179,16 +186,16 @@ int cfnmpc_init_iterate(cfnmpc_solver* s, int mode, void* stream) {
 
 int cfnmpc_set_iterate(cfnmpc_solver* s, const double* x, const double* u, int on_device, void* stream) {
     if (!s || !x || !u) return CFNMPC_EINVAL;
-    int rc = put_field(s, x, on_device, s->P.N + 1, 13, s->P.xit, (hipStream_t)stream);
+    int rc = put_field(s, x, on_device, s->P.N + 1, 13, 1, s->P.xit, (hipStream_t)stream);
     if (rc != CFNMPC_OK) return rc;
-    return put_field(s, u, on_device, s->P.N, 4, s->P.uit, (hipStream_t)stream);
+    return put_field(s, u, on_device, s->P.N, 4, 0, s->P.uit, (hipStream_t)stream);
 }
 
 int cfnmpc_get_iterate(cfnmpc_solver* s, double* x, double* u, int on_device, void* stream) {
     if (!s || !x || !u) return CFNMPC_EINVAL;
-    int rc = get_field(s, x, on_device, s->P.N + 1, 13, 0, s->P.N + 1, s->P.xit, (hipStream_t)stream);
+    int rc = get_field(s, x, on_device, s->P.N + 1, 13, 1, 0, s->P.N + 1, s->P.xit, (hipStream_t)stream);
     if (rc != CFNMPC_OK) return rc;
-    return get_field(s, u, on_device, s->P.N, 4, 0, s->P.N, s->P.uit, (hipStream_t)stream);
+    return get_field(s, u, on_device, s->P.N, 4, 0, 0, s->P.N, s->P.uit, (hipStream_t)stream);
 }
 
 int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
@@ -203,12 +210,12 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
 
 int cfnmpc_get_u(cfnmpc_solver* s, int stage, double* u, int on_device, void* stream) {
     if (!s || !u || stage < 0 || stage >= s->P.N) return CFNMPC_EINVAL;
-    return get_field(s, u, on_device, 1, 4, stage, s->P.N, s->P.uit, (hipStream_t)stream);
+    return get_field(s, u, on_device, 1, 4, 0, stage, s->P.N, s->P.uit, (hipStream_t)stream);
 }
 
 int cfnmpc_get_x(cfnmpc_solver* s, int stage, double* x, int on_device, void* stream) {
     if (!s || !x || stage < 0 || stage > s->P.N) return CFNMPC_EINVAL;
-    return get_field(s, x, on_device, 1, 13, stage, s->P.N + 1, s->P.xit, (hipStream_t)stream);
+    return get_field(s, x, on_device, 1, 13, 1, stage, s->P.N + 1, s->P.xit, (hipStream_t)stream);
 }
 
 int cfnmpc_get_stats(cfnmpc_solver* s, int* status, int* qp_iter, double* res, int on_device, void* stream) {
@@ -260,26 +267,50 @@ int cfnmpc_debug_linearise(cfnmpc_solver* s, void* stream) {
     return CFNMPC_OK;
 }
 
-int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, double* A, double* Bm, double* b) {
-    if (!s || !A || !Bm || !b) return CFNMPC_EINVAL;
+int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, int form, double* A, double* Bm, double* b) {
+    // form 0: from the row forms (AR, BR); form 1: from the column forms (AC, BC).
+    // Output dense, EXTERNAL state order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13].
+    if (!s || !A || !Bm || !b || (form != 0 && form != 1)) return CFNMPC_EINVAL;
     const cfn::Params& P = s->P;
-    const size_t Bp = P.Bp, N = P.N, B = P.B;
-    std::vector<double> ha(N * cfn::A_NNZ * Bp), hb(N * 52 * Bp), hv(N * 13 * Bp);
+    const size_t NW = P.NW, N = P.N, B = P.B;
+    std::vector<double> ha(NW * N * cfn::SZ_A), hb(NW * N * cfn::SZ_B), hv(NW * N * cfn::SZ_V13);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(ha.data(), P.A, ha.size() * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hb.data(), P.Bm, hb.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ha.data(), form ? P.AC : P.AR, ha.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hb.data(), form ? P.BC : P.BR, hb.size() * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(hv.data(), P.b, hv.size() * 8, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < B; i++)
+    for (size_t i = 0; i < B; i++) {
+        const size_t w = i / 4, q = i % 4;
         for (size_t k = 0; k < N; k++) {
+            const double* ab = ha.data() + (w * N + k) * cfn::SZ_A;
+            const double* bb = hb.data() + (w * N + k) * cfn::SZ_B;
+            const double* vb = hv.data() + (w * N + k) * cfn::SZ_V13;
             double* Ad = A + (i * N + k) * 169;
-            for (int r = 0; r < 13; r++)
+            double* Bd = Bm + (i * N + k) * 52;
+            for (int r = 0; r < 13; r++) {      // internal row / column indices
                 for (int c = 0; c < 13; c++) {
-                    const int kind = cfn::a_kind(r, c);
-                    Ad[r * 13 + c] = kind == 0 ? 0.0 : (kind == 1 ? 1.0 : ha[(k * cfn::A_NNZ + cfn::a_idx(r, c)) * Bp + i]);
+                    double val;
+                    if (c < 3) val = (r == c) ? 1.0 : 0.0;
+                    else if (form == 0) {
+                        const int sl = c - 3;
+                        val = r < cfn::ar_n(sl) ? ab[4 * cfn::ar_pre(sl) + q * cfn::ar_n(sl) + r] : 0.0;
+                    } else {
+                        val = c >= cfn::ac_first(r) ? ab[4 * cfn::ac_pre(r) + q * cfn::ac_m(r) + (c - cfn::ac_first(r))] : 0.0;
+                    }
+                    Ad[cfn::ext_of(r) * 13 + cfn::ext_of(c)] = val;
                 }
-            for (int e = 0; e < 52; e++) Bm[(i * N + k) * 52 + e] = hb[(k * 52 + e) * Bp + i];
-            for (int e = 0; e < 13; e++) b[(i * N + k) * 13 + e] = hv[(k * 13 + e) * Bp + i];
+                for (int a = 0; a < 4; a++)
+                    Bd[cfn::ext_of(r) * 4 + a] = form == 0 ? bb[(a * 4 + q) * 13 + r] : bb[(r * 4 + q) * 4 + a];
+                b[(i * N + k) * 13 + cfn::ext_of(r)] = vb[q * 13 + r];
+            }
         }
+    }
+    return CFNMPC_OK;
+}
+
+int cfnmpc_debug_get_head(cfnmpc_solver* s, int* head) {
+    if (!s || !head) return CFNMPC_EINVAL;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(head, s->P.head, (size_t)s->P.B * sizeof(int), hipMemcpyDeviceToHost));
     return CFNMPC_OK;
 }
 

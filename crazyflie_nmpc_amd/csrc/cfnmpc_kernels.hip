@@ -1,637 +1,782 @@
 // cfnmpc_kernels.hip -- HIP kernels of the batched Crazyflie SQP-RTI step (gfx950, FP64).
 //
-// v1 mapping: ONE NMPC INSTANCE PER WAVEFRONT LANE.  All per-instance data live in HBM in
-// SoA form with the instance index fastest:
-//     field[(stage * E + elem) * Bp + inst]           (Bp = batch padded to 64)
-// so that the 64 lanes of a wave read/write 512 contiguous bytes per element.  Instances are
-// independent, so there is no inter-lane or inter-wave communication at all; each wave runs
-// its own interior-point loop until all of its lanes have converged (wave-uniform exit via
-// __any), converged lanes are predicated off.
+// Mapping: one NMPC instance per 16-lane DPP row, four instances per wavefront, one wavefront
+// per workgroup (cfnmpc_ws.hpp).  Instances never communicate; every wave runs its own
+// interior-point loop until its four instances are done (wave-uniform trip count via __any).
 //
-// Kernels:
-//   k_linearise : RK4 + forward sensitivities per shooting interval (acados sim_erk + CasADi
-//                 forw_vde, acados_mpc.cpp:84), column-wise so that only one 13-vector of the
-//                 sensitivity is live; writes A (compact 97), B (52), b (13) per stage.
-//   k_qp_ipm    : box-constrained OCP-QP by Mehrotra predictor-corrector with stage-wise
-//                 Riccati sweeps (HPIPM's role, generate_c_code.py:140), delta form; then the
-//                 full RTI step (iterate += step) and per-instance statistics.
+// Kernels
+//   k_linearise : RK4 + forward sensitivities per shooting interval (the role of acados
+//                 sim_erk + CasADi forw_vde, acados_mpc.cpp:84): lane c integrates sensitivity
+//                 COLUMN c; a 13x17 LDS tile re-distributes it into the row / column forms.
+//   k_qp        : box-constrained OCP-QP by Mehrotra predictor-corrector over stage-wise
+//                 Riccati sweeps in delta form (HPIPM's role, generate_c_code.py:140), then
+//                 expansion and the full RTI step (acados_solve(), acados_mpc.cpp:611).
 //   k_sim       : RK4 predictor / plant step (acados_estimator.cpp:573-593).
-//   k_aos2soa / k_soa2aos / k_init_iterate : layout glue for the C-ABI.
+//   k_put / k_get / k_init_iterate : layout glue for the C-ABI.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
+#include "cfnmpc_dpp.hpp"
 #include "cfnmpc_model.hpp"
 #include "cfnmpc_ws.hpp"
 
 namespace cfn {
 
-#define IDX(k, e, E) (((size_t)(k) * (E) + (e)) * (size_t)P.Bp + (size_t)inst)
+// ---------------------------------------------------------------------------------------------
+// small tools
+// ---------------------------------------------------------------------------------------------
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+#define SFOR(var, lo, hi, ...) sfor<lo, hi>([&](auto var##_) { constexpr int var = decltype(var##_)::value; __VA_ARGS__ })
+
+// value of v in lane L of the caller's 16-lane row (v_mov_b64_dpp row_newbcast:L)
+template <int L>
+__device__ __forceinline__ double bc(double v) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const long long r = __builtin_amdgcn_update_dpp((long long)0, x, 0x150 + L, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, r);
+}
+__device__ __forceinline__ double row_sum(double x) {
+    double s = 0.0;
+    SFOR(l, 0, 16, { s += bc<l>(x); });
+    return s;
+}
+__device__ __forceinline__ double row_min(double x) {
+    double s = x;
+    SFOR(l, 0, 16, { s = fmin(s, bc<l>(x)); });
+    return s;
+}
+__device__ __forceinline__ double row_max(double x) {
+    double s = x;
+    SFOR(l, 0, 16, { s = fmax(s, bc<l>(x)); });
+    return s;
+}
+
+struct Lane {
+    int L;      // lane in row: 0..12 state rows, 13 affine row, 14/15 idle
+    int q;      // instance in wave 0..3
+    int wave;   // wave (= workgroup) index
+    int inst;   // global instance
+    bool valid;
+};
+__device__ __forceinline__ Lane lane_id(const Params& P) {
+    Lane t;
+    t.L = threadIdx.x & 15;
+    t.q = threadIdx.x >> 4;
+    t.wave = blockIdx.x;
+    t.inst = t.wave * 4 + t.q;
+    t.valid = t.inst < P.B;
+    return t;
+}
+// Workspace pointers live inside the by-value Params struct, where clang cannot infer the
+// address space: gm() re-types them as global (address_space(1)) so that loads / stores are
+// global_* instead of flat_*.
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) int gint;
+__device__ __forceinline__ gdouble* gm(double* p) { return (gdouble*)(unsigned long long)p; }
+__device__ __forceinline__ const gdouble* gm(const double* p) { return (const gdouble*)(unsigned long long)p; }
+__device__ __forceinline__ gint* gm(int* p) { return (gint*)(unsigned long long)p; }
+// (wave, stage) block of a field
+__device__ __forceinline__ gdouble* blk(double* f, const Lane& t, int nst, int k, int sz) {
+    return gm(f) + ((size_t)t.wave * nst + k) * sz;
+}
+// hides a value from common-subexpression elimination (keeps broadcast temporaries short-lived)
+__device__ __forceinline__ void opaque(double& x) { asm volatile("" : "+v"(x)); }
+// a value produced by one of the asm primitives of cfnmpc_dpp.hpp is about to be read through
+// DPP by compiler-generated code (bc<>): give it the two wait states hipcc cannot know about
+__device__ __forceinline__ void settle(double& x) { asm volatile("s_nop 1" : "+v"(x)); }
+// instance-major 4-vectors (interior-point state, inputs): [inst][stage][4]
+__device__ __forceinline__ size_t i4(const Params& P, const Lane& t, int k, int a) {
+    return ((size_t)t.inst * P.N + k) * 4 + a;
+}
+
+// Loads are branch-free: every lane reads a valid (clamped) address and lanes outside the
+// stored range select 0 -- exec-masked loads would split the unrolled code into tiny blocks.
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ double ld13(const gdouble* b, const Lane& t) {
+    const double v = b[t.q * 13 + imin(t.L, 12)];
+    return t.L < 13 ? v : 0.0;
+}
+__device__ __forceinline__ void st13(gdouble* b, const Lane& t, double v) { if (t.L < 13) b[t.q * 13 + t.L] = v; }
+
+__device__ __forceinline__ void ld_ar(const gdouble* b, const Lane& t, double (&ar)[10]) {
+    SFOR(s, 0, 10, {
+        const double v = b[4 * ar_pre(s) + t.q * ar_n(s) + imin(t.L, ar_n(s) - 1)];
+        ar[s] = t.L < ar_n(s) ? v : 0.0;
+    });
+}
+__device__ __forceinline__ void ld_ac(const gdouble* b, const Lane& t, double (&ac)[13]) {
+    SFOR(r, 0, 13, {
+        const int c = imin(imax(t.L, ac_first(r)), 12);
+        const double v = b[4 * ac_pre(r) + t.q * ac_m(r) + (c - ac_first(r))];
+        ac[r] = (t.L >= ac_first(r) && t.L < 13) ? v : 0.0;
+    });
+}
+__device__ __forceinline__ void ld_rows4(const gdouble* b, const Lane& t, double (&r)[4]) {  // BR / KP
+    SFOR(a, 0, 4, {
+        const double v = b[(a * 4 + t.q) * 13 + imin(t.L, 12)];
+        r[a] = t.L < 13 ? v : 0.0;
+    });
+}
+__device__ __forceinline__ void ld_cols4(const gdouble* b, const Lane& t, double (&c)[13]) {  // BC / KR
+    SFOR(l, 0, 13, {
+        const double v = b[(l * 4 + t.q) * 4 + (t.L & 3)];
+        c[l] = t.L < 4 ? v : 0.0;
+    });
+}
+
+// select element `idx` (runtime) of a register array
+template <int N>
+__device__ __forceinline__ double pick(const double (&a)[N], int idx) {
+    double r = 0.0;
+    SFOR(j, 0, N, { r = (idx == j) ? a[j] : r; });
+    return r;
+}
 
 // =============================================================================================
 // linearisation
 // =============================================================================================
-template <bool HQ, bool HW, bool IS_U>
-__device__ __forceinline__ void sens_column(const JacPoint (&J)[4], const double* __restrict__ u, int c,
-                                            double h, double* __restrict__ col) {
-    // c: state column (3..12) or input column (0..3) when IS_U
-    double s0[13], s[13], k1[13], k2[13], k3[13], k4[13], ju[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 13; i++) s0[i] = 0.0;
-    if (!IS_U) s0[c] = 1.0; else ju_col(c, u, ju);
-    jvp<HQ, HW>(J[0], s0, k1);
-#pragma unroll
-    for (int i = 0; i < 4; i++) k1[9 + i] += ju[i];
-#pragma unroll
-    for (int i = 0; i < 13; i++) s[i] = s0[i] + 0.5 * h * k1[i];
-    jvp<HQ, HW>(J[1], s, k2);
-#pragma unroll
-    for (int i = 0; i < 4; i++) k2[9 + i] += ju[i];
-#pragma unroll
-    for (int i = 0; i < 13; i++) s[i] = s0[i] + 0.5 * h * k2[i];
-    jvp<HQ, HW>(J[2], s, k3);
-#pragma unroll
-    for (int i = 0; i < 4; i++) k3[9 + i] += ju[i];
-#pragma unroll
-    for (int i = 0; i < 13; i++) s[i] = s0[i] + h * k3[i];
-    jvp<HQ, HW>(J[3], s, k4);
-#pragma unroll
-    for (int i = 0; i < 4; i++) k4[9 + i] += ju[i];
-#pragma unroll
-    for (int i = 0; i < 13; i++) col[i] = s0[i] + (h / 6.0) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]);
-}
-
 __global__ __launch_bounds__(64) void k_linearise(Params P) {
-    const int inst = blockIdx.x * 64 + threadIdx.x;
-    if (inst >= P.B) return;
+    __shared__ double tile[4][13 * 17 + 3];  // [instance][row r (internal)][17 columns: 13 x + 4 u]
+    const Lane t = lane_id(P);
     const double h = P.dt;
-    double xn[13];
-#pragma unroll
-    for (int e = 0; e < 13; e++) xn[e] = P.xit[IDX(0, e, 13)];
+    // this lane's sensitivity column: lanes 3..12 -> state column (internal index = lane),
+    // lanes 0,1,2,13 -> input columns 0,1,2,3; lanes 14,15 idle.  (p columns are unit vectors.)
+    const bool is_x = t.L >= 3 && t.L < 13;
+    const bool is_u = t.L < 3 || t.L == 13;
+    const int ucol = t.L == 13 ? 3 : t.L;
+    const int xcol_ext = ext_of(is_x ? t.L : 3);
+    const int tcol = is_x ? t.L : 13 + ucol;  // column in the LDS tile
+    double* tl_ = tile[t.q];
+
     for (int k = 0; k < P.N; k++) {
+        // every lane of the row holds the full (x_k, u_k) in EXTERNAL order (model code order)
         double x[13], u[4], xt[13], k1[13], k2[13], k3[13], k4[13];
-        JacPoint J[4];
-#pragma unroll
-        for (int e = 0; e < 13; e++) x[e] = xn[e];
-#pragma unroll
-        for (int e = 0; e < 4; e++) u[e] = P.uit[IDX(k, e, 4)];
-#pragma unroll
-        for (int e = 0; e < 13; e++) xn[e] = P.xit[IDX(k + 1, e, 13)];
-        // nominal RK4 (classic tableau, one step per interval)
+        const gdouble* xb = blk(P.xit, t, P.N + 1, k, SZ_V13);
+        SFOR(e, 0, 13, { x[e] = xb[t.q * 13 + int_of(e)]; });
+        SFOR(a, 0, 4, { u[a] = gm(P.uit)[i4(P, t, k, a)]; });
+        JacPoint J0, J1, J2, J3;
         f_expl(x, u, k1);
-        jac_point(x, J[0]);
-#pragma unroll
-        for (int e = 0; e < 13; e++) xt[e] = x[e] + 0.5 * h * k1[e];
+        jac_point(x, J0);
+        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k1[e]; });
         f_expl(xt, u, k2);
-        jac_point(xt, J[1]);
-#pragma unroll
-        for (int e = 0; e < 13; e++) xt[e] = x[e] + 0.5 * h * k2[e];
+        jac_point(xt, J1);
+        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k2[e]; });
         f_expl(xt, u, k3);
-        jac_point(xt, J[2]);
-#pragma unroll
-        for (int e = 0; e < 13; e++) xt[e] = x[e] + h * k3[e];
+        jac_point(xt, J2);
+        SFOR(e, 0, 13, { xt[e] = x[e] + h * k3[e]; });
         f_expl(xt, u, k4);
-        jac_point(xt, J[3]);
-#pragma unroll
-        for (int e = 0; e < 13; e++) {
-            const double phi = x[e] + (h / 6.0) * (k1[e] + 2 * k2[e] + 2 * k3[e] + k4[e]);
-            P.b[IDX(k, e, 13)] = phi - xn[e];
+        jac_point(xt, J3);
+        double phi[13];
+        SFOR(e, 0, 13, { phi[e] = x[e] + (h / 6.0) * (k1[e] + 2 * k2[e] + 2 * k3[e] + k4[e]); });
+        // b = Phi - x_{k+1}, distributed (lane i <-> internal state i)
+        {
+            const double xn = ld13(blk(P.xit, t, P.N + 1, k + 1, SZ_V13), t);
+            const double ph = pick(phi, ext_of(t.L < 13 ? t.L : 0));
+            st13(blk(P.b, t, P.N, k, SZ_V13), t, ph - xn);
         }
-        // sensitivities, one column at a time
-        double col[13];
-#pragma unroll
-        for (int c = 3; c < 7; c++) {  // quaternion columns: rows p,q,v
-            sens_column<true, false, false>(J, u, c, h, col);
-#pragma unroll
-            for (int r = 0; r < 10; r++) P.A[IDX(k, a_idx(r, c), A_NNZ)] = col[r];
+        // this lane's sensitivity column through the four RK stages
+        double s0[13], s[13], c1[13], c2[13], c3[13], c4[13], ju[4] = {0, 0, 0, 0};
+        SFOR(e, 0, 13, { s0[e] = (is_x && xcol_ext == e) ? 1.0 : 0.0; });
+        if (is_u) {
+            const double uc = 2.0 * pick(u, ucol);
+            const double sa = (ucol < 2) ? 1.0 : -1.0;
+            const double sb = (ucol == 0 || ucol == 3) ? 1.0 : -1.0;
+            const double sc = (ucol == 0 || ucol == 2) ? 1.0 : -1.0;
+            ju[0] = KT * uc; ju[1] = KA * sa * uc; ju[2] = KB * sb * uc; ju[3] = KC * sc * uc;
         }
-#pragma unroll
-        for (int c = 7; c < 10; c++) {  // velocity columns: rows p,v
-            sens_column<false, false, false>(J, u, c, h, col);
-#pragma unroll
-            for (int r = 0; r < 3; r++) P.A[IDX(k, a_idx(r, c), A_NNZ)] = col[r];
-#pragma unroll
-            for (int r = 7; r < 10; r++) P.A[IDX(k, a_idx(r, c), A_NNZ)] = col[r];
+        jvp<true, true>(J0, s0, c1);
+        SFOR(i, 0, 4, { c1[9 + i] += ju[i]; });
+        SFOR(e, 0, 13, { s[e] = s0[e] + 0.5 * h * c1[e]; });
+        jvp<true, true>(J1, s, c2);
+        SFOR(i, 0, 4, { c2[9 + i] += ju[i]; });
+        SFOR(e, 0, 13, { s[e] = s0[e] + 0.5 * h * c2[e]; });
+        jvp<true, true>(J2, s, c3);
+        SFOR(i, 0, 4, { c3[9 + i] += ju[i]; });
+        SFOR(e, 0, 13, { s[e] = s0[e] + h * c3[e]; });
+        jvp<true, true>(J3, s, c4);
+        SFOR(i, 0, 4, { c4[9 + i] += ju[i]; });
+        double col[13];  // internal row order
+        SFOR(r, 0, 13, {
+            constexpr int e = ext_of(r);
+            col[r] = s0[e] + (h / 6.0) * (c1[e] + 2 * c2[e] + 2 * c3[e] + c4[e]);
+        });
+        // column form of A straight from registers
+        {
+            gdouble* ac = blk(P.AC, t, P.N, k, SZ_A);
+            SFOR(r, 0, 13, {
+                if (is_x && t.L >= ac_first(r)) ac[4 * ac_pre(r) + t.q * ac_m(r) + (t.L - ac_first(r))] = col[r];
+            });
+            gdouble* bcb = blk(P.BC, t, P.N, k, SZ_B);
+            SFOR(r, 0, 13, { if (is_u) bcb[(r * 4 + t.q) * 4 + ucol] = col[r]; });
         }
-#pragma unroll
-        for (int c = 10; c < 13; c++) {  // rate columns: all rows
-            sens_column<true, true, false>(J, u, c, h, col);
-#pragma unroll
-            for (int r = 0; r < 13; r++) P.A[IDX(k, a_idx(r, c), A_NNZ)] = col[r];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; c++) {  // input columns: all rows
-            sens_column<true, true, true>(J, u, c, h, col);
-#pragma unroll
-            for (int r = 0; r < 13; r++) P.Bm[IDX(k, r * 4 + c, 52)] = col[r];
+        // row forms through the LDS tile
+        __syncthreads();
+        if (is_x || is_u) SFOR(r, 0, 13, { tl_[r * 17 + tcol] = col[r]; });
+        __syncthreads();
+        {
+            gdouble* ar = blk(P.AR, t, P.N, k, SZ_A);
+            SFOR(sl, 0, 10, { if (t.L < ar_n(sl)) ar[4 * ar_pre(sl) + t.q * ar_n(sl) + t.L] = tl_[t.L * 17 + (sl + 3)]; });
+            gdouble* brb = blk(P.BR, t, P.N, k, SZ_B);
+            SFOR(a, 0, 4, { if (t.L < 13) brb[(a * 4 + t.q) * 13 + t.L] = tl_[t.L * 17 + 13 + a]; });
         }
     }
 }
 
 // =============================================================================================
-// Riccati sweeps (per lane)
+// Riccati sweeps
 // =============================================================================================
-struct LaneIPM {
-    double mu, res, alpha;
-    int iters, status;
-    bool act;
-};
-
-// symmetric positive definite 4x4 (packed upper) -> inverse (packed upper).  false if not SPD.
-__device__ __forceinline__ bool spd4_inv(const double* __restrict__ S, double* __restrict__ Si) {
-    double L[4][4], Li[4][4];
+// symmetric positive definite 4x4 (packed upper) -> inverse (packed upper); false if not SPD
+__device__ __forceinline__ bool spd4_inv(const double (&S)[10], double (&Si)[10]) {
+    double Lm[4][4], Li[4][4];
     bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
+    SFOR(j, 0, 4, {
         double s = S[s4(j, j)];
-#pragma unroll
-        for (int k = 0; k < j; k++) s -= L[j][k] * L[j][k];
+        SFOR(k, 0, j, { s -= Lm[j][k] * Lm[j][k]; });
         ok = ok && (s > 0.0);
-        const double ljj = sqrt(s), inv = 1.0 / ljj;
-        L[j][j] = ljj;
+        const double ljj = sqrt(s);
+        const double inv = 1.0 / ljj;
+        Lm[j][j] = ljj;
         Li[j][j] = inv;
-#pragma unroll
-        for (int i = j + 1; i < 4; i++) {
-            double t = S[s4(i, j)];
-#pragma unroll
-            for (int k = 0; k < j; k++) t -= L[i][k] * L[j][k];
-            L[i][j] = t * inv;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int i = j + 1; i < 4; i++) {
-            double t = 0;
-#pragma unroll
-            for (int k = j; k < i; k++) t -= L[i][k] * Li[k][j];
-            Li[i][j] = t * Li[i][i];
-        }
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = i; j < 4; j++) {
-            double t = 0;
-#pragma unroll
-            for (int k = j; k < 4; k++) t += Li[k][i] * Li[k][j];
-            Si[s4(i, j)] = t;
-        }
+        SFOR(i, j + 1, 4, {
+            double tt = S[s4(i, j)];
+            SFOR(k, 0, j, { tt -= Lm[i][k] * Lm[j][k]; });
+            Lm[i][j] = tt * inv;
+        });
+    });
+    SFOR(j, 0, 4, {
+        SFOR(i, j + 1, 4, {
+            double tt = 0;
+            SFOR(k, j, i, { tt -= Lm[i][k] * Li[k][j]; });
+            Li[i][j] = tt * Li[i][i];
+        });
+    });
+    SFOR(i, 0, 4, {
+        SFOR(j, i, 4, {
+            double tt = 0;
+            SFOR(k, j, 4, { tt += Li[k][i] * Li[k][j]; });
+            Si[s4(i, j)] = tt;
+        });
+    });
     return ok;
 }
 
-// Backward factorisation sweep.  ABSOLUTE: start solve with the QP's affine terms (q, b, r);
-// otherwise homogeneous Newton system with input Hessian R + Dl + Du and gradient g_aff that
-// are formed on the fly from the interior-point state.  Writes K, Sinv, d per stage.
+// One stage of the augmented backward recursion.
+//   Pa[13]: lanes 0..12 row i of P_{k+1}; lane 13 the affine row p_{k+1}' (delta form) -- on
+//           exit the same for stage k.
+//   ABSOLUTE: start solve with the QP's own affine terms (q_k, b_k, r_k);
+//   otherwise input Hessian R^ and gradient g are read from P.Rh / P.g (interior-point step).
 template <bool ABSOLUTE>
-__device__ __forceinline__ bool sweep_factor(const Params& P, const int inst) {
-    double Pm[S_NNZ], p[13];
-    bool ok = true;
-#pragma unroll
-    for (int i = 0; i < S_NNZ; i++) Pm[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 13; i++) {
-        Pm[sidx(i, i)] = P.WN[i];
-        p[i] = ABSOLUTE ? P.WN[i] * (P.xit[IDX(P.N, i, 13)] - P.yref_e[IDX(0, i, 13)]) : 0.0;
+__device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, const int k, double (&Pa)[13],
+                                             double* wt /* LDS [13*17] of this instance */) {
+    double ar[10], br[4], bcl[13];
+    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, ar);
+    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, br);
+    ld_cols4(blk(P.BC, t, P.N, k, SZ_B), t, bcl);
+    // input Hessian / gradient: lane a < 4 holds element a
+    double Rh, g;
+    {
+        const int a = t.L & 3;
+        if (ABSOLUTE) {
+            const double uk = gm(P.uit)[i4(P, t, k, a)];
+            const double yr = blk(P.yref, t, P.N, k, SZ_Y)[t.q * 17 + 13 + a];
+            Rh = P.W[13 + a];
+            g = P.W[13 + a] * (uk - yr);
+        } else {
+            Rh = gm(P.Rh)[i4(P, t, k, a)];
+            g = gm(P.g)[i4(P, t, k, a)];
+        }
+        if (t.L >= 4) { Rh = 0.0; g = 0.0; }
     }
-    for (int k = P.N - 1; k >= 0; k--) {
-        double a[A_NNZ], bm[52];
-#pragma unroll
-        for (int e = 0; e < A_NNZ; e++) a[e] = P.A[IDX(k, e, A_NNZ)];
-#pragma unroll
-        for (int e = 0; e < 52; e++) bm[e] = P.Bm[IDX(k, e, 52)];
-        // input Hessian / gradient of this stage
-        double Rh[4], g[4], uk[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) uk[e] = P.uit[IDX(k, e, 4)];
-        if (ABSOLUTE) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                Rh[e] = P.W[13 + e];
-                g[e] = P.W[13 + e] * (uk[e] - P.yref[IDX(k, 13 + e, 17)]);
+    if (ABSOLUTE) {
+        // hb' = p' + (P b)' in lane 13
+        const double bv = ld13(blk(P.b, t, P.N, k, SZ_V13), t);
+        double pb = 0.0;
+        dotbc<13, 0>(pb, Pa, bv);
+        if (t.L >= 13) pb = 0.0;
+        SFOR(j, 0, 13, {
+            const double add = bc<j>(pb);
+            if (t.L == 13) Pa[j] += add;
+        });
+    }
+    // (1) W = Pa A (row form, instruction-level sparsity of A), (2) V = Pa B
+    double W[13], V[4];
+    SFOR(j, 0, 3, { W[j] = Pa[j]; });
+    SFOR(j, 3, 13, { W[j] = 0.0; });
+    dot2bc<6, 0>(W[3], W[4], Pa, ar[0], ar[1]);
+    dotbc<6, 0>(W[5], Pa, ar[2]);
+    dot2bc<10, 0>(W[6], W[7], Pa, ar[3], ar[4]);
+    dot2bc<10, 0>(W[8], W[9], Pa, ar[5], ar[6]);
+    dot2bc<13, 0>(W[10], W[11], Pa, ar[7], ar[8]);
+    dotbc<13, 0>(W[12], Pa, ar[9]);
+    SFOR(a, 0, 4, { V[a] = 0.0; });
+    dot2bc<13, 0>(V[0], V[1], Pa, br[0], br[1]);
+    dot2bc<13, 0>(V[2], V[3], Pa, br[2], br[3]);
+    // (3) Wt = transpose of W over lanes 0..12; lane 13 keeps the affine row
+    double Wt[13];
+    __syncthreads();
+    if (t.L < 13) SFOR(j, 0, 13, { wt[j * 17 + t.L] = W[j]; });
+    __syncthreads();
+    SFOR(l, 0, 13, {
+        const double w = wt[imin(t.L, 12) * 17 + l];
+        Wt[l] = t.L < 13 ? w : (t.L == 13 ? Pa[l] : 0.0);
+    });
+    // (4) M = Q + Wt A  (lane 13: q_k' + hb'A)
+    double M[13];
+    if (ABSOLUTE) {
+        // q_k distributed -> row form in lane 13
+        const double xk = ld13(blk(P.xit, t, P.N + 1, k, SZ_V13), t);
+        const double yk = blk(P.yref, t, P.N, k, SZ_Y)[t.q * 17 + imin(t.L, 12)];
+        double qv = 0.0;
+        SFOR(j, 0, 13, { if (t.L == j) qv = P.W[ext_of(j)] * (xk - yk); });
+        SFOR(j, 0, 13, {
+            const double qj = bc<j>(qv);
+            M[j] = (t.L == j) ? P.W[ext_of(j)] : (t.L == 13 ? qj : 0.0);
+        });
+    } else {
+        SFOR(j, 0, 13, { M[j] = (t.L == j) ? P.W[ext_of(j)] : 0.0; });
+    }
+    SFOR(j, 0, 3, { M[j] += Wt[j]; });
+    dot2bc<6, 0>(M[3], M[4], Wt, ar[0], ar[1]);
+    dotbc<6, 0>(M[5], Wt, ar[2]);
+    dot2bc<10, 0>(M[6], M[7], Wt, ar[3], ar[4]);
+    dot2bc<10, 0>(M[8], M[9], Wt, ar[5], ar[6]);
+    dot2bc<13, 0>(M[10], M[11], Wt, ar[7], ar[8]);
+    dotbc<13, 0>(M[12], Wt, ar[9]);
+    // (5) G' = Wt B ; lane 13: rho = g + B'hb
+    double Gp[4];
+    SFOR(a, 0, 4, { Gp[a] = 0.0; });
+    dot2bc<13, 0>(Gp[0], Gp[1], Wt, br[0], br[1]);
+    dot2bc<13, 0>(Gp[2], Gp[3], Wt, br[2], br[3]);
+    SFOR(a, 0, 4, {
+        const double ga = bc<a>(g);
+        if (t.L == 13) Gp[a] += ga;
+    });
+    // (6) S = R^ + B'V in lanes a < 4, replicated, inverted redundantly by every lane
+    double Srow[4];
+    SFOR(c, 0, 4, { Srow[c] = (t.L == c) ? Rh : 0.0; });
+    dot2bc<13, 0>(Srow[0], Srow[1], bcl, V[0], V[1]);
+    dot2bc<13, 0>(Srow[2], Srow[3], bcl, V[2], V[3]);
+    SFOR(c, 0, 4, { settle(Srow[c]); });
+    double S[10], Si[10];
+    SFOR(a, 0, 4, { SFOR(c, a, 4, { S[s4(a, c)] = bc<a>(Srow[c]); }); });
+    const bool ok = spd4_inv(S, Si);
+    // (7) K' = G' Sinv  (lane 13: feed-forward d)
+    double Kp[4], nGp[4];
+    SFOR(a, 0, 4, {
+        double s = 0.0;
+        SFOR(c, 0, 4, { s += Gp[c] * Si[s4(c, a)]; });
+        Kp[a] = s;
+        nGp[a] = -Gp[a];
+    });
+    // (8) P <- M - G' K  (lane 13: p' <- M_13 - rho' K)
+    SFOR(j, 0, 13, {
+        Pa[j] = M[j];
+        updbc<j>(Pa[j], Kp, nGp);
+    });
+    // (9) stores
+    {
+        gdouble* kp = blk(P.KP, t, P.N, k, SZ_K);
+        gdouble* kr = blk(P.KR, t, P.N, k, SZ_K);
+        SFOR(a, 0, 4, {
+            if (t.L < 13) {
+                kp[(a * 4 + t.q) * 13 + t.L] = Kp[a];
+                kr[(t.L * 4 + t.q) * 4 + a] = Kp[a];
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const double v = P.v[IDX(k, e, 4)], tl = P.tl[IDX(k, e, 4)], tu = P.tu[IDX(k, e, 4)];
-                const double ll = P.ll[IDX(k, e, 4)], lu = P.lu[IDX(k, e, 4)], rg = P.rg[IDX(k, e, 4)];
-                const double lb = P.u_min - uk[e], ub = P.u_max - uk[e];
-                const double rl = v - lb - tl, ru = ub - v - tu;
-                const double Dl = ll / tl, Du = lu / tu;
-                Rh[e] = P.W[13 + e] + Dl + Du;
-                g[e] = rg + ll + Dl * rl - lu - Du * ru;
-            }
+            if (t.L == 13) gm(P.d)[i4(P, t, k, a)] = Kp[a];
+        });
+        if (t.L == 0) {
+            gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S);
+            SFOR(e, 0, 10, { sv[t.q * 10 + e] = Si[e]; });
         }
-        // hb = p + P b (absolute only)
-        double hb[13];
-        if (ABSOLUTE) {
-            double bv[13];
-#pragma unroll
-            for (int e = 0; e < 13; e++) bv[e] = P.b[IDX(k, e, 13)];
-#pragma unroll
-            for (int i = 0; i < 13; i++) {
-                double s = p[i];
-#pragma unroll
-                for (int l = 0; l < 13; l++) s += Pm[sidx(i, l)] * bv[l];
-                hb[i] = s;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 13; i++) hb[i] = p[i];
-        }
-        // PB = P B (13x4), S = Rh + B'PB (sym 4x4), rho = g + B'hb
-        double PB[52], S[10], rho[4];
-#pragma unroll
-        for (int i = 0; i < 13; i++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                double s = 0;
-#pragma unroll
-                for (int l = 0; l < 13; l++) s += Pm[sidx(i, l)] * bm[l * 4 + j];
-                PB[i * 4 + j] = s;
-            }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-#pragma unroll
-            for (int j = i; j < 4; j++) {
-                double s = (i == j) ? Rh[i] : 0.0;
-#pragma unroll
-                for (int l = 0; l < 13; l++) s += bm[l * 4 + i] * PB[l * 4 + j];
-                S[s4(i, j)] = s;
-            }
-            double s = g[i];
-#pragma unroll
-            for (int l = 0; l < 13; l++) s += bm[l * 4 + i] * hb[l];
-            rho[i] = s;
-        }
-        double Si[10];
-        ok = spd4_inv(S, Si) && ok;
-        // column-wise: w_j = P a_j ; G[:,j] = B' w_j ; M[i][j] = a_i . w_j (i <= j)
-        double G[52], Pn[S_NNZ];
-#pragma unroll
-        for (int j = 0; j < 13; j++) {
-            double w[13];
-#pragma unroll
-            for (int i = 0; i < 13; i++) {
-                double s = 0;
-#pragma unroll
-                for (int l = 0; l < 13; l++) {
-                    if (a_kind(l, j) == 1) s += Pm[sidx(i, l)];
-                    if (a_kind(l, j) == 2) s += Pm[sidx(i, l)] * a[a_idx(l, j)];
-                }
-                w[i] = s;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                double s = 0;
-#pragma unroll
-                for (int l = 0; l < 13; l++) s += bm[l * 4 + c] * w[l];
-                G[c * 13 + j] = s;
-            }
-#pragma unroll
-            for (int i = 0; i <= j; i++) {
-                double s = (i == j) ? P.W[i] : 0.0;
-#pragma unroll
-                for (int l = 0; l < 13; l++) {
-                    if (a_kind(l, i) == 1) s += w[l];
-                    if (a_kind(l, i) == 2) s += a[a_idx(l, i)] * w[l];
-                }
-                Pn[sidx(i, j)] = s;
-            }
-        }
-        // K = Sinv G, d = Sinv rho
-        double K[52], d[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-#pragma unroll
-            for (int j = 0; j < 13; j++) {
-                double s = 0;
-#pragma unroll
-                for (int l = 0; l < 4; l++) s += Si[s4(c, l)] * G[l * 13 + j];
-                K[c * 13 + j] = s;
-            }
-            double s = 0;
-#pragma unroll
-            for (int l = 0; l < 4; l++) s += Si[s4(c, l)] * rho[l];
-            d[c] = s;
-        }
-        // P <- Q + A'PA - G'K ; p <- (q +) A'hb - K'rho
-#pragma unroll
-        for (int i = 0; i < 13; i++)
-#pragma unroll
-            for (int j = i; j < 13; j++) {
-                double s = Pn[sidx(i, j)];
-#pragma unroll
-                for (int l = 0; l < 4; l++) s -= G[l * 13 + i] * K[l * 13 + j];
-                Pm[sidx(i, j)] = s;
-            }
-#pragma unroll
-        for (int i = 0; i < 13; i++) {
-            double s = ABSOLUTE ? P.W[i] * (P.xit[IDX(k, i, 13)] - P.yref[IDX(k, i, 17)]) : 0.0;
-#pragma unroll
-            for (int l = 0; l < 13; l++) {
-                if (a_kind(l, i) == 1) s += hb[l];
-                if (a_kind(l, i) == 2) s += a[a_idx(l, i)] * hb[l];
-            }
-#pragma unroll
-            for (int l = 0; l < 4; l++) s -= K[l * 13 + i] * rho[l];
-            p[i] = s;
-        }
-#pragma unroll
-        for (int e = 0; e < 52; e++) P.K[IDX(k, e, 52)] = K[e];
-#pragma unroll
-        for (int e = 0; e < 10; e++) P.Sinv[IDX(k, e, 10)] = Si[e];
-#pragma unroll
-        for (int e = 0; e < 4; e++) P.d[IDX(k, e, 4)] = d[e];
     }
     return ok;
 }
 
-// x+ = A x + B v (+ b) with the compact A
-template <bool WITH_B>
-__device__ __forceinline__ void propagate(const Params& P, const int inst, const int k, double* __restrict__ x,
-                                          const double* __restrict__ v) {
-    double xn[13];
-#pragma unroll
-    for (int i = 0; i < 13; i++) xn[i] = WITH_B ? P.b[IDX(k, i, 13)] : 0.0;
-#pragma unroll
-    for (int i = 0; i < 13; i++)
-#pragma unroll
-        for (int l = 0; l < 13; l++) {
-            if (a_kind(i, l) == 1) xn[i] += x[l];
-            if (a_kind(i, l) == 2) xn[i] += P.A[IDX(k, a_idx(i, l), A_NNZ)] * x[l];
+// Backward factorisation over stages [0, head).  If FROM_CHK the recursion starts from a stored
+// checkpoint of the unconstrained tail (P.Pchk, affine row zero), else from the terminal cost.
+template <bool ABSOLUTE>
+__device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, const int head, const int chk,
+                                             double* wt) {
+    double Pa[13];
+    if (ABSOLUTE || chk < 0) {
+        const double xN = ABSOLUTE ? ld13(blk(P.xit, t, P.N + 1, P.N, SZ_V13), t) : 0.0;
+        const double yN = ABSOLUTE ? ld13(blk(P.yref_e, t, 1, 0, SZ_V13), t) : 0.0;
+        double qv = 0.0;
+        SFOR(j, 0, 13, { if (t.L == j) qv = P.WN[ext_of(j)] * (xN - yN); });
+        SFOR(j, 0, 13, {
+            const double qj = bc<j>(qv);
+            Pa[j] = (t.L == j) ? P.WN[ext_of(j)] : ((ABSOLUTE && t.L == 13) ? qj : 0.0);
+        });
+    } else {
+        const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + chk) * SZ_P;
+        SFOR(j, 0, 13, {
+            const double v = pc[(j * 4 + t.q) * 13 + imin(t.L, 12)];
+            Pa[j] = t.L < 13 ? v : 0.0;
+        });
+    }
+    bool ok = true;
+    for (int k = head - 1; k >= 0; k--) {
+        ok = factor_stage<ABSOLUTE>(P, t, k, Pa, wt) && ok;
+        if (ABSOLUTE) {
+            // checkpoints of the unconstrained cost-to-go (matrix part only)
+            SFOR(c, 0, N_CHK, {
+                if (k == chk_stage(c)) {
+                    gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + c) * SZ_P;
+                    SFOR(j, 0, 13, { if (t.L < 13) pc[(j * 4 + t.q) * 13 + t.L] = Pa[j]; });
+                }
+            });
         }
-#pragma unroll
-    for (int i = 0; i < 13; i++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) xn[i] += P.Bm[IDX(k, i * 4 + c, 52)] * v[c];
-#pragma unroll
-    for (int i = 0; i < 13; i++) x[i] = xn[i];
+    }
+    return ok;
 }
 
-__device__ __forceinline__ void feedback(const Params& P, const int inst, const int k, const double* __restrict__ x,
-                                         double* __restrict__ v) {
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        double s = -P.d[IDX(k, c, 4)];
-#pragma unroll
-        for (int l = 0; l < 13; l++) s -= P.K[IDX(k, c * 13 + l, 52)] * x[l];
-        v[c] = s;
+// x+ = A x + B v (+ b), all distributed; vr[4] replicated
+template <bool WITH_B>
+__device__ __forceinline__ double propagate(const Params& P, const Lane& t, const int k, const double x,
+                                            const double (&vr)[4]) {
+    double ar[10], br[4];
+    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, ar);
+    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, br);
+    double xn = t.L < 3 ? x : 0.0;
+    if (WITH_B) xn += ld13(blk(P.b, t, P.N, k, SZ_V13), t);
+    dotbc<10, 3>(xn, ar, x);
+    SFOR(a, 0, 4, { xn += br[a] * vr[a]; });
+    return xn;
+}
+
+// v = -K x - d in lanes a < 4
+__device__ __forceinline__ double feedback(const Params& P, const Lane& t, const int k, const double x) {
+    double kr[13];
+    ld_cols4(blk(P.KR, t, P.N, k, SZ_K), t, kr);
+    const double dk = gm(P.d)[i4(P, t, k, t.L & 3)];
+    double v = t.L < 4 ? -dk : 0.0;
+    double acc = 0.0;
+    dotbc<13, 0>(acc, kr, x);
+    v -= acc;
+    settle(v);
+    return v;
+}
+
+// forward sweep of a homogeneous (delta) solve over [0, head): writes the input step to `out`
+__device__ __forceinline__ void sweep_forward_delta(const Params& P, const Lane& t, const int head, gdouble* out) {
+    double x = 0.0;
+    for (int k = 0; k < head; k++) {
+        const double dv = feedback(P, t, k, x);
+        if (t.L < 4) out[i4(P, t, k, t.L)] = dv;
+        double vr[4];
+        SFOR(a, 0, 4, { vr[a] = bc<a>(dv); });
+        if (k + 1 < head) x = propagate<false>(P, t, k, x, vr);
     }
 }
 
-__device__ __forceinline__ double ratio(double z, double dz, double a) {
-    const double t = -z / dz;
-    return (dz < 0.0 && t < a) ? t : a;
-}
-
-// Backward sweep re-using the factorisation for the corrector right-hand side; overwrites d.
-__device__ __forceinline__ void sweep_resolve(const Params& P, const int inst, const double smu) {
-    double p[13];
-#pragma unroll
-    for (int i = 0; i < 13; i++) p[i] = 0.0;
-    for (int k = P.N - 1; k >= 0; k--) {
-        double rho[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const double uk = P.uit[IDX(k, e, 4)];
-            const double v = P.v[IDX(k, e, 4)], tl = P.tl[IDX(k, e, 4)], tu = P.tu[IDX(k, e, 4)];
-            const double ll = P.ll[IDX(k, e, 4)], lu = P.lu[IDX(k, e, 4)];
-            const double dva = P.dva[IDX(k, e, 4)];
-            const double lb = P.u_min - uk, ub = P.u_max - uk;
-            const double rl = v - lb - tl, ru = ub - v - tu;
-            const double dtl = dva + rl, dtu = -dva + ru;
-            const double dll = -ll - (ll / tl) * dtl, dlu = -lu - (lu / tu) * dtu;
-            const double cl = dll * dtl, cu = dlu * dtu;
-            double s = (cl - smu) / tl - (cu - smu) / tu;
-#pragma unroll
-            for (int l = 0; l < 13; l++) s += P.Bm[IDX(k, l * 4 + e, 52)] * p[l];
-            rho[e] = s;
-        }
-        double Si[10];
-#pragma unroll
-        for (int e = 0; e < 10; e++) Si[e] = P.Sinv[IDX(k, e, 10)];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            double s = 0;
-#pragma unroll
-            for (int l = 0; l < 4; l++) s += Si[s4(c, l)] * rho[l];
-            P.d[IDX(k, c, 4)] = s;
-        }
-        double pn[13];
-#pragma unroll
-        for (int i = 0; i < 13; i++) {
-            double s = 0;
-#pragma unroll
-            for (int l = 0; l < 13; l++) {
-                if (a_kind(l, i) == 1) s += p[l];
-                if (a_kind(l, i) == 2) s += P.A[IDX(k, a_idx(l, i), A_NNZ)] * p[l];
-            }
-#pragma unroll
-            for (int l = 0; l < 4; l++) s -= P.K[IDX(k, l * 13 + i, 52)] * rho[l];
-            pn[i] = s;
-        }
-#pragma unroll
-        for (int i = 0; i < 13; i++) p[i] = pn[i];
+// backward sweep re-using the factorisation for the right-hand side P.g (input rows only);
+// overwrites d
+__device__ __forceinline__ void sweep_resolve(const Params& P, const Lane& t, const int head) {
+    double p = 0.0;
+    for (int k = head - 1; k >= 0; k--) {
+        double bcl[13], ac[13], kp[4];
+        ld_cols4(blk(P.BC, t, P.N, k, SZ_B), t, bcl);
+        ld_ac(blk(P.AC, t, P.N, k, SZ_A), t, ac);
+        ld_rows4(blk(P.KP, t, P.N, k, SZ_K), t, kp);
+        const int a = t.L & 3;
+        const double gk = gm(P.g)[i4(P, t, k, a)];
+        double rho = t.L < 4 ? gk : 0.0;
+        dotbc<13, 0>(rho, bcl, p);
+        settle(rho);
+        double rr[4];
+        SFOR(c, 0, 4, { rr[c] = bc<c>(rho); });
+        const gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S) + t.q * 10;
+        double dd = 0.0;
+        SFOR(c, 0, 4, {
+            const int lo = a < c ? a : c, hi = a < c ? c : a;
+            dd += sv[lo * 4 - (lo * (lo - 1)) / 2 + (hi - lo)] * rr[c];
+        });
+        if (t.L < 4) gm(P.d)[i4(P, t, k, a)] = dd;
+        double pn = t.L < 3 ? p : 0.0;
+        dotbc<13, 0>(pn, ac, p);
+        SFOR(c, 0, 4, { pn -= kp[c] * rr[c]; });
+        p = pn;
     }
 }
 
 // =============================================================================================
 // QP solve + RTI update
 // =============================================================================================
-__global__ __launch_bounds__(64) void k_qp_ipm(Params P) {
-    const int inst = blockIdx.x * 64 + threadIdx.x;
-    const bool valid = inst < P.B;
-    LaneIPM L;
-    L.iters = 0;
-    L.status = 0;
-    L.res = 0.0;
-    L.act = false;
-    const double nc = 8.0 * P.N;
+struct RowIPM {  // uniform over the 16 lanes of a row
+    double mu, res;
+    int iters, status;
+    bool act;
+};
 
-    if (valid) {
-        // ---- start: unconstrained minimiser (absolute Riccati solve)
-        bool ok = sweep_factor<true>(P, inst);
-        double x[13];
-#pragma unroll
-        for (int e = 0; e < 13; e++) x[e] = P.x0[IDX(0, e, 13)] - P.xit[IDX(0, e, 13)];
-        bool feas = true;
-        double viol = 0.0;
-        for (int k = 0; k < P.N; k++) {
-            double v[4];
-            feedback(P, inst, k, x, v);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const double uk = P.uit[IDX(k, e, 4)];
+__device__ __forceinline__ double ratio(double z, double dz, double a) {
+    const double tt = -z / dz;
+    return (dz < 0.0 && tt < a) ? tt : a;
+}
+
+// element-wise passes: lane L of a row handles elements e = L, L+16, ... of the head*4 inputs
+struct Elem {
+    double v, tl, tu, ll, lu, rg, lb, ub;
+};
+__device__ __forceinline__ Elem ld_elem(const Params& P, const Lane& t, size_t idx) {
+    Elem e;
+    e.v = gm(P.v)[idx]; e.tl = gm(P.tl)[idx]; e.tu = gm(P.tu)[idx]; e.ll = gm(P.ll)[idx]; e.lu = gm(P.lu)[idx]; e.rg = gm(P.rg)[idx];
+    const double uk = gm(P.uit)[idx];
+    e.lb = P.u_min - uk;
+    e.ub = P.u_max - uk;
+    return e;
+}
+
+__global__ __launch_bounds__(64) void k_qp(Params P) {
+    __shared__ double wtile[4][13 * 17 + 3];
+    const Lane t = lane_id(P);
+    double* wt = wtile[t.q];
+    const int N = P.N;
+    const size_t ibase = (size_t)t.inst * N * 4;  // this instance's 4-vectors
+    RowIPM R;
+    R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
+
+    // ---- start: unconstrained minimiser (absolute Riccati solve over the whole horizon)
+    bool ok = sweep_factor<true>(P, t, N, -1, wt);
+    double viol = 0.0;      // max bound violation of the unconstrained inputs
+    int last_tight = -1;    // last stage whose unconstrained input is outside / near a bound
+    {
+        const double margin = 0.05 * (P.u_max - P.u_min);
+        bool sawnan = false;
+        double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
+        for (int k = 0; k < N; k++) {
+            const double v = feedback(P, t, k, x);
+            if (t.L < 4) {
+                const double uk = gm(P.uit)[i4(P, t, k, t.L)];
                 const double lb = P.u_min - uk, ub = P.u_max - uk;
-                feas = feas && (v[e] >= lb) && (v[e] <= ub);
-                viol = fmax(viol, fmax(lb - v[e], v[e] - ub));
-                P.v[IDX(k, e, 4)] = v[e];
+                gm(P.v)[i4(P, t, k, t.L)] = v;
+                viol = fmax(viol, fmax(lb - v, v - ub));
+                if (v < lb + margin || v > ub - margin) last_tight = k;
+                sawnan = sawnan || !(v == v);
             }
-            propagate<true>(P, inst, k, x, v);
+            double vr[4];
+            SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
+            x = propagate<true>(P, t, k, x, vr);
         }
-        if (!ok || !(viol == viol)) {
-            L.status = 4;
-            L.res = nan("");
-        } else if (!feas) {
-            // ---- shift slacks / multipliers positive; residuals of the start
+        viol = row_max(viol);
+        last_tight = (int)row_max((double)last_tight);
+        if (row_max(sawnan ? 1.0 : 0.0) > 0.0) viol = nan("");
+    }
+    ok = row_min(ok ? 1.0 : 0.0) > 0.0;
+
+    // ---- head of the horizon the interior-point sweeps work on (wave-uniform)
+    int head = N, chk = -1;
+    const bool infeasible = t.valid && ok && (viol > 0.0);
+    if (P.active_horizon) {
+        int want = infeasible ? last_tight + 3 : 0;
+        // wave-uniform maximum over the four instances
+        want = max(want, __shfl_xor(want, 16));
+        want = max(want, __shfl_xor(want, 32));
+        head = N;
+        SFOR(c, 0, N_CHK, {
+            constexpr int cs = chk_stage(N_CHK - 1 - c);
+            if (want <= cs && cs < N) { head = cs; chk = N_CHK - 1 - c; }
+        });
+    }
+
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (!t.valid) {
+            R.status = 0;
+        } else if (!ok || !(viol == viol)) {
+            R.status = 4;
+            R.res = nan("");
+        } else if (infeasible) {
+            // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
             const double mu0 = fmax(viol, P.lam0_min);
             double mu = 0.0, res = 0.0;
-            for (int k = 0; k < P.N; k++) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double uk = P.uit[IDX(k, e, 4)], v = P.v[IDX(k, e, 4)];
-                    const double lb = P.u_min - uk, ub = P.u_max - uk;
-                    const double tl = fmax(v - lb, P.thr0), tu = fmax(ub - v, P.thr0);
-                    const double ll = mu0 / tl, lu = mu0 / tu, rg = -ll + lu;
-                    P.tl[IDX(k, e, 4)] = tl; P.tu[IDX(k, e, 4)] = tu;
-                    P.ll[IDX(k, e, 4)] = ll; P.lu[IDX(k, e, 4)] = lu;
-                    P.rg[IDX(k, e, 4)] = rg;
-                    mu += ll * tl + lu * tu;
-                    res = fmax(res, fmax(ll * tl, lu * tu));
-                    res = fmax(res, fmax(fabs(rg), fmax(fabs(v - lb - tl), fabs(ub - v - tu))));
-                }
+            for (int e = t.L; e < head * 4; e += 16) {
+                const size_t idx = ibase + e;
+                const double uk = gm(P.uit)[idx], v = gm(P.v)[idx];
+                const double lb = P.u_min - uk, ub = P.u_max - uk;
+                const double tl = fmax(v - lb, P.thr0), tu = fmax(ub - v, P.thr0);
+                const double ll = mu0 / tl, lu = mu0 / tu, rg = -ll + lu;
+                gm(P.tl)[idx] = tl; gm(P.tu)[idx] = tu; gm(P.ll)[idx] = ll; gm(P.lu)[idx] = lu; gm(P.rg)[idx] = rg;
+                const double rl = v - lb - tl, ru = ub - v - tu;
+                const double Dl = ll / tl, Du = lu / tu;
+                gm(P.Rh)[idx] = P.W[13 + (e & 3)] + Dl + Du;
+                gm(P.g)[idx] = rg + ll + Dl * rl - lu - Du * ru;
+                mu += ll * tl + lu * tu;
+                res = fmax(res, fmax(fmax(ll * tl, lu * tu), fmax(fabs(rg), fmax(fabs(rl), fabs(ru)))));
             }
-            L.mu = mu / nc;
-            L.res = res;
-            L.act = true;
+            R.mu = row_sum(mu) / (8.0 * head);
+            R.res = row_max(res);
+            R.act = true;
+            R.status = 2;
         }
-    }
 
-    // ---- interior-point loop, wave-uniform trip count
-    while (__any(L.act)) {
-        if (L.act) {
-            if (!(L.res == L.res)) { L.status = 4; L.act = false; }
-            else if (L.res <= P.tol) { L.status = 0; L.act = false; }
-            else if (L.iters >= P.max_iter) { L.status = 2; L.act = false; }
-        }
-        if (!__any(L.act)) break;
-        if (L.act) {
-            L.iters++;
-            // predictor: factorise, forward
-            const bool ok = sweep_factor<false>(P, inst);
-            double x[13];
-#pragma unroll
-            for (int e = 0; e < 13; e++) x[e] = 0.0;
-            double a = 1.0;
-            for (int k = 0; k < P.N; k++) {
-                double dv[4];
-                feedback(P, inst, k, x, dv);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double uk = P.uit[IDX(k, e, 4)];
-                    const double v = P.v[IDX(k, e, 4)], tl = P.tl[IDX(k, e, 4)], tu = P.tu[IDX(k, e, 4)];
-                    const double ll = P.ll[IDX(k, e, 4)], lu = P.lu[IDX(k, e, 4)];
-                    const double lb = P.u_min - uk, ub = P.u_max - uk;
-                    const double rl = v - lb - tl, ru = ub - v - tu;
-                    const double dtl = dv[e] + rl, dtu = -dv[e] + ru;
-                    const double dll = -ll - (ll / tl) * dtl, dlu = -lu - (lu / tu) * dtu;
-                    a = ratio(tl, dtl, a); a = ratio(tu, dtu, a);
-                    a = ratio(ll, dll, a); a = ratio(lu, dlu, a);
-                    P.dva[IDX(k, e, 4)] = dv[e];
-                }
-                propagate<false>(P, inst, k, x, dv);
+        // ---- interior-point loop, wave-uniform trip count
+        while (__any(R.act)) {
+            if (R.act) {
+                if (!(R.res == R.res)) { R.status = 4; R.act = false; }
+                else if (R.res <= P.tol) { R.status = 0; R.act = false; }
+                else if (R.iters >= P.max_iter) { R.status = 2; R.act = false; }
             }
-            // mu_aff
-            double mu_aff = 0.0;
-            for (int k = 0; k < P.N; k++) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double uk = P.uit[IDX(k, e, 4)];
-                    const double v = P.v[IDX(k, e, 4)], tl = P.tl[IDX(k, e, 4)], tu = P.tu[IDX(k, e, 4)];
-                    const double ll = P.ll[IDX(k, e, 4)], lu = P.lu[IDX(k, e, 4)];
-                    const double dva = P.dva[IDX(k, e, 4)];
-                    const double lb = P.u_min - uk, ub = P.u_max - uk;
-                    const double rl = v - lb - tl, ru = ub - v - tu;
+            if (!__any(R.act)) break;
+            if (R.act) R.iters++;
+            // predictor: factorise (R^, g from the element-wise pass), forward
+            const bool fok = sweep_factor<false>(P, t, head, chk, wt);
+            sweep_forward_delta(P, t, head, gm(P.dva));
+            // affine step length, mu_aff, centering; corrector right-hand side
+            double smu;
+            {
+                double a = 1.0;
+                for (int e = t.L; e < head * 4; e += 16) {
+                    const Elem el = ld_elem(P, t, ibase + e);
+                    const double dva = gm(P.dva)[ibase + e];
+                    const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
                     const double dtl = dva + rl, dtu = -dva + ru;
-                    const double dll = -ll - (ll / tl) * dtl, dlu = -lu - (lu / tu) * dtu;
-                    mu_aff += (ll + a * dll) * (tl + a * dtl) + (lu + a * dlu) * (tu + a * dtu);
+                    const double dll = -el.ll - (el.ll / el.tl) * dtl, dlu = -el.lu - (el.lu / el.tu) * dtu;
+                    a = ratio(el.tl, dtl, a); a = ratio(el.tu, dtu, a);
+                    a = ratio(el.ll, dll, a); a = ratio(el.lu, dlu, a);
+                }
+                a = row_min(a);
+                double mu_aff = 0.0;
+                for (int e = t.L; e < head * 4; e += 16) {
+                    const Elem el = ld_elem(P, t, ibase + e);
+                    const double dva = gm(P.dva)[ibase + e];
+                    const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
+                    const double dtl = dva + rl, dtu = -dva + ru;
+                    const double dll = -el.ll - (el.ll / el.tl) * dtl, dlu = -el.lu - (el.lu / el.tu) * dtu;
+                    mu_aff += (el.ll + a * dll) * (el.tl + a * dtl) + (el.lu + a * dlu) * (el.tu + a * dtu);
+                }
+                mu_aff = row_sum(mu_aff) / (8.0 * head);
+                const double sr = mu_aff / R.mu;
+                smu = sr * sr * sr * R.mu;
+                for (int e = t.L; e < head * 4; e += 16) {
+                    const Elem el = ld_elem(P, t, ibase + e);
+                    const double dva = gm(P.dva)[ibase + e];
+                    const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
+                    const double dtl = dva + rl, dtu = -dva + ru;
+                    const double dll = -el.ll - (el.ll / el.tl) * dtl, dlu = -el.lu - (el.lu / el.tu) * dtu;
+                    const double cl = dll * dtl, cu = dlu * dtu;
+                    gm(P.g)[ibase + e] = (cl - smu) / el.tl - (cu - smu) / el.tu;
                 }
             }
-            mu_aff /= nc;
-            const double sr = mu_aff / L.mu, smu = sr * sr * sr * L.mu;
             // corrector: re-solve, forward
-            sweep_resolve(P, inst, smu);
-#pragma unroll
-            for (int e = 0; e < 13; e++) x[e] = 0.0;
-            a = 1.0;
-            for (int k = 0; k < P.N; k++) {
-                double dvc[4];
-                feedback(P, inst, k, x, dvc);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double uk = P.uit[IDX(k, e, 4)];
-                    const double v = P.v[IDX(k, e, 4)], tl = P.tl[IDX(k, e, 4)], tu = P.tu[IDX(k, e, 4)];
-                    const double ll = P.ll[IDX(k, e, 4)], lu = P.lu[IDX(k, e, 4)];
-                    const double dva = P.dva[IDX(k, e, 4)];
-                    const double lb = P.u_min - uk, ub = P.u_max - uk;
-                    const double rl = v - lb - tl, ru = ub - v - tu;
+            sweep_resolve(P, t, head);
+            sweep_forward_delta(P, t, head, gm(P.dvc));
+            // step, update, residuals of the new point, next R^ and g
+            {
+                double a = 1.0;
+                for (int e = t.L; e < head * 4; e += 16) {
+                    const Elem el = ld_elem(P, t, ibase + e);
+                    const double dva = gm(P.dva)[ibase + e], dv = dva + gm(P.dvc)[ibase + e];
+                    const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
                     const double dtla = dva + rl, dtua = -dva + ru;
-                    const double Dl = ll / tl, Du = lu / tu;
-                    const double cl = (-ll - Dl * dtla) * dtla, cu = (-lu - Du * dtua) * dtua;
-                    const double dv = dva + dvc[e];
+                    const double Dl = el.ll / el.tl, Du = el.lu / el.tu;
+                    const double cl = (-el.ll - Dl * dtla) * dtla, cu = (-el.lu - Du * dtua) * dtua;
                     const double dtl = dv + rl, dtu = -dv + ru;
-                    const double dll = (smu - cl) / tl - ll - Dl * dtl, dlu = (smu - cu) / tu - lu - Du * dtu;
-                    a = ratio(tl, dtl, a); a = ratio(tu, dtu, a);
-                    a = ratio(ll, dll, a); a = ratio(lu, dlu, a);
-                    P.dvc[IDX(k, e, 4)] = dvc[e];
+                    const double dll = (smu - cl) / el.tl - el.ll - Dl * dtl, dlu = (smu - cu) / el.tu - el.lu - Du * dtu;
+                    a = ratio(el.tl, dtl, a); a = ratio(el.tu, dtu, a);
+                    a = ratio(el.ll, dll, a); a = ratio(el.lu, dlu, a);
                 }
-                propagate<false>(P, inst, k, x, dvc);
-            }
-            a = fmin(1.0, P.tau * a);
-            // update + residuals of the new point
-            double mu = 0.0, res = 0.0;
-            for (int k = 0; k < P.N; k++) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const double uk = P.uit[IDX(k, e, 4)];
-                    double v = P.v[IDX(k, e, 4)], tl = P.tl[IDX(k, e, 4)], tu = P.tu[IDX(k, e, 4)];
-                    double ll = P.ll[IDX(k, e, 4)], lu = P.lu[IDX(k, e, 4)], rg = P.rg[IDX(k, e, 4)];
-                    const double dva = P.dva[IDX(k, e, 4)], dvc = P.dvc[IDX(k, e, 4)];
-                    const double lb = P.u_min - uk, ub = P.u_max - uk;
-                    const double rl = v - lb - tl, ru = ub - v - tu;
+                a = fmin(1.0, P.tau * row_min(a));
+                double mu = 0.0, res = 0.0;
+                for (int e = t.L; e < head * 4; e += 16) {
+                    const size_t idx = ibase + e;
+                    const Elem el = ld_elem(P, t, idx);
+                    const double dva = gm(P.dva)[idx], dv = dva + gm(P.dvc)[idx];
+                    const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
                     const double dtla = dva + rl, dtua = -dva + ru;
-                    const double Dl = ll / tl, Du = lu / tu;
-                    const double cl = (-ll - Dl * dtla) * dtla, cu = (-lu - Du * dtua) * dtua;
-                    const double dv = dva + dvc;
+                    const double Dl0 = el.ll / el.tl, Du0 = el.lu / el.tu;
+                    const double cl = (-el.ll - Dl0 * dtla) * dtla, cu = (-el.lu - Du0 * dtua) * dtua;
                     const double dtl = dv + rl, dtu = -dv + ru;
-                    const double dll = (smu - cl) / tl - ll - Dl * dtl, dlu = (smu - cu) / tu - lu - Du * dtu;
-                    v += a * dv; tl += a * dtl; tu += a * dtu; ll += a * dll; lu += a * dlu;
-                    rg *= (1.0 - a);
-                    P.v[IDX(k, e, 4)] = v; P.tl[IDX(k, e, 4)] = tl; P.tu[IDX(k, e, 4)] = tu;
-                    P.ll[IDX(k, e, 4)] = ll; P.lu[IDX(k, e, 4)] = lu; P.rg[IDX(k, e, 4)] = rg;
+                    const double dll = (smu - cl) / el.tl - el.ll - Dl0 * dtl, dlu = (smu - cu) / el.tu - el.lu - Du0 * dtu;
+                    const double v = el.v + a * dv, tl = el.tl + a * dtl, tu = el.tu + a * dtu;
+                    const double ll = el.ll + a * dll, lu = el.lu + a * dlu, rg = el.rg * (1.0 - a);
+                    const double rln = v - el.lb - tl, run = el.ub - v - tu;
+                    const double Dl = ll / tl, Du = lu / tu;
+                    if (R.act) {
+                        gm(P.v)[idx] = v; gm(P.tl)[idx] = tl; gm(P.tu)[idx] = tu; gm(P.ll)[idx] = ll; gm(P.lu)[idx] = lu; gm(P.rg)[idx] = rg;
+                        gm(P.Rh)[idx] = P.W[13 + (e & 3)] + Dl + Du;
+                        gm(P.g)[idx] = rg + ll + Dl * rln - lu - Du * run;
+                    }
                     mu += ll * tl + lu * tu;
-                    res = fmax(res, fmax(ll * tl, lu * tu));
-                    res = fmax(res, fmax(fabs(rg), fmax(fabs(v - lb - tl), fabs(ub - v - tu))));
+                    res = fmax(res, fmax(fmax(ll * tl, lu * tu), fmax(fabs(rg), fmax(fabs(rln), fabs(run)))));
+                }
+                mu = row_sum(mu) / (8.0 * head);
+                res = row_max(res);
+                const bool fok_row = row_min(fok ? 1.0 : 0.0) > 0.0;
+                if (R.act) {
+                    R.mu = mu;
+                    R.res = fok_row ? res : nan("");
                 }
             }
-            L.mu = mu / nc;
-            L.res = ok ? res : nan("");
+        }
+
+        // ---- expand: dynamics-exact roll-out; head stages use the QP inputs, tail stages the
+        //      unconstrained feedback law of the start solve, whose inputs must stay inside the box
+        bool tail_ok = true;
+        {
+            double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
+            for (int k = 0; k < N; k++) {
+                st13(blk(P.dx, t, N + 1, k, SZ_V13), t, x);
+                double v;
+                if (k < head) {
+                    const double vk = gm(P.v)[i4(P, t, k, t.L & 3)];
+                    v = t.L < 4 ? vk : 0.0;
+                } else {
+                    v = feedback(P, t, k, x);
+                    if (t.L < 4) {
+                        const double uk = gm(P.uit)[i4(P, t, k, t.L)];
+                        tail_ok = tail_ok && (v >= P.u_min - uk) && (v <= P.u_max - uk);
+                        gm(P.v)[i4(P, t, k, t.L)] = v;
+                    }
+                }
+                double vr[4];
+                SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
+                x = propagate<true>(P, t, k, x, vr);
+            }
+            st13(blk(P.dx, t, N + 1, N, SZ_V13), t, x);
+            tail_ok = row_min(tail_ok ? 1.0 : 0.0) > 0.0;
+        }
+        const bool redo = t.valid && R.status != 4 && !tail_ok && head < N;
+        if (!__any(redo)) break;
+        // rare: a tail input left the box -> solve again over the full horizon (whole wave)
+        head = N; chk = -1;
+        R.iters = 0; R.status = 0; R.res = 0.0; R.act = false;
+        ok = sweep_factor<true>(P, t, N, -1, wt);
+        ok = row_min(ok ? 1.0 : 0.0) > 0.0;
+        {
+            double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
+            for (int k = 0; k < N; k++) {
+                const double v = feedback(P, t, k, x);
+                if (t.L < 4) gm(P.v)[i4(P, t, k, t.L)] = v;
+                double vr[4];
+                SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
+                x = propagate<true>(P, t, k, x, vr);
+            }
         }
     }
 
-    // ---- expand (dynamics-exact state roll-out of the final inputs) + full RTI step
-    if (valid) {
-        double x[13];
-#pragma unroll
-        for (int e = 0; e < 13; e++) x[e] = P.x0[IDX(0, e, 13)] - P.xit[IDX(0, e, 13)];
-        if (L.status != 4) {
-            for (int k = 0; k < P.N; k++) {
-                double v[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = P.v[IDX(k, e, 4)];
-                double xk[13];
-#pragma unroll
-                for (int e = 0; e < 13; e++) xk[e] = x[e];
-                propagate<true>(P, inst, k, x, v);
-#pragma unroll
-                for (int e = 0; e < 13; e++) P.xit[IDX(k, e, 13)] += xk[e];
-#pragma unroll
-                for (int e = 0; e < 4; e++) P.uit[IDX(k, e, 4)] += v[e];
+    // ---- full RTI step (iterate += step) and statistics
+    if (t.valid) {
+        if (R.status != 4) {
+            for (int k = 0; k <= N; k++) {
+                gdouble* xb = blk(P.xit, t, N + 1, k, SZ_V13);
+                const double dxk = ld13(blk(P.dx, t, N + 1, k, SZ_V13), t);
+                if (t.L < 13) xb[t.q * 13 + t.L] += dxk;
             }
-#pragma unroll
-            for (int e = 0; e < 13; e++) P.xit[IDX(P.N, e, 13)] += x[e];
+            for (int e = t.L; e < N * 4; e += 16) gm(P.uit)[ibase + e] += gm(P.v)[ibase + e];
         }
-        P.status[inst] = L.status;
-        P.iters[inst] = L.iters;
-        P.res[inst] = L.res;
+        if (t.L == 0) {
+            gm(P.status)[t.inst] = R.status;
+            gm(P.iters)[t.inst] = R.iters;
+            gm(P.res)[t.inst] = R.res;
+            gm(P.head)[t.inst] = head;
+        }
     }
 }
 
@@ -666,54 +811,67 @@ __global__ void k_sim(int B, const double* __restrict__ x, const double* __restr
     for (int e = 0; e < 13; e++) xn[(size_t)i * 13 + e] = xc[e];
 }
 
-// AoS [B][S][E] (caller) -> SoA [S][E][Bp] (workspace) and back
-__global__ void k_aos2soa(int B, int Bp, int S, int E, const double* __restrict__ aos, double* __restrict__ soa) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B) return;
-    const int SE = S * E;
-    for (int se = 0; se < SE; se++) soa[(size_t)se * Bp + i] = aos[(size_t)i * SE + se];
+// AoS [B][S][E] (external order) -> wave-blocked [wave][S][inst 0..3][E]; if perm13 the first 13
+// entries of a row are permuted to the internal state order.  E == 4 fields are instance-major
+// ([inst][S][4]) and handled by the same formula with a different block shape.
+__device__ __forceinline__ size_t blk_index(int i, int s, int e, int S, int E) {
+    if (E == 4) return ((size_t)i * S + s) * 4 + e;
+    return (((size_t)(i >> 2) * S + s) * 4 + (i & 3)) * E + e;
 }
-__global__ void k_soa2aos(int B, int Bp, int S, int E, int s0, int Stot, const double* __restrict__ soa,
-                          double* __restrict__ aos) {
-    // copies stages s0 .. s0+S-1 of an SoA field with Stot stages into AoS [B][S][E]
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B) return;
-    for (int s = 0; s < S; s++)
-        for (int e = 0; e < E; e++) aos[((size_t)i * S + s) * E + e] = soa[((size_t)(s0 + s) * E + e) * Bp + i];
+__global__ void k_put(int B, int S, int E, int perm13, const double* __restrict__ aos, double* __restrict__ blkp) {
+    const size_t n = (size_t)B * S * E;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(idx % E);
+        const int s = (int)((idx / E) % S);
+        const int i = (int)(idx / ((size_t)E * S));
+        const int ei = (perm13 && e < 13) ? int_of(e) : e;
+        blkp[blk_index(i, s, ei, S, E)] = aos[idx];
+    }
+}
+__global__ void k_get(int B, int S, int E, int perm13, int s0, int Stot, const double* __restrict__ blkp,
+                      double* __restrict__ aos) {
+    const size_t n = (size_t)B * S * E;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(idx % E);
+        const int s = (int)((idx / E) % S);
+        const int i = (int)(idx / ((size_t)E * S));
+        const int ei = (perm13 && e < 13) ? int_of(e) : e;
+        aos[idx] = blkp[blk_index(i, s0 + s, ei, Stot, E)];
+    }
 }
 __global__ void k_init_iterate(Params P, int mode) {
-    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
-    if (inst >= P.B) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.B) return;
     // generate_c_code.py:58,135 / SURVEY App. D-3
     const double hov = sqrt((MQ * G0) / (4 * CT));
     for (int k = 0; k <= P.N; k++)
-        for (int e = 0; e < 13; e++)
-            P.xit[IDX(k, e, 13)] = (mode == 1) ? P.x0[IDX(0, e, 13)] : (e == 3 ? 1.0 : 0.0);
+        for (int e = 0; e < 13; e++) {
+            const double x0e = P.x0[blk_index(i, 0, int_of(e), 1, 13)];
+            P.xit[blk_index(i, k, int_of(e), P.N + 1, 13)] = (mode == 1) ? x0e : (e == 3 ? 1.0 : 0.0);
+        }
     for (int k = 0; k < P.N; k++)
-        for (int e = 0; e < 4; e++) P.uit[IDX(k, e, 4)] = (mode == 1) ? hov : 0.0;
+        for (int e = 0; e < 4; e++) P.uit[blk_index(i, k, e, P.N, 4)] = (mode == 1) ? hov : 0.0;
 }
 
-}  // namespace cfn
-
 // ---------------------------------------------------------------------------------------------
-// launchers (called from cfnmpc_api.cpp through plain C++ declarations in cfnmpc_ws.hpp)
+// launchers
 // ---------------------------------------------------------------------------------------------
-namespace cfn {
-
 void launch_linearise(const Params& P, hipStream_t st) {
-    hipLaunchKernelGGL(k_linearise, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(k_linearise, dim3(P.NW), dim3(64), 0, st, P);
 }
-void launch_qp(const Params& P, hipStream_t st) {
-    hipLaunchKernelGGL(k_qp_ipm, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
-}
+void launch_qp(const Params& P, hipStream_t st) { hipLaunchKernelGGL(k_qp, dim3(P.NW), dim3(64), 0, st, P); }
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st) {
     hipLaunchKernelGGL(k_sim, dim3((B + 255) / 256), dim3(256), 0, st, B, x, u, T, steps, xn);
 }
-void launch_aos2soa(int B, int Bp, int S, int E, const double* aos, double* soa, hipStream_t st) {
-    hipLaunchKernelGGL(k_aos2soa, dim3((B + 255) / 256), dim3(256), 0, st, B, Bp, S, E, aos, soa);
+static inline int grid_for(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
-void launch_soa2aos(int B, int Bp, int S, int E, int s0, int Stot, const double* soa, double* aos, hipStream_t st) {
-    hipLaunchKernelGGL(k_soa2aos, dim3((B + 255) / 256), dim3(256), 0, st, B, Bp, S, E, s0, Stot, soa, aos);
+void launch_put(int B, int S, int E, int perm13, const double* aos, double* blkp, hipStream_t st) {
+    hipLaunchKernelGGL(k_put, dim3(grid_for((size_t)B * S * E)), dim3(256), 0, st, B, S, E, perm13, aos, blkp);
+}
+void launch_get(int B, int S, int E, int perm13, int s0, int Stot, const double* blkp, double* aos, hipStream_t st) {
+    hipLaunchKernelGGL(k_get, dim3(grid_for((size_t)B * S * E)), dim3(256), 0, st, B, S, E, perm13, s0, Stot, blkp, aos);
 }
 void launch_init_iterate(const Params& P, int mode, hipStream_t st) {
     hipLaunchKernelGGL(k_init_iterate, dim3((P.B + 255) / 256), dim3(256), 0, st, P, mode);

@@ -1,44 +1,95 @@
 // cfnmpc_ws.hpp -- device workspace description shared by the kernels and the C-ABI layer.
 //
-// HBM layout: every field is SoA with the instance index fastest,
-//     field[(stage * E + elem) * Bp + inst],      Bp = batch rounded up to 64,
-// FP64 throughout (the reference computes in double: BLASFEO d_ API, acados_mpc.cpp:68).
+// v2 mapping ("row groups"): ONE NMPC INSTANCE PER 16-LANE DPP ROW, four instances per
+// wavefront.  Lane i < 13 of a row owns ROW i of every 13-row object (P, A, B, K', W, ...) and
+// element i of every 13-vector; lane 13 carries the affine part of the Riccati recursion as
+// a 14th row (augmented recursion); lanes 14,15 idle.  Products are formed with
+//     acc += own * row_newbcast<l>(src)          (v_mov_b64_dpp + v_fmac_f64)
+// so no LDS / shuffles are needed for C = X * Y when X is row-distributed.
+//
+// Internal state order (lanes): p(0..2) v(3..5) q(6..9) w(10..12) -- i.e. the reference's
+// order (acados_mpc.cpp:117-131) with the v and q blocks swapped, which makes
+// A = dPhi/dx block UPPER triangular:
+//            p  v  q  w
+//        p [ I  *  *  * ]
+//        v [ 0  *  *  * ]     97 stored entries
+//        q [ 0  0  *  * ]
+//        w [ 0  0  0  * ]
+//
+// HBM layout: wave-blocked.  For a field with S doubles per
+// (wave, stage):   base + ((size_t)wave * stages + stage) * S + offset_in_block,
+// and inside a block  [slot][instance-in-wave 0..3][contiguous lane range]  so that every
+// load/store instruction of a wave touches one contiguous run of bytes with no padding.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace cfn {
 
+// ---- internal <-> external state order -------------------------------------------------
+__host__ __device__ constexpr int ext_of(int i) { return i < 3 ? i : (i < 6 ? i + 4 : (i < 10 ? i - 3 : i)); }
+__host__ __device__ constexpr int int_of(int e) { return e < 3 ? e : (e < 7 ? e + 3 : (e < 10 ? e - 4 : e)); }
+
+// ---- A in "row form" (AR): lane i holds A[i][3..12] in slots 0..9 (slot s <-> column s+3),
+//      structurally zero slots are not stored.  Rows that own column c: c in v -> rows 0..5,
+//      c in q -> rows 0..9, c in w -> rows 0..12  (a lane prefix).
+__host__ __device__ constexpr int ar_n(int s) { return s < 3 ? 6 : (s < 7 ? 10 : 13); }
+__host__ __device__ constexpr int ar_pre(int s) { return s < 3 ? 6 * s : (s < 7 ? 18 + 10 * (s - 3) : 58 + 13 * (s - 7)); }
+// ---- A in "column form" (AC): lane c holds A[0..n_c-1][c] in slots r (slot r <-> row r).
+//      Columns that own row r: r in p,v -> lanes 3..12, r in q -> lanes 6..12, r in w -> 10..12.
+__host__ __device__ constexpr int ac_first(int r) { return r < 6 ? 3 : (r < 10 ? 6 : 10); }
+__host__ __device__ constexpr int ac_m(int r) { return 13 - ac_first(r); }
+__host__ __device__ constexpr int ac_pre(int r) { return r < 6 ? 10 * r : (r < 10 ? 60 + 7 * (r - 6) : 88 + 3 * (r - 10)); }
+static_assert(ar_pre(9) + ar_n(9) == 97 && ac_pre(12) + ac_m(12) == 97, "97 stored entries of dPhi/dx");
+
+// doubles per (wave, stage) block
+constexpr int SZ_A = 4 * 97;   // AR or AC
+constexpr int SZ_B = 4 * 52;   // BR: [a][inst][13]      BC: [l][inst][4]
+constexpr int SZ_K = 4 * 52;   // KP ("K'", lane i holds K[0..3][i]): [a][inst][13] ; KR (lane a holds K[a][0..12]): [l][inst][4]
+constexpr int SZ_V13 = 4 * 13; // 13-vectors: [inst][13]
+constexpr int SZ_V4 = 4 * 4;   // 4-vectors:  [inst][4]
+constexpr int SZ_S = 4 * 10;   // packed symmetric 4x4: [inst][10]
+constexpr int SZ_Y = 4 * 17;   // yref row: [inst][17] (first 13 in internal order)
+constexpr int SZ_P = 4 * 13 * 13;  // a row-distributed 13x13: [col j][inst][13]
+
+constexpr int N_CHK = 6;  // Riccati checkpoints for the active-horizon QP (stage indices below)
+__host__ __device__ constexpr int chk_stage(int c) { return c == 0 ? 4 : (c == 1 ? 8 : (c == 2 ? 12 : (c == 3 ? 16 : (c == 4 ? 24 : 32)))); }
+
 struct Params {
-    int B, Bp, N;
+    int B, NW, N;  // instances, waves (= ceil(B/4)), horizon
     double dt;
-    double W[17], WN[13];
+    double W[17], WN[13];  // external order, as in cfnmpc_opts
     double u_min, u_max, tol, tau, thr0, lam0_min;
     int max_iter;
+    int active_horizon;  // 1: interior-point sweeps only over the stages that can saturate
     // persistent iterate (acados nlp_out, acados_mpc.cpp:77) and per-step inputs
-    double *xit;     // [(N+1)][13]
-    double *uit;     // [N][4]
-    double *x0;      // [1][13]
-    double *yref;    // [N][17]
-    double *yref_e;  // [1][13]
-    // linearisation (written by k_linearise, read by every Riccati sweep)
-    double *A;   // [N][97]  compact dPhi/dx (cfnmpc_model.hpp)
-    double *Bm;  // [N][52]  dPhi/du, row-major 13x4
-    double *b;   // [N][13]  Phi(x_k,u_k) - x_{k+1}
+    double *xit;     // (N+1) stages x SZ_V13
+    double *uit;     // N x SZ_V4
+    double *x0;      // 1 x SZ_V13
+    double *yref;    // N x SZ_Y
+    double *yref_e;  // 1 x SZ_V13
+    // linearisation
+    double *AR, *AC;  // N x SZ_A
+    double *BR, *BC;  // N x SZ_B
+    double *b;        // N x SZ_V13
     // Riccati factors
-    double *K;     // [N][52]  feedback gain, row-major 4x13
-    double *Sinv;  // [N][10]  inverse of R^ + B'PB, packed symmetric
-    double *d;     // [N][4]   feed-forward
-    // interior-point state
-    double *v, *tl, *tu, *ll, *lu, *rg, *dva, *dvc;  // [N][4] each
-    int *status, *iters;
+    double *KP, *KR;  // N x SZ_K
+    double *Sinv;     // N x SZ_S
+    double *d;        // N x SZ_V4
+    double *Pchk;     // N_CHK x SZ_P   cost-to-go of the unconstrained tail at the checkpoints
+    // interior-point state, N x SZ_V4 each
+    double *v, *tl, *tu, *ll, *lu, *rg, *dva, *dvc, *Rh, *g;
+    double *dx;  // (N+1) x SZ_V13: step in x of the accepted QP solution (commit buffer)
+    int *status, *iters, *head;  // per instance
     double *res;
 };
 
 void launch_linearise(const Params& P, hipStream_t st);
 void launch_qp(const Params& P, hipStream_t st);
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st);
-void launch_aos2soa(int B, int Bp, int S, int E, const double* aos, double* soa, hipStream_t st);
-void launch_soa2aos(int B, int Bp, int S, int E, int s0, int Stot, const double* soa, double* aos, hipStream_t st);
+// AoS [B][S][E] (external order) <-> wave-blocked vectors; perm13: first 13 entries of each
+// row are states and are permuted to the internal order.
+void launch_put(int B, int S, int E, int perm13, const double* aos, double* blk, hipStream_t st);
+void launch_get(int B, int S, int E, int perm13, int s0, int Stot, const double* blk, double* aos, hipStream_t st);
 void launch_init_iterate(const Params& P, int mode, hipStream_t st);
 
 }  // namespace cfn

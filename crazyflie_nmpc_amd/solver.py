@@ -144,11 +144,16 @@ class BatchSolver:
                                         rs.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_get_stats")
         return st, it, rs
 
-    def get_linearisation(self):
+    def get_linearisation(self, form=0):
         A = np.empty((self.B, self.N, NX, NX)); Bm = np.empty((self.B, self.N, NX, NU)); b = np.empty((self.B, self.N, NX))
-        _check(self._L.cfnmpc_debug_get_linearisation(self._h, A.ctypes.data_as(C.c_void_p), Bm.ctypes.data_as(C.c_void_p),
+        _check(self._L.cfnmpc_debug_get_linearisation(self._h, int(form), A.ctypes.data_as(C.c_void_p), Bm.ctypes.data_as(C.c_void_p),
                                                       b.ctypes.data_as(C.c_void_p)), "cfnmpc_debug_get_linearisation")
         return A, Bm, b
+
+    def heads(self):
+        h = np.empty(self.B, dtype=np.int32)
+        _check(self._L.cfnmpc_debug_get_head(self._h, h.ctypes.data_as(C.c_void_p)), "cfnmpc_debug_get_head")
+        return h
 
 
 def sim(x, u, T=0.06, steps=4, out=None):

@@ -54,6 +54,10 @@ typedef struct cfnmpc_opts {
     double tau;          /* QP: fraction to the boundary (0.995)                           */
     double thr0;         /* QP: slack floor of the starting point (1.0)                    */
     double lam0_min;     /* QP: complementarity floor of the starting point (1e-2)         */
+    int active_horizon;  /* QP: 1 = interior-point sweeps only over the head of the horizon
+                            whose inputs can saturate; the unconstrained tail keeps its
+                            Riccati feedback law and is verified afterwards (exact); 0 = all
+                            N stages in every sweep (default 1)                              */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);
@@ -95,12 +99,15 @@ int cfnmpc_get_stats(cfnmpc_solver *s, int *status /*[B]*/, int *qp_iter /*[B]*/
  * xn = RK4(x, u) over T seconds in `steps` sub-steps.  Stateless. */
 int cfnmpc_sim(int batch, const double *x, const double *u, double T, int steps, double *xn, int on_device, void *stream);
 
-/* Kernel-level access for parity tests (oracle comparison of the linearisation):
- * copies the stage blocks of the last linearisation, dense row-major:
- * A [B][N][13][13], Bm [B][N][13][4], b [B][N][13] (host pointers). */
-int cfnmpc_debug_get_linearisation(cfnmpc_solver *s, double *A, double *Bm, double *b);
+/* Kernel-level access for parity tests (oracle comparison of the linearisation): copies the
+ * stage blocks of the last linearisation as dense row-major arrays in the reference's state
+ * order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13] (host pointers).  form 0 decodes the
+ * row-distributed copies (AR, BR), form 1 the column-distributed ones (AC, BC). */
+int cfnmpc_debug_get_linearisation(cfnmpc_solver *s, int form, double *A, double *Bm, double *b);
 /* runs only the linearisation kernel */
 int cfnmpc_debug_linearise(cfnmpc_solver *s, void *stream);
+/* number of leading stages the last QP's interior-point sweeps covered, per instance [B] (host) */
+int cfnmpc_debug_get_head(cfnmpc_solver *s, int *head);
 
 const char *cfnmpc_version(void);
 

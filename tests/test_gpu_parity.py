@@ -41,33 +41,43 @@ def test_linearisation_matches_oracle(oracle, cref, B):
     s = BatchSolver(B)
     s.set_x0(x0); s.set_yref(yref, yref_e); s.set_iterate(xit, uit)
     s.linearise_only()
-    A, Bm, b = s.get_linearisation()
     opts = cref.default_opts()
-    for i in range(min(B, 8)):
-        Ar, Br, br, _q, _r = cref.linearise(opts, xit[i].copy(), uit[i].copy(), x0[i].copy(), yref[i].copy(), yref_e[i].copy())
-        assert np.abs(A[i] - Ar).max() < 1e-12   # FP64, same RK4+VDE arithmetic up to association
-        assert np.abs(Bm[i] - Br).max() < 1e-12
-        assert np.abs(b[i] - br).max() < 1e-12
+    for form in (0, 1):   # row-distributed (AR, BR) and column-distributed (AC, BC) copies
+        A, Bm, b = s.get_linearisation(form)
+        for i in list(range(min(B, 6))) + [B - 1]:
+            Ar, Br, br, _q, _r = cref.linearise(opts, xit[i].copy(), uit[i].copy(), x0[i].copy(), yref[i].copy(), yref_e[i].copy())
+            assert np.abs(A[i] - Ar).max() < 1e-12   # FP64, same RK4+VDE arithmetic up to association
+            assert np.abs(Bm[i] - Br).max() < 1e-12
+            assert np.abs(b[i] - br).max() < 1e-12
 
 
-@pytest.mark.parametrize("init", ["hover", "acados"])
-def test_closed_loop_rti_matches_oracle(oracle, cref, init):
-    """20 closed-loop RTI steps of hover regulation for 192 instances (3 waves): iterate,
-    controls and QP statistics must match the CPU restatement."""
-    from crazyflie_nmpc_amd import BatchSolver, sim
+@pytest.mark.parametrize("init,active_horizon,tol", [("hover", 0, 1e-8), ("acados", 0, 1e-8),
+                                                     ("hover", 1, 1e-11), ("hover", 1, 1e-8)])
+def test_closed_loop_rti_matches_oracle(oracle, cref, init, active_horizon, tol):
+    """20 closed-loop RTI steps of hover regulation for 192 instances (48 waves): iterate,
+    controls and QP statistics against the CPU restatement.
+
+    active_horizon=0 runs exactly the oracle's algorithm (all N stages in every interior-point
+    sweep): FP64 agreement 1e-8.  active_horizon=1 restricts the interior-point sweeps to the
+    head of the horizon (exact reformulation, different central path): both solvers converge
+    to the same unique QP solution, so agreement is set by the QP tolerance (tested at 1e-11
+    -> 1e-8 on the iterate, and at the default 1e-8 -> 1e-5)."""
+    from crazyflie_nmpc_amd import BatchSolver, sim, default_opts
     from crazyflie_nmpc_amd.solver import INIT_ACADOS, INIT_HOVER
     B, N = 192, 50
     x0, yref, yref_e = _problem(oracle, B)
-    opts = cref.default_opts()
+    opts = cref.default_opts(tol=tol)
     if init == "hover":
         xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
     else:
         xr = np.tile(np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0]), (B, N + 1, 1)); ur = np.zeros((B, N, 4))
-    s = BatchSolver(B)
+    s = BatchSolver(B, default_opts(active_horizon=active_horizon, tol=tol))
     s.set_x0(x0); s.set_yref(yref, yref_e)
     s.init_iterate(INIT_HOVER if init == "hover" else INIT_ACADOS)
     x = x0.copy()
     n_constrained = 0
+    short_heads = 0
+    strict = 1e-8 if (active_horizon == 0 or tol <= 1e-11) else 1e-5
     for t in range(20):
         s.set_x0(x)
         s.solve(1)
@@ -75,12 +85,17 @@ def test_closed_loop_rti_matches_oracle(oracle, cref, init):
         st_r, it_r, rs_r, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
         xg, ug = s.get_iterate()
         assert (st == 0).all() and (st_r == 0).all(), (t, np.bincount(st), np.bincount(st_r))
-        # same algorithm, same tolerances: iteration counts agree except for borderline exits
-        assert (np.abs(it - it_r) <= 1).all(), (t, it[it != it_r], it_r[it != it_r])
-        same = it == it_r
-        assert np.abs(ug[same] - ur[same]).max() < 1e-8, t     # kRPM
-        assert np.abs(xg[same] - xr[same]).max() < 1e-8, t
-        assert np.abs(ug - ur).max() < 1e-5 and np.abs(xg - xr).max() < 1e-5, t  # borderline exits: tol-level
+        assert ((it > 0) == (it_r > 0)).all()      # same instances needed the interior-point method
+        if active_horizon == 0:
+            # same algorithm, same tolerances: iteration counts agree except for borderline exits
+            assert (np.abs(it - it_r) <= 1).all(), (t, it[it != it_r], it_r[it != it_r])
+            same = it == it_r
+            assert np.abs(ug[same] - ur[same]).max() < 1e-8, t     # kRPM
+            assert np.abs(xg[same] - xr[same]).max() < 1e-8, t
+            assert np.abs(ug - ur).max() < 1e-5 and np.abs(xg - xr).max() < 1e-5, t  # borderline exits: tol-level
+        else:
+            assert np.abs(ug - ur).max() < strict and np.abs(xg - xr).max() < strict, (t, np.abs(ug - ur).max())
+            short_heads += int((s.heads()[it > 0] < N).sum())
         n_constrained += int((it > 0).sum())
         u0 = s.get_u(0)
         assert np.abs(u0 - ug[:, 0]).max() == 0.0
@@ -88,18 +103,23 @@ def test_closed_loop_rti_matches_oracle(oracle, cref, init):
         x = sim(x, u0, T=0.015, steps=1)
         ur[:] = ug; xr[:] = xg  # keep both closed loops on the same trajectory
     assert n_constrained > 50  # the interior-point path was actually exercised
+    if active_horizon:
+        assert short_heads > 50  # ... and mostly on a shortened horizon
     if init == "hover":
         assert np.abs(x[:, :3] - np.array([0, 0, 0.4])).max() < 0.25  # and the loop regulates
 
 
-def test_qp_solution_satisfies_kkt_and_matches_dense_oracle(oracle):
-    """Independent check: the HIP step equals the dense-QP oracle's step and satisfies the KKT
-    conditions of the QP built by the numpy oracle (sympy Jacobians)."""
-    from crazyflie_nmpc_amd import BatchSolver
+@pytest.mark.parametrize("tol,bound", [(1e-12, 5e-6), (1e-8, 5e-4)])
+def test_qp_solution_matches_dense_oracle(oracle, tol, bound):
+    """Independent check: the HIP step equals the step of the dense-QP oracle on the QP built by
+    the numpy oracle (sympy Jacobians).  An interior-point solution sits on the central path:
+    for a (nearly) degenerate bound slack ~ multiplier ~ sqrt(mu), so the primal error is bounded
+    by ~sqrt(tol) -- 1e-6 at tol 1e-12 and 1e-4 at the default 1e-8 (same property as HPIPM)."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
     from crazyflie_nmpc_amd.solver import INIT_HOVER
     B, N = 64, 50
     x0, yref, yref_e = _problem(oracle, B, seed=99, scale=1.5)
-    s = BatchSolver(B)
+    s = BatchSolver(B, default_opts(tol=tol))
     s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
     s.solve(1)
     xg, ug = s.get_iterate()
@@ -112,8 +132,8 @@ def test_qp_solution_satisfies_kkt_and_matches_dense_oracle(oracle):
         ref = oracle.solve_qp_dense(qp)
         du = ug[i] - ubar
         dx = xg[i] - xbar
-        assert np.abs(du - ref["du"]).max() < 5e-6   # IPM tol 1e-8 on complementarity -> ~1e-6 on kRPM
-        assert np.abs(dx - ref["dx"]).max() < 5e-6
+        assert np.abs(du - ref["du"]).max() < bound
+        assert np.abs(dx - ref["dx"]).max() < bound
         checked += it[i] > 0
     assert checked >= 1
 

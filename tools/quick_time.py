@@ -20,6 +20,7 @@ for B in (4096, 65536):
         s.solve(1)
         torch.cuda.synchronize(); dt = time.time() - t0
         st, it, rs = s.stats()
-        print(f"  step {t}: {dt*1e3:.2f} ms  {B/dt/1e6:.3f} Msteps/s  iters mean {it.mean():.2f} max {it.max()} frac>0 {(it>0).mean():.2f} status {np.bincount(st)}")
+        hd = s.heads()
+        print(f"  step {t}: {dt*1e3:.2f} ms  {B/dt/1e6:.3f} Msteps/s  iters mean {it.mean():.2f} max {it.max()} frac>0 {(it>0).mean():.2f} status {np.bincount(st)} heads {np.bincount(hd, minlength=51)[[4,8,12,16,24,32,50]]}")
     t0 = time.time(); s.linearise_only(); torch.cuda.synchronize(); print("  linearise only: %.2f ms" % ((time.time() - t0) * 1e3))
     s.close()
