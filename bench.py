@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""bench.py -- NMPC RTI steps/s of the MI355X-native Crazyflie SQP-RTI engine.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
+under torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json metric: "NMPC RTI steps/sec (batch=65536, N=50, nx=13, nu=4)";
+SURVEY.md section 8d configs C2/C3): per GPU a synthetic fleet of 65536 Crazyflie hover-regulation
+problems, horizon N = 50, run CLOSED LOOP through the RK4 plant (device-resident):
+    step = { x0 <- plant state ; acados_solve() equivalent: linearise + Riccati-IPM QP + update ;
+             u0 -> plant RK4 step ; 1/20 of the fleet is kicked to a fresh random perturbed state }
+The staggered kicks make every step statistically identical to the time average of SURVEY's
+"20 RTI steps closed loop from a perturbed hover" (so the timed region never degenerates into
+the converged, bound-free regime).  Instances are independent: the batch shards across GPUs
+with no data-path collective ("scaling": "weak" -- 65536 instances per GPU); RCCL is used only
+to aggregate the report (max time, statistics).
+
+Also reported on the same line:
+  roofline     -- dominant kernel (k_qp): algorithmic bytes per launch / HIP-event duration vs
+                  8 TB/s;
+  cpu_baseline -- the plain-C CPU restatement of the same algorithm (oracle/cfnmpc_ref.c,
+                  "port": acados itself cannot be built here) timed on this host's cores on a
+                  bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12         # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+FP64_VEC_PEAK = 78.6e12   # FLOP/s, FP64 vector (= FP64 matrix) peak of MI355X
+N_HORIZON = 50
+KICK_PERIOD = 20
+
+
+def alg_bytes_step(N):
+    """algorithmic bytes per RTI step per instance, 8*(553 N + 80)."""
+    return 8 * (553 * N + 80)
+
+
+def alg_bytes_qp(N):
+    """Share of the QP kernel: stage blocks read once (251 N + 13 words) +
+    x0, yref, iterate read, iterate write, status (51 N + 54 words)."""
+    return 8 * (302 * N + 67)
+
+
+def cpu_baseline(seed, n_inst=2048, n_steps=4):
+    """Times the CPU restatement on a bounded sample of the same workload (closed loop)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cfnmpc_oracle as o
+    import cref
+    cref.build()
+    rng = np.random.default_rng(seed)
+    x = o.sample_hover_x0(rng, n_inst)
+    yr, ye = o.regulation_yref(N_HORIZON, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], n_inst, 0).copy()
+    yref_e = np.repeat(ye[None], n_inst, 0).copy()
+    opts = cref.default_opts()
+    xit = np.repeat(x[:, None, :], N_HORIZON + 1, 1).copy()
+    uit = np.full((n_inst, N_HORIZON, 4), o.HOV_W)
+    cores = os.cpu_count() or 1
+    t_solve = 0.0
+    used = 1
+    iters = []
+    for _ in range(n_steps):
+        t0 = time.perf_counter()
+        st, it, rs, used = cref.rti_step(opts, xit, uit, x.copy(), yref, yref_e, nthreads=0)
+        t_solve += time.perf_counter() - t0
+        iters.append(float(it.mean()))
+        x = cref.sim(x, uit[:, 0, :].copy(), 0.015, 1)
+    # single-thread latency on a small slice
+    m = min(64, n_inst)
+    xs = np.repeat(x[:m, None, :], N_HORIZON + 1, 1).copy(); us = np.full((m, N_HORIZON, 4), o.HOV_W)
+    t0 = time.perf_counter()
+    cref.rti_step(opts, xs, us, x[:m].copy(), yref[:m].copy(), yref_e[:m].copy(), nthreads=1)
+    t1 = time.perf_counter() - t0
+    return {
+        "value": n_inst * n_steps / t_solve, "unit": "RTI steps/s", "cores": int(used),
+        "host_cores": int(cores), "kind": "port",
+        "single_thread_steps_per_s": m / t1,
+        "sample": f"{n_inst} instances x {n_steps} closed-loop RTI steps of the same hover workload, "
+                  f"oracle/cfnmpc_ref.c (CPU restatement, not acados), OpenMP over {used} threads; "
+                  f"mean QP iterations {np.mean(iters):.2f}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--active-horizon", type=int, default=1)
+    args = ap.parse_args()
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.synthetic import regulation_row, sample_hover_x0 as sample_x0
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+
+    B, N = args.batch, N_HORIZON
+    seed = 20200103 + rank
+    rng = np.random.default_rng(seed)
+    # synthetic, device-resident inputs: initial states, references, kick pool
+    x = torch.from_numpy(sample_x0(rng, B)).to(dev)
+    row = regulation_row((0.0, 0.0, 0.4))
+    yref = torch.from_numpy(np.tile(row, (B, N, 1))).to(dev)
+    yref_e = torch.from_numpy(np.tile(row[:13], (B, 1))).to(dev)
+    cohort = (B + KICK_PERIOD - 1) // KICK_PERIOD
+    kicks = torch.from_numpy(sample_x0(rng, cohort * KICK_PERIOD).reshape(KICK_PERIOD, cohort, 13)).to(dev)
+    u0 = torch.empty((B, 4), dtype=torch.float64, device=dev)
+    xn = torch.empty_like(x)
+
+    solver = BatchSolver(B, default_opts(active_horizon=args.active_horizon))
+    solver.set_x0(x)
+    solver.set_yref(yref, yref_e)
+    solver.init_iterate(INIT_HOVER)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    it_sum = [0.0, 0.0, 0]
+    state = {"x": x, "xn": xn, "t": 0}
+
+    def step():
+        t = state["t"]
+        xc = state["x"]
+        c0 = (t % KICK_PERIOD) * cohort
+        c1 = min(c0 + cohort, B)
+        if c1 > c0:
+            xc[c0:c1].copy_(kicks[t % KICK_PERIOD, : c1 - c0])     # disturbance of one cohort
+        solver.set_x0(xc)                                          # lbx = ubx = x0 (acados_mpc.cpp:581)
+        solver.solve(1, stream)                                    # acados_solve()  (acados_mpc.cpp:611)
+        solver.get_u(0, out=u0)                                    # ocp_nlp_out_get(.., 0, "u")  (:619)
+        sim(xc, u0, T=0.015, steps=1, out=state["xn"])             # plant: one RK4 step of the ODE
+        state["x"], state["xn"] = state["xn"], xc
+        state["t"] = t + 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # statistics of the last step + per-kernel durations from a short profiled continuation
+    st, it, rs = solver.stats()
+    heads = solver.heads()
+    solver.set_profiling(True)
+    prof_steps = min(args.steps, 20)
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize(dev)
+    ms_lin, ms_qp, nprof = solver.get_profile()
+    solver.set_profiling(False)
+
+    stats = torch.tensor([float((st == 0).sum()), float((st != 0).sum()), float(it.sum()), float((it > 0).sum()),
+                          float(heads.sum()), ms_lin, ms_qp], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)   # RCCL: aggregate reporting only
+    stats = stats.cpu().numpy()
+    total_inst = B * world
+    ms_lin_avg, ms_qp_avg = stats[5] / world, stats[6] / world
+
+    if rank == 0:
+        value = total_inst * args.steps / elapsed
+        ach = alg_bytes_qp(N) * B / (ms_qp_avg * 1e-3)
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                if int(tj.get("batch", -1)) == B:
+                    traffic = tj.get("hbm_bytes_per_launch_k_qp")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "NMPC RTI steps/sec (batch=65536, N=50, nx=13, nu=4)",
+            "value": value, "unit": "RTI steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3 hover regulation, closed loop through the RK4 plant, staggered kicks "
+                                   f"(1/{KICK_PERIOD} of the fleet per step)", "batch_per_gpu": B, "horizon_N": N,
+                       "nx": 13, "nu": 4, "sharding": f"independent instances, {world} shard(s), no data-path collective",
+                       "qp": "Riccati Mehrotra IPM, tol 1e-8, active-horizon sweeps" if args.active_horizon else
+                             "Riccati Mehrotra IPM, tol 1e-8, full-horizon sweeps"},
+            "roofline": {"bound": "hbm", "kernel": "k_qp", "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
+                         "alg_bytes_per_launch": alg_bytes_qp(N) * B, "kernel_ms": ms_qp_avg,
+                         "linearise_ms": ms_lin_avg,
+                         "step_frac_hbm": alg_bytes_step(N) * value / (world * HBM_PEAK)},
+            "qp_stats": {"status_ok_frac": stats[0] / total_inst, "mean_ipm_iters": stats[2] / total_inst,
+                         "frac_needing_ipm": stats[3] / total_inst, "mean_head_stages": stats[4] / total_inst},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(seed)
+            except Exception as e:  # the baseline is a report, never a dependency of the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "RTI steps/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ SYMBOLS = [
     "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_init_iterate",
     "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_get_u", "cfnmpc_get_x",
     "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise",
-    "cfnmpc_debug_get_head", "cfnmpc_version",
+    "cfnmpc_debug_get_head", "cfnmpc_set_profiling", "cfnmpc_get_profile", "cfnmpc_version",
 ]
 
 
@@ -61,6 +61,8 @@ def lib():
     L.cfnmpc_sim.argtypes = [i32, vp, vp, dbl, i32, vp, i32, vp]
     L.cfnmpc_debug_get_linearisation.argtypes = [vp, i32, vp, vp, vp]
     L.cfnmpc_debug_get_head.argtypes = [vp, vp]
+    L.cfnmpc_set_profiling.argtypes = [vp, i32]
+    L.cfnmpc_get_profile.argtypes = [vp, vp, vp, vp]
     L.cfnmpc_debug_linearise.argtypes = [vp, vp]
     L.cfnmpc_version.restype = C.c_char_p
     for name in SYMBOLS:

@@ -20,6 +20,10 @@ struct cfnmpc_solver {
     double* stage_buf;  // device staging buffer for AoS transfers (largest AoS array)
     size_t stage_doubles;
     unsigned long long bytes;
+    // optional per-kernel timing with HIP events on the launch stream (cfnmpc_set_profiling)
+    int profiling;
+    std::vector<hipEvent_t> ev;  // triples (before linearise, between, after qp), one per RTI step
+    size_t ev_used;
 };
 
 namespace {
@@ -118,6 +122,8 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     cfnmpc_solver* s = new (std::nothrow) cfnmpc_solver();
     if (!s) return CFNMPC_ENOMEM;
     s->bytes = 0;
+    s->profiling = 0;
+    s->ev_used = 0;
     if (hipGetDevice(&s->device) != hipSuccess) { delete s; return CFNMPC_EHIP; }
     cfn::Params& P = s->P;
     std::memset(&P, 0, sizeof P);
@@ -157,6 +163,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
 int cfnmpc_free(cfnmpc_solver* s) {
     if (!s) return CFNMPC_EINVAL;
     for (void* p : s->allocs) (void)hipFree(p);
+    for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     delete s;
     return CFNMPC_OK;
 }
@@ -200,9 +207,23 @@ int cfnmpc_get_iterate(cfnmpc_solver* s, double* x, double* u, int on_device, vo
 
 int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
     if (!s || n_rti < 1) return CFNMPC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
     for (int it = 0; it < n_rti; it++) {
-        cfn::launch_linearise(s->P, (hipStream_t)stream);
-        cfn::launch_qp(s->P, (hipStream_t)stream);
+        hipEvent_t* e = nullptr;
+        if (s->profiling) {
+            while (s->ev.size() < s->ev_used + 3) {
+                hipEvent_t ne;
+                HIP_TRY(hipEventCreate(&ne));
+                s->ev.push_back(ne);
+            }
+            e = &s->ev[s->ev_used];
+            s->ev_used += 3;
+            HIP_TRY(hipEventRecord(e[0], st));
+        }
+        cfn::launch_linearise(s->P, st);
+        if (e) HIP_TRY(hipEventRecord(e[1], st));
+        cfn::launch_qp(s->P, st);
+        if (e) HIP_TRY(hipEventRecord(e[2], st));
     }
     HIP_TRY(hipGetLastError());
     return CFNMPC_OK;
@@ -258,6 +279,32 @@ int cfnmpc_sim(int batch, const double* x, const double* u, double T, int steps,
     }
     (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dn);
     return rc;
+}
+
+int cfnmpc_set_profiling(cfnmpc_solver* s, int enable) {
+    if (!s) return CFNMPC_EINVAL;
+    s->profiling = enable ? 1 : 0;
+    s->ev_used = 0;
+    return CFNMPC_OK;
+}
+
+int cfnmpc_get_profile(cfnmpc_solver* s, double* ms_linearise, double* ms_qp, int* n_steps) {
+    if (!s || !ms_linearise || !ms_qp || !n_steps) return CFNMPC_EINVAL;
+    double a = 0.0, b = 0.0;
+    const size_t n = s->ev_used / 3;
+    for (size_t i = 0; i < n; i++) {
+        float t0 = 0.f, t1 = 0.f;
+        HIP_TRY(hipEventSynchronize(s->ev[3 * i + 2]));
+        HIP_TRY(hipEventElapsedTime(&t0, s->ev[3 * i], s->ev[3 * i + 1]));
+        HIP_TRY(hipEventElapsedTime(&t1, s->ev[3 * i + 1], s->ev[3 * i + 2]));
+        a += t0;
+        b += t1;
+    }
+    *ms_linearise = n ? a / n : 0.0;
+    *ms_qp = n ? b / n : 0.0;
+    *n_steps = (int)n;
+    s->ev_used = 0;
+    return CFNMPC_OK;
 }
 
 int cfnmpc_debug_linearise(cfnmpc_solver* s, void* stream) {

@@ -113,7 +113,17 @@ class BatchSolver:
 
     # ---- solve
     def solve(self, n_rti=1, stream=None):
+        """acados_solve() for the batch; `stream` is a raw hipStream_t (int) or None = default."""
         _check(self._L.cfnmpc_solve(self._h, int(n_rti), C.c_void_p(stream or 0)), "cfnmpc_solve")
+
+    def set_profiling(self, enable=True):
+        _check(self._L.cfnmpc_set_profiling(self._h, int(bool(enable))), "cfnmpc_set_profiling")
+
+    def get_profile(self):
+        """-> (ms_linearise, ms_qp, n_steps): average kernel durations since the last call."""
+        a = C.c_double(0); b = C.c_double(0); n = C.c_int(0)
+        _check(self._L.cfnmpc_get_profile(self._h, C.byref(a), C.byref(b), C.byref(n)), "cfnmpc_get_profile")
+        return a.value, b.value, n.value
 
     def linearise_only(self, stream=None):
         _check(self._L.cfnmpc_debug_linearise(self._h, C.c_void_p(stream or 0)), "cfnmpc_debug_linearise")

@@ -95,6 +95,13 @@ int cfnmpc_get_x(cfnmpc_solver *s, int stage, double *x /*[B][13]*/, int on_devi
  * (max-norm residual of the last QP).  Any pointer may be NULL. */
 int cfnmpc_get_stats(cfnmpc_solver *s, int *status /*[B]*/, int *qp_iter /*[B]*/, double *res /*[B]*/, int on_device, void *stream);
 
+/* Per-kernel timing (the role of nlp_out->total_time, acados_mpc.cpp:616): when enabled,
+ * cfnmpc_solve brackets its two kernels (linearise, QP) with HIP events on the launch stream;
+ * cfnmpc_get_profile waits for them and returns the average kernel durations [ms] over the RTI
+ * steps since the last call, then resets. */
+int cfnmpc_set_profiling(cfnmpc_solver *s, int enable);
+int cfnmpc_get_profile(cfnmpc_solver *s, double *ms_linearise, double *ms_qp, int *n_steps);
+
 /* crazyflie_acados_sim_solve() equivalent, batched (acados_estimator.cpp:573-593):
  * xn = RK4(x, u) over T seconds in `steps` sub-steps.  Stateless. */
 int cfnmpc_sim(int batch, const double *x, const double *u, double T, int steps, double *xn, int on_device, void *stream);
