@@ -124,7 +124,8 @@ def main():
     from crazyflie_nmpc_amd.solver import INIT_HOVER
 
     B, N = args.batch, N_HORIZON
-    seed = 20200103 + rank
+    from crazyflie_nmpc_amd import parallel
+    seed = parallel.shard_seed(rank)
     rng = np.random.default_rng(seed)
     # synthetic, device-resident inputs: initial states, references, kick pool
     x = torch.from_numpy(sample_x0(rng, B)).to(dev)

@@ -1,0 +1,191 @@
+// cf_nmpc_node.hpp -- ROS-free host-side mirror of the reference NMPC node
+// (crazyflie_controller/src/acados_mpc.cpp, class NMPC :115-719) on top of the acados-named
+// C-ABI of include/acados_solver_crazyflie.h.  Same member / method names and per-step protocol
+// as the reference; ROS messages are replaced by plain structs with the message layouts
+// (msg/CrazyflieStateStamped.msg, msg/PropellerSpeedsStamped.msg, geometry_msgs/Twist).
+//
+// Deliberate differences (all flagged where they occur):
+//   B4  `policy` is initialised (Regulation, z = 0.40 as the dynamic_reconfigure default,
+//       config/crazyflie_params.cfg:12,17) instead of relying on the server's first callback;
+//   B6  the solver status is kept in `acados_status` AND returned by iteration();
+//   Eigen's Quaterniond is replaced by four doubles (only normalize() was used, :650).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/acados_solver_crazyflie.h"
+
+namespace cf {
+
+// acados dims (acados_mpc.cpp:96-104)
+constexpr int N = 50, NX = 13, NU = 4, NY = 17, NYN = 13;
+constexpr double pi = 3.14159265358979323846;
+constexpr double g0 = 9.80665;  // the node's constant (acados_mpc.cpp:107); the model uses 9.8066 (App. B2)
+
+struct CrazyflieState {  // msg/CrazyflieStateStamped.msg
+    double pos[3], vel[3], quat[4] /* w x y z */, rates[3];
+};
+struct PropellerSpeeds {  // msg/PropellerSpeedsStamped.msg: int32 w1..w4 (truncation, App. B1)
+    int32_t w1, w2, w3, w4;
+};
+struct Twist {  // geometry_msgs/Twist fields the node fills (acados_mpc.cpp:655-668)
+    double linear_x /* pitch deg */, linear_y /* -roll deg */, linear_z /* thrust PWM */, angular_z /* yaw rate deg/s */;
+};
+
+class NMPC {
+public:
+    enum systemStates { xq = 0, yq, zq, qw, qx, qy, qz, vbx, vby, vbz, wx, wy, wz };
+    enum controlInputs { w1 = 0, w2, w3, w4 };
+    enum reference_mode { Regulation = 0, Tracking = 1, Position_Hold = 2 };
+    struct euler { double phi, theta, psi; };
+    struct solver_output {
+        double status, KKT_res, cpu_time;
+        double u0[NU], u1[NU], x4[NX];
+    };
+    struct solver_input {
+        double x0[NX], yref[NY * N], yref_e[NYN];
+    };
+
+    float uss, Ct, mq;  // float as in the reference (acados_mpc.cpp:189)
+    double x0_sign[NX], yref_sign[(NY * N) + NY];
+    double xq_des, yq_des, zq_des;
+    solver_input acados_in;
+    solver_output acados_out;
+    int acados_status;
+    reference_mode policy;
+    std::vector<std::vector<double>> precomputed_traj;
+    int N_STEPS, iter;
+    PropellerSpeeds last_motvel;  // what would go to /crazyflie/acados_motvel
+    Twist last_cmd_vel;           // what would go to /crazyflie/cmd_vel
+
+    // acados_mpc.cpp:219-291
+    explicit NMPC(const std::string& ref_traj) {
+        const int status = acados_create();
+        if (status) throw status;  // the reference exit(1)s (:227-230)
+        for (int i = 0; i < NU; i++) acados_out.u0[i] = 0.0;
+        mq = 33e-3f;
+        Ct = 3.25e-4f;
+        uss = std::sqrt((mq * g0) / (4 * Ct));
+        N_STEPS = ref_traj.empty() ? 0 : readDataFromFile(ref_traj.c_str(), precomputed_traj);
+        xq_des = 0; yq_des = 0; zq_des = 0.40;  // App. B4
+        iter = 0;
+        policy = Regulation;
+        acados_status = 0;
+    }
+    ~NMPC() { nmpcReset(); }
+
+    // acados_mpc.cpp:305-329 (dynamic_reconfigure callback), reduced to its effect
+    void reconfigure(bool enable_traj_tracking, bool enable_regulation, double x, double y, double z) {
+        if (enable_traj_tracking) policy = Tracking;
+        if (enable_regulation) { xq_des = x; yq_des = y; zq_des = z; policy = Regulation; }
+    }
+
+    // acados_mpc.cpp:354-382
+    static int readDataFromFile(const char* fileName, std::vector<std::vector<double>>& data) {
+        std::ifstream file(fileName);
+        std::string line;
+        int num_of_steps = 0;
+        if (!file.is_open()) return 0;
+        while (getline(file, line)) {
+            ++num_of_steps;
+            std::istringstream linestream(line);
+            std::vector<double> linedata;
+            double number;
+            while (linestream >> number) linedata.push_back(number);
+            data.push_back(linedata);
+        }
+        return num_of_steps;
+    }
+
+    // acados_mpc.cpp:384-404
+    static euler quatern2euler(double w, double x, double y, double z) {
+        const double R11 = 2 * (w * w + x * x) - 1;
+        const double R21 = 2 * (x * y - w * z);
+        const double R31 = 2 * (x * z + w * y);
+        const double R32 = 2 * (y * z - w * x);
+        const double R33 = 2 * (w * w + z * z) - 1;
+        euler angle;
+        angle.phi = std::atan2(R32, R33);
+        angle.theta = -std::asin(R31);
+        angle.psi = std::atan2(R21, R11);
+        return angle;
+    }
+    static double rad2Deg(double rad) { return rad * 180.0 / pi; }
+    // acados_mpc.cpp:421-425 (truncation to int is the wire unit, App. B8)
+    static int krpm2pwm(double Krpm) { return (int)(((Krpm * 1000) - 4070.3) / 0.2685); }
+
+    void nmpcReset() { acados_free(); }  // acados_mpc.cpp:416-419
+
+    // acados_mpc.cpp:427-718; returns the solver status (App. B6)
+    int iteration(const CrazyflieState& msg) {
+        switch (policy) {
+            case Regulation:
+                for (int k = 0; k < N + 1; k++) fill_hold_row(k, xq_des, yq_des, zq_des);
+                break;
+            case Tracking:
+                if (iter < N_STEPS - N) {
+                    for (int k = 0; k < N + 1; k++)
+                        for (int j = 0; j < NY; j++) yref_sign[k * NY + j] = precomputed_traj[iter + k][j];
+                    ++iter;
+                } else {
+                    policy = Position_Hold;  // the reference keeps the previous window for this step (:486)
+                }
+                break;
+            case Position_Hold:
+                for (int k = 0; k < N + 1; k++)
+                    fill_hold_row(k, precomputed_traj[N_STEPS - 1][xq], precomputed_traj[N_STEPS - 1][yq],
+                                  precomputed_traj[N_STEPS - 1][zq]);
+                break;
+        }
+        // --- read estimate (:560-578)
+        acados_in.x0[xq] = msg.pos[0]; acados_in.x0[yq] = msg.pos[1]; acados_in.x0[zq] = msg.pos[2];
+        acados_in.x0[qw] = msg.quat[0]; acados_in.x0[qx] = msg.quat[1]; acados_in.x0[qy] = msg.quat[2]; acados_in.x0[qz] = msg.quat[3];
+        acados_in.x0[vbx] = msg.vel[0]; acados_in.x0[vby] = msg.vel[1]; acados_in.x0[vbz] = msg.vel[2];
+        acados_in.x0[wx] = msg.rates[0]; acados_in.x0[wy] = msg.rates[1]; acados_in.x0[wz] = msg.rates[2];
+        // --- acados NMPC (:581-594)
+        ocp_nlp_constraints_model_set(nlp_config, nlp_dims, nlp_in, 0, "lbx", acados_in.x0);
+        ocp_nlp_constraints_model_set(nlp_config, nlp_dims, nlp_in, 0, "ubx", acados_in.x0);
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < NY; ++j) acados_in.yref[i * NY + j] = yref_sign[i * NY + j];
+        for (int i = 0; i < NYN; i++) acados_in.yref_e[i] = yref_sign[N * NY + i];
+        for (int ii = 0; ii < N; ii++) ocp_nlp_cost_model_set(nlp_config, nlp_dims, nlp_in, ii, "yref", acados_in.yref + ii * NY);
+        ocp_nlp_cost_model_set(nlp_config, nlp_dims, nlp_in, N, "yref", acados_in.yref_e);
+        // --- call solver (:611-616)
+        acados_status = acados_solve();
+        acados_out.status = acados_status;
+        acados_out.KKT_res = (double)nlp_out->inf_norm_res;
+        acados_out.cpu_time = (double)nlp_out->total_time;
+        // --- get solution (:619-625): u0, u1, and x4 = stage 4 compensates the 60 ms delay
+        ocp_nlp_out_get(nlp_config, nlp_dims, nlp_out, 0, "u", (void*)acados_out.u0);
+        ocp_nlp_out_get(nlp_config, nlp_dims, nlp_out, 1, "u", (void*)acados_out.u1);
+        ocp_nlp_out_get(nlp_config, nlp_dims, nlp_out, 4, "x", (void*)acados_out.x4);
+        // --- motor speeds message (:628-642), double -> int32 truncation as on the wire
+        last_motvel.w1 = (int32_t)acados_out.u0[w1]; last_motvel.w2 = (int32_t)acados_out.u0[w2];
+        last_motvel.w3 = (int32_t)acados_out.u0[w3]; last_motvel.w4 = (int32_t)acados_out.u0[w4];
+        // --- attitude / thrust command (:645-670)
+        double qn[4] = {acados_out.x4[qw], acados_out.x4[qx], acados_out.x4[qy], acados_out.x4[qz]};
+        const double nrm = std::sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        for (double& c : qn) c /= nrm;
+        const euler eu = quatern2euler(qn[0], qn[1], qn[2], qn[3]);
+        last_cmd_vel.linear_x = 1.0 * rad2Deg(eu.theta);
+        last_cmd_vel.linear_y = -1.0 * rad2Deg(eu.phi);
+        last_cmd_vel.linear_z = krpm2pwm((acados_out.u1[w1] + acados_out.u1[w2] + acados_out.u1[w3] + acados_out.u1[w4]) / 4);
+        last_cmd_vel.angular_z = rad2Deg(acados_out.x4[wz]);
+        return acados_status;
+    }
+
+private:
+    // one row of the Regulation / Position_Hold windows (acados_mpc.cpp:438-454, 497-513)
+    void fill_hold_row(int k, double x, double y, double z) {
+        double* r = yref_sign + k * NY;
+        r[0] = x; r[1] = y; r[2] = z; r[3] = 1.00;
+        for (int j = 4; j < 13; j++) r[j] = 0.00;
+        for (int j = 13; j < 17; j++) r[j] = uss;
+    }
+};
+
+}  // namespace cf

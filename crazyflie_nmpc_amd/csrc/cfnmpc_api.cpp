@@ -184,6 +184,15 @@ int cfnmpc_set_yref(cfnmpc_solver* s, const double* yref, const double* yref_e, 
     return put_field(s, yref_e, on_device, 1, 13, 1, s->P.yref_e, (hipStream_t)stream);
 }
 
+int cfnmpc_set_weights(cfnmpc_solver* s, const double* W, const double* WN) {
+    if (!s || (!W && !WN)) return CFNMPC_EINVAL;
+    if (W) for (int i = 0; i < 17; i++) { if (!(W[i] > 0.0)) return CFNMPC_EINVAL; }
+    if (WN) for (int i = 0; i < 13; i++) { if (!(WN[i] > 0.0)) return CFNMPC_EINVAL; }
+    if (W) for (int i = 0; i < 17; i++) s->P.W[i] = W[i];
+    if (WN) for (int i = 0; i < 13; i++) s->P.WN[i] = WN[i];
+    return CFNMPC_OK;  // kernel arguments: take effect at the next cfnmpc_solve
+}
+
 int cfnmpc_init_iterate(cfnmpc_solver* s, int mode, void* stream) {
     if (!s || (mode != CFNMPC_INIT_ACADOS && mode != CFNMPC_INIT_HOVER)) return CFNMPC_EINVAL;
     cfn::launch_init_iterate(s->P, mode, (hipStream_t)stream);

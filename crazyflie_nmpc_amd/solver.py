@@ -102,6 +102,12 @@ class BatchSolver:
             raise ValueError("yref and yref_e must live on the same side")
         _check(self._L.cfnmpc_set_yref(self._h, p, pe, dev, st), "cfnmpc_set_yref")
 
+    def set_weights(self, W=None, WN=None):
+        w = None if W is None else np.ascontiguousarray(W, dtype=np.float64)
+        wn = None if WN is None else np.ascontiguousarray(WN, dtype=np.float64)
+        _check(self._L.cfnmpc_set_weights(self._h, None if w is None else w.ctypes.data_as(C.c_void_p),
+                                          None if wn is None else wn.ctypes.data_as(C.c_void_p)), "cfnmpc_set_weights")
+
     def init_iterate(self, mode=INIT_ACADOS, stream=None):
         _check(self._L.cfnmpc_init_iterate(self._h, mode, C.c_void_p(stream or 0)), "cfnmpc_init_iterate")
 

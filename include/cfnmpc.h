@@ -75,6 +75,10 @@ unsigned long long cfnmpc_workspace_bytes(const cfnmpc_solver *s);
 int cfnmpc_set_x0(cfnmpc_solver *s, const double *x0, int on_device, void *stream);
 /* ocp_nlp_cost_model_set(.., k, "yref", ..) for k = 0..N (acados_mpc.cpp:590-594) */
 int cfnmpc_set_yref(cfnmpc_solver *s, const double *yref, const double *yref_e, int on_device, void *stream);
+/* ocp_nlp_cost_model_set(.., k, "W", ..) equivalent (acados_mpc.cpp:596-602, compiled out by
+ * SET_WEIGHTS 0 in the reference): diagonal stage / terminal weights for ALL instances and
+ * stages; either pointer may be NULL (unchanged).  Entries must be > 0. */
+int cfnmpc_set_weights(cfnmpc_solver *s, const double *W /*[17]*/, const double *WN /*[13]*/);
 /* ocp_nlp_constraints_model_set(.., 0, "lbu"/"ubu", ..) is NOT offered per stage: the box is
  * the global [u_min, u_max] of cfnmpc_opts (FIXED_U0 is 0 in the reference, acados_mpc.cpp:111). */
 

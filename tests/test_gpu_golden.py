@@ -1,0 +1,144 @@
+"""GPU suite against the committed golden fixtures (tests/golden/*.npz) and through the
+acados-named drop-in: HIP path == exact QP solutions of the dense oracle (generated in the
+build container by tests/golden/make_golden.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+HOV = 15.777730167256925
+
+
+def test_sim_and_linearisation_match_golden_model_vectors():
+    from crazyflie_nmpc_amd import BatchSolver, sim
+    m = np.load(os.path.join(G, "model.npz"))
+    n = m["x"].shape[0]
+    assert np.abs(sim(m["x"], m["u"], T=0.015, steps=1) - m["phi"]).max() < 1e-13
+    assert np.abs(sim(m["x"], m["u"], T=float(m["pred_T"]), steps=4) - m["pred"]).max() < 1e-13
+    N = 50
+    s = BatchSolver(n)
+    xit = np.repeat(m["x"][:, None, :], N + 1, 1).copy(); uit = np.repeat(m["u"][:, None, :], N, 1).copy()
+    row = np.zeros(17); row[3] = 1
+    s.set_x0(m["x"]); s.set_yref(np.tile(row, (n, N, 1)), np.tile(row[:13], (n, 1))); s.set_iterate(xit, uit)
+    s.linearise_only()
+    for form in (0, 1):
+        A, B, b = s.get_linearisation(form)
+        for k in (0, 17, 49):
+            assert np.abs(A[:, k] - m["A"]).max() < 1e-13       # sympy-Jacobian sensitivities
+            assert np.abs(B[:, k] - m["B"]).max() < 1e-13
+            assert np.abs(b[:, k] - (m["phi"] - m["x"])).max() < 1e-13
+
+
+@pytest.mark.parametrize("tol,bound", [(1e-12, 5e-6), (1e-8, 5e-4)])
+def test_qp_steps_match_golden_exact_solutions(tol, bound):
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    q = np.load(os.path.join(G, "qp.npz"))
+    n, N = q["x0"].shape[0], 50
+    for ah in (0, 1):
+        s = BatchSolver(n, default_opts(tol=tol, active_horizon=ah))
+        s.set_x0(q["x0"]); s.set_yref(np.tile(q["yref"], (n, 1, 1)), np.tile(q["yref_e"], (n, 1))); s.init_iterate(INIT_HOVER)
+        s.solve(1)
+        st, it, _ = s.stats()
+        xg, ug = s.get_iterate()
+        assert (st == 0).all() and ((it > 0) == (q["n_active"] > 0)).all()
+        assert np.abs(ug - HOV - q["du"]).max() < bound
+        assert np.abs(xg - q["x0"][:, None, :] - q["dx"]).max() < bound
+
+
+def test_closed_loops_match_golden_through_batch_node():
+    """Regulation + Tracking (smooth_step, helix) through the Python mirror of NMPC::iteration."""
+    from crazyflie_nmpc_amd import default_opts, sim
+    from crazyflie_nmpc_amd.node import BatchNMPC, TRACKING
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    c = np.load(os.path.join(G, "closed_loop.npz"))
+    t = np.load(os.path.join(G, "traj.npz"))
+    for key, traj, steps in (("reg", None, 20), ("ss", t["smooth_step"], 60), ("hx", t["helix"], 40)):
+        nm = BatchNMPC(1, traj=traj, opts=default_opts(tol=1e-12), uss=HOV)
+        if traj is not None:
+            nm.policy[:] = TRACKING
+        x = c[key + "_x"][0:1].copy()
+        nm.solver.set_x0(x); nm.solver.init_iterate(INIT_HOVER)
+        for k in range(steps):
+            assert np.abs(x - c[key + "_x"][k]).max() < 1e-5, (key, k)
+            out = nm.iteration(x)
+            assert out["status"][0] == 0
+            assert np.abs(out["u0"][0] - c[key + "_u0"][k]).max() < 1e-5, (key, k)   # kRPM
+            assert np.abs(out["u1"][0] - c[key + "_u1"][k]).max() < 1e-5, (key, k)
+            assert np.abs(out["x4"][0] - c[key + "_x4"][k]).max() < 1e-5, (key, k)
+            x = sim(x, out["u0"], T=0.015, steps=1)
+
+
+def test_acados_dropin_replay_matches_batch_api(tmp_path):
+    """The ROS-free C++ mirror of the reference node (csrc/cf_nmpc_node.hpp), which defines the
+    acados globals itself and calls acados_create/solve/ocp_nlp_* exactly like acados_mpc.cpp,
+    produces the same controls as the batch API and the same wire values as node.postprocess."""
+    from crazyflie_nmpc_amd import default_opts, sim
+    from crazyflie_nmpc_amd.node import BatchNMPC, TRACKING, postprocess, uss_node
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    from crazyflie_nmpc_amd.trajectories import save_traj_text
+    exe = os.path.join(ROOT, "crazyflie_nmpc_amd", "cf_nmpc_replay")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "crazyflie_nmpc_amd", "csrc"), "-s"])
+    t = np.load(os.path.join(G, "traj.npz"))
+    c = np.load(os.path.join(G, "closed_loop.npz"))
+    for mode, key, steps in (("regulation", "reg", 20), ("tracking", "ss", 30)):
+        x0 = c[key + "_x"][0]
+        np.savetxt(tmp_path / "x0.txt", x0[None], fmt="%.17g")
+        trajfile = "-"
+        traj = None
+        if mode == "tracking":
+            # the text format has 4 decimals: replay and Python mirror must use the SAME rounded rows
+            trajfile = str(tmp_path / "traj.txt")
+            save_traj_text(trajfile, t["smooth_step"])
+            traj = np.loadtxt(trajfile)
+        out_csv = tmp_path / f"{mode}.csv"
+        subprocess.check_call([exe, mode, trajfile, str(steps), str(tmp_path / "x0.txt"), "1", str(out_csv)])
+        R = np.loadtxt(out_csv, delimiter=",")
+        assert R.shape == (steps, 3 + 4 + 4 + 13 + 4 + 4 + 2)
+        assert (R[:, 1] == 0).all()                                  # acados_solve() status
+        nm = BatchNMPC(1, traj=traj, opts=default_opts(), uss=uss_node())
+        if mode == "tracking":
+            nm.policy[:] = TRACKING
+        x = x0[None].copy()
+        nm.solver.set_x0(x); nm.solver.init_iterate(INIT_HOVER)
+        for k in range(steps):
+            out = nm.iteration(x)
+            u0, u1, x4 = R[k, 3:7], R[k, 7:11], R[k, 11:24]
+            assert np.abs(out["u0"][0] - u0).max() < 1e-9 and np.abs(out["u1"][0] - u1).max() < 1e-9
+            assert np.abs(out["x4"][0] - x4).max() < 1e-9
+            pp = postprocess(u0[None], u1[None], x4[None])
+            assert np.abs(pp["cmd_vel"][0] - R[k, 24:28]).max() < 1e-9
+            assert (pp["motvel"][0] == R[k, 28:32]).all()
+            assert int(R[k, 33]) == int(out["qp_iter"][0])
+            x = sim(x, out["u0"], T=0.015, steps=1)
+
+
+def test_figure8_tracking_config4_runs_and_tracks():
+    """Config C4: figure-8 reference synthesised per SURVEY App. C, per-instance phase offsets."""
+    from crazyflie_nmpc_amd import sim
+    from crazyflie_nmpc_amd.node import BatchNMPC, TRACKING
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    from crazyflie_nmpc_amd.synthetic import sample_hover_x0
+    from crazyflie_nmpc_amd.trajectories import Figure8, figure8_reference
+    t = np.load(os.path.join(G, "traj.npz"))
+    ref = figure8_reference(Figure8(t["figure8"]), z0=0.5)
+    B = 64
+    rng = np.random.default_rng(20200104)
+    nm = BatchNMPC(B, traj=ref)
+    nm.policy[:] = TRACKING
+    nm.iter[:] = rng.integers(0, 436, B)
+    x = ref[nm.iter, :13].copy()
+    x += 0.3 * (sample_hover_x0(rng, B, center=(0, 0, 0)) - np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0]))
+    x[:, 3:7] /= np.linalg.norm(x[:, 3:7], axis=1, keepdims=True)
+    nm.solver.set_x0(x); nm.solver.init_iterate(INIT_HOVER)
+    for k in range(40):
+        out = nm.iteration(x)
+        assert (out["status"] == 0).all()
+        x = sim(x, out["u0"], T=0.015, steps=1)
+    err = np.abs(x[:, :3] - ref[nm.iter, :3]).max()
+    assert err < 0.15, err                       # metres: the fleet follows the figure-8
