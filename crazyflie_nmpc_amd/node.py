@@ -14,9 +14,13 @@ G0_NODE = 9.80665  # the node's constant (acados_mpc.cpp:107); the model uses 9.
 
 
 def uss_node():
-    """Steady-state propeller speed as the node computes it: float arithmetic (acados_mpc.cpp:189,253)."""
+    """Steady-state propeller speed exactly as the node computes it (acados_mpc.cpp:189,247-253):
+    `float uss = sqrt((mq*g0)/(4*Ct))` with float mq, Ct and the double macro g0 -- i.e. mq*g0 and
+    the quotient are evaluated in double, 4*Ct in float, and the result is rounded to float."""
     mq, ct = np.float32(33e-3), np.float32(3.25e-4)
-    return float(np.float32(np.sqrt((mq * G0_NODE) / (4 * ct))))
+    num = float(mq) * G0_NODE
+    den = float(np.float32(4.0) * ct)
+    return float(np.float32(np.sqrt(num / den)))
 
 
 def quatern2euler(q):
