@@ -60,7 +60,7 @@ def lib():
     L.cfnmpc_get_x.argtypes = [vp, i32, vp, i32, vp]
     L.cfnmpc_get_stats.argtypes = [vp, vp, vp, vp, i32, vp]
     L.cfnmpc_sim.argtypes = [i32, vp, vp, dbl, i32, vp, i32, vp]
-    L.cfnmpc_debug_get_linearisation.argtypes = [vp, i32, vp, vp, vp]
+    L.cfnmpc_debug_get_linearisation.argtypes = [vp, vp, vp, vp]
     L.cfnmpc_debug_get_head.argtypes = [vp, vp]
     L.cfnmpc_set_profiling.argtypes = [vp, i32]
     L.cfnmpc_get_profile.argtypes = [vp, vp, vp, vp]

@@ -89,7 +89,7 @@ int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int pe
 
 extern "C" {
 
-const char* cfnmpc_version(void) { return "cfnmpc 0.2 (gfx950, 16-lane row groups, DPP broadcast Riccati)"; }
+const char* cfnmpc_version(void) { return "cfnmpc 0.3 (gfx950, 16-lane row groups, fused DPP broadcast Riccati, phase-split kernels)"; }
 
 void cfnmpc_default_opts(cfnmpc_opts* o) {
     // generate_c_code.py:41-42,63-84,109,133-134
@@ -136,19 +136,20 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.u_min = o.u_min; P.u_max = o.u_max; P.tol = o.tol; P.tau = o.tau; P.thr0 = o.thr0;
     P.lam0_min = o.lam0_min; P.max_iter = o.max_iter;
     P.active_horizon = o.active_horizon ? 1 : 0;
-    const size_t NW = P.NW, N = P.N;
+    // one spare workspace block (index P.NW) parks the idle rows of compacted interior-point waves
+    const size_t NW = P.NW + 1, N = P.N;
     int rc = CFNMPC_OK;
 #define ALLOC(field, cnt) if (rc == CFNMPC_OK) rc = dev_alloc(s, &P.field, (size_t)(cnt))
     ALLOC(xit, NW * (N + 1) * cfn::SZ_V13); ALLOC(uit, NW * 4 * N * 4); ALLOC(x0, NW * cfn::SZ_V13);
     ALLOC(yref, NW * N * cfn::SZ_Y); ALLOC(yref_e, NW * cfn::SZ_V13);
-    ALLOC(AR, NW * N * cfn::SZ_A); ALLOC(AC, NW * N * cfn::SZ_A);
-    ALLOC(BR, NW * N * cfn::SZ_B); ALLOC(BC, NW * N * cfn::SZ_B); ALLOC(b, NW * N * cfn::SZ_V13);
-    ALLOC(KP, NW * N * cfn::SZ_K); ALLOC(KR, NW * N * cfn::SZ_K); ALLOC(Sinv, NW * N * cfn::SZ_S);
+    ALLOC(AR, NW * N * cfn::SZ_A); ALLOC(BR, NW * N * cfn::SZ_B); ALLOC(b, NW * N * cfn::SZ_V13);
+    ALLOC(KR, NW * N * cfn::SZ_K); ALLOC(Sinv, NW * N * cfn::SZ_S);
     ALLOC(d, NW * 4 * N * 4); ALLOC(Pchk, NW * cfn::N_CHK * cfn::SZ_P);
     ALLOC(v, NW * 4 * N * 4); ALLOC(tl, NW * 4 * N * 4); ALLOC(tu, NW * 4 * N * 4); ALLOC(ll, NW * 4 * N * 4);
     ALLOC(lu, NW * 4 * N * 4); ALLOC(rg, NW * 4 * N * 4); ALLOC(dva, NW * 4 * N * 4); ALLOC(dvc, NW * 4 * N * 4);
     ALLOC(Rh, NW * 4 * N * 4); ALLOC(g, NW * 4 * N * 4); ALLOC(dx, NW * (N + 1) * cfn::SZ_V13);
-    ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4);
+    ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4); ALLOC(viol, NW * 4);
+    ALLOC(ilist, NW * 4); ALLOC(nipm, 4);
 #undef ALLOC
     s->stage_doubles = (size_t)batch * (N + 1) * 17;
     if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->stage_buf, s->stage_doubles);
@@ -323,16 +324,16 @@ int cfnmpc_debug_linearise(cfnmpc_solver* s, void* stream) {
     return CFNMPC_OK;
 }
 
-int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, int form, double* A, double* Bm, double* b) {
-    // form 0: from the row forms (AR, BR); form 1: from the column forms (AC, BC).
-    // Output dense, EXTERNAL state order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13].
-    if (!s || !A || !Bm || !b || (form != 0 && form != 1)) return CFNMPC_EINVAL;
+int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, double* A, double* Bm, double* b) {
+    // Decodes the row-distributed stage blocks (AR, BR, b) into dense arrays in the EXTERNAL
+    // state order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13].
+    if (!s || !A || !Bm || !b) return CFNMPC_EINVAL;
     const cfn::Params& P = s->P;
     const size_t NW = P.NW, N = P.N, B = P.B;
     std::vector<double> ha(NW * N * cfn::SZ_A), hb(NW * N * cfn::SZ_B), hv(NW * N * cfn::SZ_V13);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(ha.data(), form ? P.AC : P.AR, ha.size() * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(hb.data(), form ? P.BC : P.BR, hb.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ha.data(), P.AR, ha.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hb.data(), P.BR, hb.size() * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(hv.data(), P.b, hv.size() * 8, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < B; i++) {
         const size_t w = i / 4, q = i % 4;
@@ -342,20 +343,17 @@ int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, int form, double* A, double
             const double* vb = hv.data() + (w * N + k) * cfn::SZ_V13;
             double* Ad = A + (i * N + k) * 169;
             double* Bd = Bm + (i * N + k) * 52;
-            for (int r = 0; r < 13; r++) {      // internal row / column indices
-                for (int c = 0; c < 13; c++) {
+            for (int r = 0; r < 13; r++) {  // internal row / column indices
+                for (int cc = 0; cc < 13; cc++) {
                     double val;
-                    if (c < 3) val = (r == c) ? 1.0 : 0.0;
-                    else if (form == 0) {
-                        const int sl = c - 3;
+                    if (cc < 3) val = (r == cc) ? 1.0 : 0.0;
+                    else {
+                        const int sl = cc - 3;
                         val = r < cfn::ar_n(sl) ? ab[4 * cfn::ar_pre(sl) + q * cfn::ar_n(sl) + r] : 0.0;
-                    } else {
-                        val = c >= cfn::ac_first(r) ? ab[4 * cfn::ac_pre(r) + q * cfn::ac_m(r) + (c - cfn::ac_first(r))] : 0.0;
                     }
-                    Ad[cfn::ext_of(r) * 13 + cfn::ext_of(c)] = val;
+                    Ad[cfn::ext_of(r) * 13 + cfn::ext_of(cc)] = val;
                 }
-                for (int a = 0; a < 4; a++)
-                    Bd[cfn::ext_of(r) * 4 + a] = form == 0 ? bb[(a * 4 + q) * 13 + r] : bb[(r * 4 + q) * 4 + a];
+                for (int a = 0; a < 4; a++) Bd[cfn::ext_of(r) * 4 + a] = bb[(a * 4 + q) * 13 + r];
                 b[(i * N + k) * 13 + cfn::ext_of(r)] = vb[q * 13 + r];
             }
         }

@@ -4,13 +4,19 @@
 // per workgroup (cfnmpc_ws.hpp).  Instances never communicate; every wave runs its own
 // interior-point loop until its four instances are done (wave-uniform trip count via __any).
 //
-// Kernels
+// Kernels, one RTI step = five launches on one stream:
 //   k_linearise : RK4 + forward sensitivities per shooting interval (the role of acados
 //                 sim_erk + CasADi forw_vde, acados_mpc.cpp:84): lane c integrates sensitivity
-//                 COLUMN c; a 13x17 LDS tile re-distributes it into the row / column forms.
-//   k_qp        : box-constrained OCP-QP by Mehrotra predictor-corrector over stage-wise
-//                 Riccati sweeps in delta form (HPIPM's role, generate_c_code.py:140), then
-//                 expansion and the full RTI step (acados_solve(), acados_mpc.cpp:611).
+//                 COLUMN c; a 13x17 LDS tile re-distributes it into the row form.
+//   k_factor    : start solve, backward: augmented Riccati factorisation of the unconstrained
+//                 QP over all N stages, next stage software-prefetched (2 waves/SIMD).
+//   k_forward   : start solve, forward: unconstrained inputs, feasibility / active-horizon
+//                 decision per wave (streaming sweep, high occupancy).
+//   k_ipm       : only waves with an infeasible instance: Mehrotra predictor-corrector over
+//                 stage-wise Riccati sweeps in delta form (HPIPM's role,
+//                 generate_c_code.py:140), expansion, tail verification.
+//   k_commit    : full RTI step (iterate += step) and statistics (acados_solve() epilogue,
+//                 acados_mpc.cpp:611-616).
 //   k_sim       : RK4 predictor / plant step (acados_estimator.cpp:573-593).
 //   k_put / k_get / k_init_iterate : layout glue for the C-ABI.
 #include <hip/hip_runtime.h>
@@ -60,18 +66,32 @@ __device__ __forceinline__ double row_max(double x) {
 
 struct Lane {
     int L;      // lane in row: 0..12 state rows, 13 affine row, 14/15 idle
-    int q;      // instance in wave 0..3
-    int wave;   // wave (= workgroup) index
+    int row;    // DPP row of this lane inside the wavefront, 0..3 (LDS tile index)
+    int q;      // position of the instance inside its workspace block, 0..3
+    int wave;   // workspace block (= "home" wave) of the instance
     int inst;   // global instance
     bool valid;
 };
 __device__ __forceinline__ Lane lane_id(const Params& P) {
     Lane t;
     t.L = threadIdx.x & 15;
-    t.q = threadIdx.x >> 4;
+    t.row = threadIdx.x >> 4;
+    t.q = t.row;
     t.wave = blockIdx.x;
     t.inst = t.wave * 4 + t.q;
     t.valid = t.inst < P.B;
+    return t;
+}
+// Row r of this wavefront works on an arbitrary instance (compacted interior-point waves);
+// rows without work are parked on the spare workspace block NW (never read by anyone else).
+__device__ __forceinline__ Lane lane_indirect(const Params& P, int inst, bool valid) {
+    Lane t;
+    t.L = threadIdx.x & 15;
+    t.row = threadIdx.x >> 4;
+    t.inst = valid ? inst : P.NW * 4 + t.row;
+    t.wave = t.inst >> 2;
+    t.q = t.inst & 3;
+    t.valid = valid;
     return t;
 }
 // Workspace pointers live inside the by-value Params struct, where clang cannot infer the
@@ -112,13 +132,6 @@ __device__ __forceinline__ void ld_ar(const gdouble* b, const Lane& t, double (&
         ar[s] = t.L < ar_n(s) ? v : 0.0;
     });
 }
-__device__ __forceinline__ void ld_ac(const gdouble* b, const Lane& t, double (&ac)[13]) {
-    SFOR(r, 0, 13, {
-        const int c = imin(imax(t.L, ac_first(r)), 12);
-        const double v = b[4 * ac_pre(r) + t.q * ac_m(r) + (c - ac_first(r))];
-        ac[r] = (t.L >= ac_first(r) && t.L < 13) ? v : 0.0;
-    });
-}
 __device__ __forceinline__ void ld_rows4(const gdouble* b, const Lane& t, double (&r)[4]) {  // BR / KP
     SFOR(a, 0, 4, {
         const double v = b[(a * 4 + t.q) * 13 + imin(t.L, 12)];
@@ -132,6 +145,11 @@ __device__ __forceinline__ void ld_cols4(const gdouble* b, const Lane& t, double
     });
 }
 
+// input weight R_a for a runtime a in 0..3 (a select chain: dynamic indexing of the kernel
+// argument struct would force a scratch copy of it)
+__device__ __forceinline__ double w_u(const Params& P, int a) {
+    return a == 0 ? P.W[13] : (a == 1 ? P.W[14] : (a == 2 ? P.W[15] : P.W[16]));
+}
 // select element `idx` (runtime) of a register array
 template <int N>
 __device__ __forceinline__ double pick(const double (&a)[N], int idx) {
@@ -154,37 +172,14 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
     const int ucol = t.L == 13 ? 3 : t.L;
     const int xcol_ext = ext_of(is_x ? t.L : 3);
     const int tcol = is_x ? t.L : 13 + ucol;  // column in the LDS tile
-    double* tl_ = tile[t.q];
+    double* tl_ = tile[t.row];
 
     for (int k = 0; k < P.N; k++) {
         // every lane of the row holds the full (x_k, u_k) in EXTERNAL order (model code order)
-        double x[13], u[4], xt[13], k1[13], k2[13], k3[13], k4[13];
+        double x[13], u[4], xt[13], kk[13], cc[13], s[13], aphi[13], acol[13], ju[4] = {0, 0, 0, 0};
         const gdouble* xb = blk(P.xit, t, P.N + 1, k, SZ_V13);
         SFOR(e, 0, 13, { x[e] = xb[t.q * 13 + int_of(e)]; });
         SFOR(a, 0, 4, { u[a] = gm(P.uit)[i4(P, t, k, a)]; });
-        JacPoint J0, J1, J2, J3;
-        f_expl(x, u, k1);
-        jac_point(x, J0);
-        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k1[e]; });
-        f_expl(xt, u, k2);
-        jac_point(xt, J1);
-        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k2[e]; });
-        f_expl(xt, u, k3);
-        jac_point(xt, J2);
-        SFOR(e, 0, 13, { xt[e] = x[e] + h * k3[e]; });
-        f_expl(xt, u, k4);
-        jac_point(xt, J3);
-        double phi[13];
-        SFOR(e, 0, 13, { phi[e] = x[e] + (h / 6.0) * (k1[e] + 2 * k2[e] + 2 * k3[e] + k4[e]); });
-        // b = Phi - x_{k+1}, distributed (lane i <-> internal state i)
-        {
-            const double xn = ld13(blk(P.xit, t, P.N + 1, k + 1, SZ_V13), t);
-            const double ph = pick(phi, ext_of(t.L < 13 ? t.L : 0));
-            st13(blk(P.b, t, P.N, k, SZ_V13), t, ph - xn);
-        }
-        // this lane's sensitivity column through the four RK stages
-        double s0[13], s[13], c1[13], c2[13], c3[13], c4[13], ju[4] = {0, 0, 0, 0};
-        SFOR(e, 0, 13, { s0[e] = (is_x && xcol_ext == e) ? 1.0 : 0.0; });
         if (is_u) {
             const double uc = 2.0 * pick(u, ucol);
             const double sa = (ucol < 2) ? 1.0 : -1.0;
@@ -192,30 +187,52 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
             const double sc = (ucol == 0 || ucol == 2) ? 1.0 : -1.0;
             ju[0] = KT * uc; ju[1] = KA * sa * uc; ju[2] = KB * sb * uc; ju[3] = KC * sc * uc;
         }
-        jvp<true, true>(J0, s0, c1);
-        SFOR(i, 0, 4, { c1[9 + i] += ju[i]; });
-        SFOR(e, 0, 13, { s[e] = s0[e] + 0.5 * h * c1[e]; });
-        jvp<true, true>(J1, s, c2);
-        SFOR(i, 0, 4, { c2[9 + i] += ju[i]; });
-        SFOR(e, 0, 13, { s[e] = s0[e] + 0.5 * h * c2[e]; });
-        jvp<true, true>(J2, s, c3);
-        SFOR(i, 0, 4, { c3[9 + i] += ju[i]; });
-        SFOR(e, 0, 13, { s[e] = s0[e] + h * c3[e]; });
-        jvp<true, true>(J3, s, c4);
-        SFOR(i, 0, 4, { c4[9 + i] += ju[i]; });
-        double col[13];  // internal row order
+        // the four RK stages, nominal trajectory and this lane's sensitivity column interleaved
+        // so that only one Jacobian point is live at a time
+        JacPoint J;
+        SFOR(e, 0, 13, { s[e] = (is_x && xcol_ext == e) ? 1.0 : 0.0; });
+        f_expl(x, u, kk);
+        jac_point(x, J);
+        jvp<true, true>(J, s, cc);
+        SFOR(i, 0, 4, { cc[9 + i] += ju[i]; });
+        SFOR(e, 0, 13, {
+            aphi[e] = kk[e]; acol[e] = cc[e];
+            xt[e] = x[e] + 0.5 * h * kk[e];
+            s[e] = ((is_x && xcol_ext == e) ? 1.0 : 0.0) + 0.5 * h * cc[e];
+        });
+        f_expl(xt, u, kk);
+        jac_point(xt, J);
+        jvp<true, true>(J, s, cc);
+        SFOR(i, 0, 4, { cc[9 + i] += ju[i]; });
+        SFOR(e, 0, 13, {
+            aphi[e] += 2 * kk[e]; acol[e] += 2 * cc[e];
+            xt[e] = x[e] + 0.5 * h * kk[e];
+            s[e] = ((is_x && xcol_ext == e) ? 1.0 : 0.0) + 0.5 * h * cc[e];
+        });
+        f_expl(xt, u, kk);
+        jac_point(xt, J);
+        jvp<true, true>(J, s, cc);
+        SFOR(i, 0, 4, { cc[9 + i] += ju[i]; });
+        SFOR(e, 0, 13, {
+            aphi[e] += 2 * kk[e]; acol[e] += 2 * cc[e];
+            xt[e] = x[e] + h * kk[e];
+            s[e] = ((is_x && xcol_ext == e) ? 1.0 : 0.0) + h * cc[e];
+        });
+        f_expl(xt, u, kk);
+        jac_point(xt, J);
+        jvp<true, true>(J, s, cc);
+        SFOR(i, 0, 4, { cc[9 + i] += ju[i]; });
+        double phi[13], col[13];  // col in internal row order
+        SFOR(e, 0, 13, { phi[e] = x[e] + (h / 6.0) * (aphi[e] + kk[e]); });
         SFOR(r, 0, 13, {
             constexpr int e = ext_of(r);
-            col[r] = s0[e] + (h / 6.0) * (c1[e] + 2 * c2[e] + 2 * c3[e] + c4[e]);
+            col[r] = ((is_x && xcol_ext == e) ? 1.0 : 0.0) + (h / 6.0) * (acol[e] + cc[e]);
         });
-        // column form of A straight from registers
+        // b = Phi - x_{k+1}, distributed (lane i <-> internal state i)
         {
-            gdouble* ac = blk(P.AC, t, P.N, k, SZ_A);
-            SFOR(r, 0, 13, {
-                if (is_x && t.L >= ac_first(r)) ac[4 * ac_pre(r) + t.q * ac_m(r) + (t.L - ac_first(r))] = col[r];
-            });
-            gdouble* bcb = blk(P.BC, t, P.N, k, SZ_B);
-            SFOR(r, 0, 13, { if (is_u) bcb[(r * 4 + t.q) * 4 + ucol] = col[r]; });
+            const double xn = ld13(blk(P.xit, t, P.N + 1, k + 1, SZ_V13), t);
+            const double ph = pick(phi, ext_of(t.L < 13 ? t.L : 0));
+            st13(blk(P.b, t, P.N, k, SZ_V13), t, ph - xn);
         }
         // row forms through the LDS tile
         __syncthreads();
@@ -268,39 +285,56 @@ __device__ __forceinline__ bool spd4_inv(const double (&S)[10], double (&Si)[10]
     return ok;
 }
 
+// Everything one factorisation stage reads from HBM (so that the caller can prefetch it).
+template <bool ABSOLUTE>
+struct StageIn {
+    double ar[10], br[4];
+    double Rh, g;            // lanes a < 4: input Hessian diagonal / gradient element a
+    double bv, qv;           // ABSOLUTE: b_k[i] and q_k[i] = Q_i (x_k[i] - yref_k[i]) in lane i
+};
+template <bool ABSOLUTE>
+__device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const int k, StageIn<ABSOLUTE>& in) {
+    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
+    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+    const int a = t.L & 3;
+    if (ABSOLUTE) {
+        const double uk = gm(P.uit)[i4(P, t, k, a)];
+        const gdouble* yb = blk(P.yref, t, P.N, k, SZ_Y);
+        const double yr = yb[t.q * 17 + 13 + a];
+        const double wa = w_u(P, a);
+        in.Rh = t.L < 4 ? wa : 0.0;
+        in.g = t.L < 4 ? wa * (uk - yr) : 0.0;
+        in.bv = ld13(blk(P.b, t, P.N, k, SZ_V13), t);
+        const double xk = ld13(blk(P.xit, t, P.N + 1, k, SZ_V13), t);
+        const double yk = yb[t.q * 17 + imin(t.L, 12)];
+        double qv = 0.0;
+        SFOR(j, 0, 13, { if (t.L == j) qv = P.W[ext_of(j)] * (xk - yk); });
+        in.qv = qv;
+    } else {
+        const double rh = gm(P.Rh)[i4(P, t, k, a)], gg = gm(P.g)[i4(P, t, k, a)];
+        in.Rh = t.L < 4 ? rh : 0.0;
+        in.g = t.L < 4 ? gg : 0.0;
+        in.bv = 0.0;
+        in.qv = 0.0;
+    }
+}
+
 // One stage of the augmented backward recursion.
-//   Pa[13]: lanes 0..12 row i of P_{k+1}; lane 13 the affine row p_{k+1}' (delta form) -- on
-//           exit the same for stage k.
-//   ABSOLUTE: start solve with the QP's own affine terms (q_k, b_k, r_k);
-//   otherwise input Hessian R^ and gradient g are read from P.Rh / P.g (interior-point step).
+//   Pa[13]: lanes 0..12 row i of P_{k+1}; lane 13 the affine row p_{k+1}' -- on exit the same for
+//           stage k.  ABSOLUTE: start solve with the QP's own affine terms (q_k, b_k, r_k);
+//   otherwise R^ and g come from the interior-point state (homogeneous Newton system).
+//   wt: LDS [13*17] (transpose of W), sb: LDS [4*16] (columns of B for lanes 0..3).
 template <bool ABSOLUTE>
 __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, const int k, double (&Pa)[13],
-                                             double* wt /* LDS [13*17] of this instance */) {
-    double ar[10], br[4], bcl[13];
-    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, ar);
-    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, br);
-    ld_cols4(blk(P.BC, t, P.N, k, SZ_B), t, bcl);
-    // input Hessian / gradient: lane a < 4 holds element a
-    double Rh, g;
-    {
-        const int a = t.L & 3;
-        if (ABSOLUTE) {
-            const double uk = gm(P.uit)[i4(P, t, k, a)];
-            const double yr = blk(P.yref, t, P.N, k, SZ_Y)[t.q * 17 + 13 + a];
-            Rh = P.W[13 + a];
-            g = P.W[13 + a] * (uk - yr);
-        } else {
-            Rh = gm(P.Rh)[i4(P, t, k, a)];
-            g = gm(P.g)[i4(P, t, k, a)];
-        }
-        if (t.L >= 4) { Rh = 0.0; g = 0.0; }
-    }
+                                             const StageIn<ABSOLUTE>& in, double* wt, double* sb) {
+    const double(&ar)[10] = in.ar;
+    const double(&br)[4] = in.br;
     if (ABSOLUTE) {
         // hb' = p' + (P b)' in lane 13
-        const double bv = ld13(blk(P.b, t, P.N, k, SZ_V13), t);
         double pb = 0.0;
-        dotbc<13, 0>(pb, Pa, bv);
+        dotbc<13, 0>(pb, Pa, in.bv);
         if (t.L >= 13) pb = 0.0;
+        settle(pb);
         SFOR(j, 0, 13, {
             const double add = bc<j>(pb);
             if (t.L == 13) Pa[j] += add;
@@ -319,10 +353,14 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     SFOR(a, 0, 4, { V[a] = 0.0; });
     dot2bc<13, 0>(V[0], V[1], Pa, br[0], br[1]);
     dot2bc<13, 0>(V[2], V[3], Pa, br[2], br[3]);
-    // (3) Wt = transpose of W over lanes 0..12; lane 13 keeps the affine row
+    // (3) Wt = transpose of W over lanes 0..12; lane 13 keeps the affine row.  The same LDS
+    //     round trip hands the columns of B to lanes 0..3.
     double Wt[13];
     __syncthreads();
-    if (t.L < 13) SFOR(j, 0, 13, { wt[j * 17 + t.L] = W[j]; });
+    if (t.L < 13) {
+        SFOR(j, 0, 13, { wt[j * 17 + t.L] = W[j]; });
+        SFOR(a, 0, 4, { sb[a * 16 + t.L] = br[a]; });
+    }
     __syncthreads();
     SFOR(l, 0, 13, {
         const double w = wt[imin(t.L, 12) * 17 + l];
@@ -331,13 +369,8 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     // (4) M = Q + Wt A  (lane 13: q_k' + hb'A)
     double M[13];
     if (ABSOLUTE) {
-        // q_k distributed -> row form in lane 13
-        const double xk = ld13(blk(P.xit, t, P.N + 1, k, SZ_V13), t);
-        const double yk = blk(P.yref, t, P.N, k, SZ_Y)[t.q * 17 + imin(t.L, 12)];
-        double qv = 0.0;
-        SFOR(j, 0, 13, { if (t.L == j) qv = P.W[ext_of(j)] * (xk - yk); });
         SFOR(j, 0, 13, {
-            const double qj = bc<j>(qv);
+            const double qj = bc<j>(in.qv);
             M[j] = (t.L == j) ? P.W[ext_of(j)] : (t.L == 13 ? qj : 0.0);
         });
     } else {
@@ -356,12 +389,17 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     dot2bc<13, 0>(Gp[0], Gp[1], Wt, br[0], br[1]);
     dot2bc<13, 0>(Gp[2], Gp[3], Wt, br[2], br[3]);
     SFOR(a, 0, 4, {
-        const double ga = bc<a>(g);
+        const double ga = bc<a>(in.g);
         if (t.L == 13) Gp[a] += ga;
     });
     // (6) S = R^ + B'V in lanes a < 4, replicated, inverted redundantly by every lane
+    double bcl[13];
+    SFOR(l, 0, 13, {
+        const double v = sb[(t.L & 3) * 16 + l];
+        bcl[l] = t.L < 4 ? v : 0.0;
+    });
     double Srow[4];
-    SFOR(c, 0, 4, { Srow[c] = (t.L == c) ? Rh : 0.0; });
+    SFOR(c, 0, 4, { Srow[c] = (t.L == c) ? in.Rh : 0.0; });
     dot2bc<13, 0>(Srow[0], Srow[1], bcl, V[0], V[1]);
     dot2bc<13, 0>(Srow[2], Srow[3], bcl, V[2], V[3]);
     SFOR(c, 0, 4, { settle(Srow[c]); });
@@ -381,15 +419,11 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         Pa[j] = M[j];
         updbc<j>(Pa[j], Kp, nGp);
     });
-    // (9) stores
+    // (9) stores: gain in "lane a holds K[a][.]" form, Sinv, feed-forward
     {
-        gdouble* kp = blk(P.KP, t, P.N, k, SZ_K);
         gdouble* kr = blk(P.KR, t, P.N, k, SZ_K);
         SFOR(a, 0, 4, {
-            if (t.L < 13) {
-                kp[(a * 4 + t.q) * 13 + t.L] = Kp[a];
-                kr[(t.L * 4 + t.q) * 4 + a] = Kp[a];
-            }
+            if (t.L < 13) kr[(t.L * 4 + t.q) * 4 + a] = Kp[a];
             if (t.L == 13) gm(P.d)[i4(P, t, k, a)] = Kp[a];
         });
         if (t.L == 0) {
@@ -400,11 +434,12 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     return ok;
 }
 
-// Backward factorisation over stages [0, head).  If FROM_CHK the recursion starts from a stored
-// checkpoint of the unconstrained tail (P.Pchk, affine row zero), else from the terminal cost.
+// Backward factorisation over stages [0, head), next stage prefetched while the current one is
+// computed.  chk >= 0: start from a stored checkpoint of the unconstrained tail (P.Pchk, affine
+// row zero), else from the terminal cost.
 template <bool ABSOLUTE>
 __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, const int head, const int chk,
-                                             double* wt) {
+                                             double* wt, double* sb) {
     double Pa[13];
     if (ABSOLUTE || chk < 0) {
         const double xN = ABSOLUTE ? ld13(blk(P.xit, t, P.N + 1, P.N, SZ_V13), t) : 0.0;
@@ -423,8 +458,11 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
         });
     }
     bool ok = true;
+    StageIn<ABSOLUTE> cur, nxt;
+    load_stage<ABSOLUTE>(P, t, head - 1, cur);
     for (int k = head - 1; k >= 0; k--) {
-        ok = factor_stage<ABSOLUTE>(P, t, k, Pa, wt) && ok;
+        load_stage<ABSOLUTE>(P, t, k > 0 ? k - 1 : 0, nxt);  // prefetch (k = 0: harmless reload)
+        ok = factor_stage<ABSOLUTE>(P, t, k, Pa, cur, wt, sb) && ok;
         if (ABSOLUTE) {
             // checkpoints of the unconstrained cost-to-go (matrix part only)
             SFOR(c, 0, N_CHK, {
@@ -434,81 +472,243 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
                 }
             });
         }
+        cur = nxt;
     }
     return ok;
 }
 
-// x+ = A x + B v (+ b), all distributed; vr[4] replicated
+// Everything one forward stage reads from HBM: gain, feed-forward, A, B (and b), so that the
+// caller can issue the loads of stage k+1 before the arithmetic of stage k (the recursion
+// itself only carries the 13-vector x).
 template <bool WITH_B>
-__device__ __forceinline__ double propagate(const Params& P, const Lane& t, const int k, const double x,
-                                            const double (&vr)[4]) {
-    double ar[10], br[4];
-    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, ar);
-    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, br);
-    double xn = t.L < 3 ? x : 0.0;
-    if (WITH_B) xn += ld13(blk(P.b, t, P.N, k, SZ_V13), t);
-    dotbc<10, 3>(xn, ar, x);
-    SFOR(a, 0, 4, { xn += br[a] * vr[a]; });
-    return xn;
+struct FwdIn {
+    double kr[13], ar[10], br[4], d, bv;
+};
+template <bool WITH_B>
+__device__ __forceinline__ void load_fwd(const Params& P, const Lane& t, const int k, FwdIn<WITH_B>& in) {
+    ld_cols4(blk(P.KR, t, P.N, k, SZ_K), t, in.kr);
+    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
+    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+    in.d = gm(P.d)[i4(P, t, k, t.L & 3)];
+    in.bv = WITH_B ? ld13(blk(P.b, t, P.N, k, SZ_V13), t) : 0.0;
 }
-
 // v = -K x - d in lanes a < 4
-__device__ __forceinline__ double feedback(const Params& P, const Lane& t, const int k, const double x) {
-    double kr[13];
-    ld_cols4(blk(P.KR, t, P.N, k, SZ_K), t, kr);
-    const double dk = gm(P.d)[i4(P, t, k, t.L & 3)];
-    double v = t.L < 4 ? -dk : 0.0;
+template <bool WITH_B>
+__device__ __forceinline__ double feedback(const Lane& t, const FwdIn<WITH_B>& in, const double x) {
+    double v = t.L < 4 ? -in.d : 0.0;
     double acc = 0.0;
-    dotbc<13, 0>(acc, kr, x);
+    dotbc<13, 0>(acc, in.kr, x);
     v -= acc;
     settle(v);
     return v;
+}
+// x+ = A x + B v (+ b), all distributed; vr[4] replicated
+template <bool WITH_B>
+__device__ __forceinline__ double propagate(const Lane& t, const FwdIn<WITH_B>& in, const double x, const double (&vr)[4]) {
+    double xn = t.L < 3 ? x : 0.0;
+    if (WITH_B) xn += in.bv;
+    dotbc<10, 3>(xn, in.ar, x);
+    SFOR(a, 0, 4, { xn += in.br[a] * vr[a]; });
+    return xn;
 }
 
 // forward sweep of a homogeneous (delta) solve over [0, head): writes the input step to `out`
 __device__ __forceinline__ void sweep_forward_delta(const Params& P, const Lane& t, const int head, gdouble* out) {
     double x = 0.0;
+    FwdIn<false> cur, nxt;
+    load_fwd<false>(P, t, 0, cur);
     for (int k = 0; k < head; k++) {
-        const double dv = feedback(P, t, k, x);
+        load_fwd<false>(P, t, imin(k + 1, head - 1), nxt);  // prefetch
+        const double dv = feedback<false>(t, cur, x);
         if (t.L < 4) out[i4(P, t, k, t.L)] = dv;
         double vr[4];
         SFOR(a, 0, 4, { vr[a] = bc<a>(dv); });
-        if (k + 1 < head) x = propagate<false>(P, t, k, x, vr);
+        x = propagate<false>(t, cur, x, vr);
+        cur = nxt;
     }
 }
 
-// backward sweep re-using the factorisation for the right-hand side P.g (input rows only);
-// overwrites d
+// Backward sweep re-using the factorisation for the right-hand side P.g (input rows only);
+// overwrites d.  The costate row p' is carried REPLICATED in every lane (13 registers), so only
+// the row forms AR / BR / KR are needed:  rho = g + B'p ;  p' <- p'A - rho'K.
+struct ResIn {
+    double ar[10], br[4], kr[13], g, sv[4];
+};
+__device__ __forceinline__ void load_res(const Params& P, const Lane& t, const int k, ResIn& in) {
+    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
+    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+    ld_cols4(blk(P.KR, t, P.N, k, SZ_K), t, in.kr);
+    const int a = t.L & 3;
+    in.g = gm(P.g)[i4(P, t, k, a)];
+    const gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S) + t.q * 10;
+    SFOR(c, 0, 4, {
+        const int lo = a < c ? a : c, hi = a < c ? c : a;
+        in.sv[c] = sv[lo * 4 - (lo * (lo - 1)) / 2 + (hi - lo)];
+    });
+}
 __device__ __forceinline__ void sweep_resolve(const Params& P, const Lane& t, const int head) {
-    double p = 0.0;
+    double p[13];
+    SFOR(j, 0, 13, { p[j] = 0.0; });
+    ResIn cur, nxt;
+    load_res(P, t, head - 1, cur);
     for (int k = head - 1; k >= 0; k--) {
-        double bcl[13], ac[13], kp[4];
-        ld_cols4(blk(P.BC, t, P.N, k, SZ_B), t, bcl);
-        ld_ac(blk(P.AC, t, P.N, k, SZ_A), t, ac);
-        ld_rows4(blk(P.KP, t, P.N, k, SZ_K), t, kp);
+        load_res(P, t, imax(k - 1, 0), nxt);  // prefetch
+        const double(&ar)[10] = cur.ar;
+        const double(&br)[4] = cur.br;
+        const double(&kr)[13] = cur.kr;
         const int a = t.L & 3;
-        const double gk = gm(P.g)[i4(P, t, k, a)];
-        double rho = t.L < 4 ? gk : 0.0;
-        dotbc<13, 0>(rho, bcl, p);
-        settle(rho);
-        double rr[4];
-        SFOR(c, 0, 4, { rr[c] = bc<c>(rho); });
-        const gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S) + t.q * 10;
+        double glane = t.L < 4 ? cur.g : 0.0;
+        // rho[a] = g[a] + sum_l p[l] B[l][a]   (replicated)
+        double rr[4], nrr[4];
+        SFOR(c, 0, 4, { rr[c] = bc<c>(glane); });
+        dot2bc<13, 0>(rr[0], rr[1], p, br[0], br[1]);
+        dot2bc<13, 0>(rr[2], rr[3], p, br[2], br[3]);
+        SFOR(c, 0, 4, { nrr[c] = -rr[c]; });
+        // d = Sinv rho in lanes a < 4
         double dd = 0.0;
-        SFOR(c, 0, 4, {
-            const int lo = a < c ? a : c, hi = a < c ? c : a;
-            dd += sv[lo * 4 - (lo * (lo - 1)) / 2 + (hi - lo)] * rr[c];
-        });
+        SFOR(c, 0, 4, { dd += cur.sv[c] * rr[c]; });
         if (t.L < 4) gm(P.d)[i4(P, t, k, a)] = dd;
-        double pn = t.L < 3 ? p : 0.0;
-        dotbc<13, 0>(pn, ac, p);
-        SFOR(c, 0, 4, { pn -= kp[c] * rr[c]; });
-        p = pn;
+        // p' <- p'A - rho'K
+        double pn[13];
+        SFOR(j, 0, 3, { pn[j] = p[j]; });
+        SFOR(j, 3, 13, { pn[j] = 0.0; });
+        dot2bc<6, 0>(pn[3], pn[4], p, ar[0], ar[1]);
+        dotbc<6, 0>(pn[5], p, ar[2]);
+        dot2bc<10, 0>(pn[6], pn[7], p, ar[3], ar[4]);
+        dot2bc<10, 0>(pn[8], pn[9], p, ar[5], ar[6]);
+        dot2bc<13, 0>(pn[10], pn[11], p, ar[7], ar[8]);
+        dotbc<13, 0>(pn[12], p, ar[9]);
+        SFOR(j, 0, 13, { dotbc<4, 0>(pn[j], nrr, kr[j]); });
+        SFOR(j, 0, 13, { p[j] = pn[j]; });
+        cur = nxt;
     }
 }
 
 // =============================================================================================
-// QP solve + RTI update
+// start solve: backward factorisation, forward sweep
+// =============================================================================================
+__global__ __launch_bounds__(64, 2) void k_factor(Params P) {
+    __shared__ double wtile[4][13 * 17 + 3];
+    __shared__ double btile[4][64];
+    const Lane t = lane_id(P);
+    bool ok = sweep_factor<true>(P, t, P.N, -1, wtile[t.row], btile[t.row]);
+    ok = row_min(ok ? 1.0 : 0.0) > 0.0;
+    if (t.L == 0 && t.valid) gm(P.status)[t.inst] = ok ? 0 : 4;
+}
+
+// Unconstrained inputs and state step of the start solve; per instance the largest bound
+// violation, per wave the head of the horizon the interior-point sweeps must cover (0: none).
+__device__ __forceinline__ void start_forward(const Params& P, const Lane& t, double& viol, int& last_tight) {
+    const int N = P.N;
+    const double margin = 0.05 * (P.u_max - P.u_min);
+    bool sawnan = false;
+    viol = 0.0;
+    last_tight = -1;
+    double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
+    FwdIn<true> cur, nxt;
+    load_fwd<true>(P, t, 0, cur);
+    double ucur = gm(P.uit)[i4(P, t, 0, t.L & 3)], unxt;
+    for (int k = 0; k < N; k++) {
+        load_fwd<true>(P, t, imin(k + 1, N - 1), nxt);  // prefetch
+        unxt = gm(P.uit)[i4(P, t, imin(k + 1, N - 1), t.L & 3)];
+        st13(blk(P.dx, t, N + 1, k, SZ_V13), t, x);
+        const double v = feedback<true>(t, cur, x);
+        if (t.L < 4) {
+            const double lb = P.u_min - ucur, ub = P.u_max - ucur;
+            gm(P.v)[i4(P, t, k, t.L)] = v;
+            viol = fmax(viol, fmax(lb - v, v - ub));
+            if (v < lb + margin || v > ub - margin) last_tight = k;
+            sawnan = sawnan || !(v == v);
+        }
+        double vr[4];
+        SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
+        x = propagate<true>(t, cur, x, vr);
+        cur = nxt;
+        ucur = unxt;
+    }
+    st13(blk(P.dx, t, N + 1, N, SZ_V13), t, x);
+    viol = row_max(viol);
+    last_tight = (int)row_max((double)last_tight);
+    if (row_max(sawnan ? 1.0 : 0.0) > 0.0) viol = nan("");
+}
+
+// head class of an instance: the interior-point sweeps must cover stages [0, want)
+__device__ __forceinline__ int head_class(const Params& P, int want) {
+    if (want <= 0) return 0;
+    int head = P.N;
+    if (P.active_horizon) {
+        SFOR(c, 0, N_CHK, {
+            constexpr int cs = chk_stage(N_CHK - 1 - c);
+            if (want <= cs && cs < P.N) head = cs;
+        });
+    }
+    return head;
+}
+
+__global__ __launch_bounds__(64) void k_forward(Params P) {
+    const Lane t = lane_id(P);
+    double viol;
+    int last_tight;
+    start_forward(P, t, viol, last_tight);
+    const bool okf = t.valid && gm(P.status)[imin(t.inst, P.B - 1)] == 0;
+    const bool bad = t.valid && (!okf || !(viol == viol));
+    const bool infeasible = t.valid && !bad && (viol > 0.0);
+    if (t.valid && t.L == 0) {
+        gm(P.viol)[t.inst] = infeasible ? viol : 0.0;
+        gm(P.status)[t.inst] = bad ? 4 : 0;
+        gm(P.iters)[t.inst] = 0;
+        gm(P.res)[t.inst] = bad ? nan("") : 0.0;
+        gm(P.head)[t.inst] = infeasible ? head_class(P, last_tight + 3) : 0;
+    }
+}
+
+// Stable compaction of the instances that need the interior-point method, grouped by head
+// class (largest first) so that the four rows of a wave work on similar horizons.  One block.
+__global__ __launch_bounds__(1024) void k_compact(Params P) {
+    constexpr int NC = N_CHK + 1;
+    __shared__ int cnt[NC][1024];
+    __shared__ int base[NC + 1];
+    const int tid = threadIdx.x;
+    const int chunk = (P.B + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(lo + chunk, P.B);
+    int c[NC];
+    for (int j = 0; j < NC; j++) c[j] = 0;
+    auto cls = [&](int h) {  // 0: full horizon, 1..N_CHK: checkpoints from large to small
+        int r = 0;
+        SFOR(cc, 0, N_CHK, { if (h == chk_stage(N_CHK - 1 - cc) && h < P.N) r = 1 + cc; });
+        return r;
+    };
+    for (int i = lo; i < hi; i++) {
+        const int h = gm(P.head)[i];
+        if (h > 0) c[cls(h)]++;
+    }
+    for (int j = 0; j < NC; j++) cnt[j][tid] = c[j];
+    __syncthreads();
+    // exclusive scan over threads, per class (Hillis-Steele on 1024 entries)
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v[NC];
+        for (int j = 0; j < NC; j++) v[j] = tid >= off ? cnt[j][tid - off] : 0;
+        __syncthreads();
+        for (int j = 0; j < NC; j++) cnt[j][tid] += v[j];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int acc = 0;
+        for (int j = 0; j < NC; j++) { base[j] = acc; acc += cnt[j][1023]; }
+        base[NC] = acc;
+        gm(P.nipm)[0] = acc;
+    }
+    __syncthreads();
+    int pos[NC];
+    for (int j = 0; j < NC; j++) pos[j] = base[j] + cnt[j][tid] - c[j];
+    for (int i = lo; i < hi; i++) {
+        const int h = gm(P.head)[i];
+        if (h > 0) gm(P.ilist)[pos[cls(h)]++] = i;
+    }
+}
+
+// =============================================================================================
+// interior-point QP on the waves that need it
 // =============================================================================================
 struct RowIPM {  // uniform over the 16 lanes of a row
     double mu, res;
@@ -534,65 +734,31 @@ __device__ __forceinline__ Elem ld_elem(const Params& P, const Lane& t, size_t i
     return e;
 }
 
-__global__ __launch_bounds__(64) void k_qp(Params P) {
+__global__ __launch_bounds__(64) void k_ipm(Params P) {
     __shared__ double wtile[4][13 * 17 + 3];
-    const Lane t = lane_id(P);
-    double* wt = wtile[t.q];
+    __shared__ double btile[4][64];
+    const int nipm = gm(P.nipm)[0];
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (blockIdx.x * 4 >= nipm) return;  // wave-uniform: no work for this wave
+    const bool has = slot < nipm;
+    const Lane t = lane_indirect(P, has ? gm(P.ilist)[imin(slot, nipm - 1)] : 0, has);
+    double* wt = wtile[t.row];
+    double* sb = btile[t.row];
     const int N = P.N;
     const size_t ibase = (size_t)t.inst * N * 4;  // this instance's 4-vectors
+    // wave-uniform head = largest head class among the four rows
+    int head = t.valid ? gm(P.head)[t.inst] : 0;
+    head = max(head, __shfl_xor(head, 16));
+    head = max(head, __shfl_xor(head, 32));
+    int chk = -1;
+    SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
+    const double viol = t.valid ? gm(P.viol)[t.inst] : 0.0;
+    const bool infeasible = t.valid && (viol > 0.0);
     RowIPM R;
-    R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
-
-    // ---- start: unconstrained minimiser (absolute Riccati solve over the whole horizon)
-    bool ok = sweep_factor<true>(P, t, N, -1, wt);
-    double viol = 0.0;      // max bound violation of the unconstrained inputs
-    int last_tight = -1;    // last stage whose unconstrained input is outside / near a bound
-    {
-        const double margin = 0.05 * (P.u_max - P.u_min);
-        bool sawnan = false;
-        double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
-        for (int k = 0; k < N; k++) {
-            const double v = feedback(P, t, k, x);
-            if (t.L < 4) {
-                const double uk = gm(P.uit)[i4(P, t, k, t.L)];
-                const double lb = P.u_min - uk, ub = P.u_max - uk;
-                gm(P.v)[i4(P, t, k, t.L)] = v;
-                viol = fmax(viol, fmax(lb - v, v - ub));
-                if (v < lb + margin || v > ub - margin) last_tight = k;
-                sawnan = sawnan || !(v == v);
-            }
-            double vr[4];
-            SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
-            x = propagate<true>(P, t, k, x, vr);
-        }
-        viol = row_max(viol);
-        last_tight = (int)row_max((double)last_tight);
-        if (row_max(sawnan ? 1.0 : 0.0) > 0.0) viol = nan("");
-    }
-    ok = row_min(ok ? 1.0 : 0.0) > 0.0;
-
-    // ---- head of the horizon the interior-point sweeps work on (wave-uniform)
-    int head = N, chk = -1;
-    const bool infeasible = t.valid && ok && (viol > 0.0);
-    if (P.active_horizon) {
-        int want = infeasible ? last_tight + 3 : 0;
-        // wave-uniform maximum over the four instances
-        want = max(want, __shfl_xor(want, 16));
-        want = max(want, __shfl_xor(want, 32));
-        head = N;
-        SFOR(c, 0, N_CHK, {
-            constexpr int cs = chk_stage(N_CHK - 1 - c);
-            if (want <= cs && cs < N) { head = cs; chk = N_CHK - 1 - c; }
-        });
-    }
 
     for (int attempt = 0; attempt < 2; attempt++) {
-        if (!t.valid) {
-            R.status = 0;
-        } else if (!ok || !(viol == viol)) {
-            R.status = 4;
-            R.res = nan("");
-        } else if (infeasible) {
+        R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
+        if (infeasible) {
             // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
             const double mu0 = fmax(viol, P.lam0_min);
             double mu = 0.0, res = 0.0;
@@ -605,7 +771,7 @@ __global__ __launch_bounds__(64) void k_qp(Params P) {
                 gm(P.tl)[idx] = tl; gm(P.tu)[idx] = tu; gm(P.ll)[idx] = ll; gm(P.lu)[idx] = lu; gm(P.rg)[idx] = rg;
                 const double rl = v - lb - tl, ru = ub - v - tu;
                 const double Dl = ll / tl, Du = lu / tu;
-                gm(P.Rh)[idx] = P.W[13 + (e & 3)] + Dl + Du;
+                gm(P.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
                 gm(P.g)[idx] = rg + ll + Dl * rl - lu - Du * ru;
                 mu += ll * tl + lu * tu;
                 res = fmax(res, fmax(fmax(ll * tl, lu * tu), fmax(fabs(rg), fmax(fabs(rl), fabs(ru)))));
@@ -626,7 +792,7 @@ __global__ __launch_bounds__(64) void k_qp(Params P) {
             if (!__any(R.act)) break;
             if (R.act) R.iters++;
             // predictor: factorise (R^, g from the element-wise pass), forward
-            const bool fok = sweep_factor<false>(P, t, head, chk, wt);
+            const bool fok = sweep_factor<false>(P, t, head, chk, wt, sb);
             sweep_forward_delta(P, t, head, gm(P.dva));
             // affine step length, mu_aff, centering; corrector right-hand side
             double smu;
@@ -700,7 +866,7 @@ __global__ __launch_bounds__(64) void k_qp(Params P) {
                     const double Dl = ll / tl, Du = lu / tu;
                     if (R.act) {
                         gm(P.v)[idx] = v; gm(P.tl)[idx] = tl; gm(P.tu)[idx] = tu; gm(P.ll)[idx] = ll; gm(P.lu)[idx] = lu; gm(P.rg)[idx] = rg;
-                        gm(P.Rh)[idx] = P.W[13 + (e & 3)] + Dl + Du;
+                        gm(P.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
                         gm(P.g)[idx] = rg + ll + Dl * rln - lu - Du * run;
                     }
                     mu += ll * tl + lu * tu;
@@ -721,63 +887,67 @@ __global__ __launch_bounds__(64) void k_qp(Params P) {
         bool tail_ok = true;
         {
             double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
+            FwdIn<true> cur, nxt;
+            load_fwd<true>(P, t, 0, cur);
+            double vcur = gm(P.v)[i4(P, t, 0, t.L & 3)], ucur = gm(P.uit)[i4(P, t, 0, t.L & 3)], vnxt, unxt;
             for (int k = 0; k < N; k++) {
+                const int kn = imin(k + 1, N - 1);
+                load_fwd<true>(P, t, kn, nxt);  // prefetch
+                vnxt = gm(P.v)[i4(P, t, kn, t.L & 3)];
+                unxt = gm(P.uit)[i4(P, t, kn, t.L & 3)];
                 st13(blk(P.dx, t, N + 1, k, SZ_V13), t, x);
                 double v;
                 if (k < head) {
-                    const double vk = gm(P.v)[i4(P, t, k, t.L & 3)];
-                    v = t.L < 4 ? vk : 0.0;
+                    v = t.L < 4 ? vcur : 0.0;
                 } else {
-                    v = feedback(P, t, k, x);
+                    v = feedback<true>(t, cur, x);
                     if (t.L < 4) {
-                        const double uk = gm(P.uit)[i4(P, t, k, t.L)];
-                        tail_ok = tail_ok && (v >= P.u_min - uk) && (v <= P.u_max - uk);
+                        tail_ok = tail_ok && (v >= P.u_min - ucur) && (v <= P.u_max - ucur);
                         gm(P.v)[i4(P, t, k, t.L)] = v;
                     }
                 }
                 double vr[4];
                 SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
-                x = propagate<true>(P, t, k, x, vr);
+                x = propagate<true>(t, cur, x, vr);
+                cur = nxt;
+                vcur = vnxt;
+                ucur = unxt;
             }
             st13(blk(P.dx, t, N + 1, N, SZ_V13), t, x);
             tail_ok = row_min(tail_ok ? 1.0 : 0.0) > 0.0;
         }
         const bool redo = t.valid && R.status != 4 && !tail_ok && head < N;
         if (!__any(redo)) break;
-        // rare: a tail input left the box -> solve again over the full horizon (whole wave)
+        // rare: a tail input left the box -> solve again over the full horizon (whole wave):
+        // the head stages' gains were overwritten by the delta sweeps, so redo the start solve
         head = N; chk = -1;
-        R.iters = 0; R.status = 0; R.res = 0.0; R.act = false;
-        ok = sweep_factor<true>(P, t, N, -1, wt);
-        ok = row_min(ok ? 1.0 : 0.0) > 0.0;
+        (void)sweep_factor<true>(P, t, N, -1, wt, sb);
         {
-            double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
-            for (int k = 0; k < N; k++) {
-                const double v = feedback(P, t, k, x);
-                if (t.L < 4) gm(P.v)[i4(P, t, k, t.L)] = v;
-                double vr[4];
-                SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
-                x = propagate<true>(P, t, k, x, vr);
-            }
+            double vv; int lt;
+            start_forward(P, t, vv, lt);
         }
     }
+    if (t.L == 0 && infeasible) {
+        gm(P.status)[t.inst] = R.status;
+        gm(P.iters)[t.inst] = R.iters;
+        gm(P.res)[t.inst] = R.res;
+        gm(P.head)[t.inst] = head;
+    }
+}
 
-    // ---- full RTI step (iterate += step) and statistics
-    if (t.valid) {
-        if (R.status != 4) {
-            for (int k = 0; k <= N; k++) {
-                gdouble* xb = blk(P.xit, t, N + 1, k, SZ_V13);
-                const double dxk = ld13(blk(P.dx, t, N + 1, k, SZ_V13), t);
-                if (t.L < 13) xb[t.q * 13 + t.L] += dxk;
-            }
-            for (int e = t.L; e < N * 4; e += 16) gm(P.uit)[ibase + e] += gm(P.v)[ibase + e];
-        }
-        if (t.L == 0) {
-            gm(P.status)[t.inst] = R.status;
-            gm(P.iters)[t.inst] = R.iters;
-            gm(P.res)[t.inst] = R.res;
-            gm(P.head)[t.inst] = head;
-        }
+// full RTI step: iterate += step (streaming)
+__global__ __launch_bounds__(64) void k_commit(Params P) {
+    const Lane t = lane_id(P);
+    if (!t.valid) return;
+    const int N = P.N;
+    if (gm(P.status)[t.inst] == 4) return;  // failed QP: keep the iterate (status tells the caller)
+    for (int k = 0; k <= N; k++) {
+        gdouble* xb = blk(P.xit, t, N + 1, k, SZ_V13);
+        const double dxk = ld13(blk(P.dx, t, N + 1, k, SZ_V13), t);
+        if (t.L < 13) xb[t.q * 13 + t.L] += dxk;
     }
+    const size_t ibase = (size_t)t.inst * N * 4;
+    for (int e = t.L; e < N * 4; e += 16) gm(P.uit)[ibase + e] += gm(P.v)[ibase + e];
 }
 
 // =============================================================================================
@@ -859,7 +1029,13 @@ __global__ void k_init_iterate(Params P, int mode) {
 void launch_linearise(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_linearise, dim3(P.NW), dim3(64), 0, st, P);
 }
-void launch_qp(const Params& P, hipStream_t st) { hipLaunchKernelGGL(k_qp, dim3(P.NW), dim3(64), 0, st, P); }
+void launch_qp(const Params& P, hipStream_t st) {
+    hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(k_forward, dim3(P.NW), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, P);
+    hipLaunchKernelGGL(k_ipm, dim3(P.NW), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(k_commit, dim3(P.NW), dim3(64), 0, st, P);
+}
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st) {
     hipLaunchKernelGGL(k_sim, dim3((B + 255) / 256), dim3(256), 0, st, B, x, u, T, steps, xn);
 }

@@ -34,17 +34,12 @@ __host__ __device__ constexpr int int_of(int e) { return e < 3 ? e : (e < 7 ? e 
 //      c in q -> rows 0..9, c in w -> rows 0..12  (a lane prefix).
 __host__ __device__ constexpr int ar_n(int s) { return s < 3 ? 6 : (s < 7 ? 10 : 13); }
 __host__ __device__ constexpr int ar_pre(int s) { return s < 3 ? 6 * s : (s < 7 ? 18 + 10 * (s - 3) : 58 + 13 * (s - 7)); }
-// ---- A in "column form" (AC): lane c holds A[0..n_c-1][c] in slots r (slot r <-> row r).
-//      Columns that own row r: r in p,v -> lanes 3..12, r in q -> lanes 6..12, r in w -> 10..12.
-__host__ __device__ constexpr int ac_first(int r) { return r < 6 ? 3 : (r < 10 ? 6 : 10); }
-__host__ __device__ constexpr int ac_m(int r) { return 13 - ac_first(r); }
-__host__ __device__ constexpr int ac_pre(int r) { return r < 6 ? 10 * r : (r < 10 ? 60 + 7 * (r - 6) : 88 + 3 * (r - 10)); }
-static_assert(ar_pre(9) + ar_n(9) == 97 && ac_pre(12) + ac_m(12) == 97, "97 stored entries of dPhi/dx");
+static_assert(ar_pre(9) + ar_n(9) == 97, "97 stored entries of dPhi/dx");
 
 // doubles per (wave, stage) block
-constexpr int SZ_A = 4 * 97;   // AR or AC
-constexpr int SZ_B = 4 * 52;   // BR: [a][inst][13]      BC: [l][inst][4]
-constexpr int SZ_K = 4 * 52;   // KP ("K'", lane i holds K[0..3][i]): [a][inst][13] ; KR (lane a holds K[a][0..12]): [l][inst][4]
+constexpr int SZ_A = 4 * 97;   // AR: [slot][inst][lanes < ar_n(slot)]
+constexpr int SZ_B = 4 * 52;   // BR: [a][inst][13]
+constexpr int SZ_K = 4 * 52;   // KR (lane a holds K[a][0..12]): [l][inst][4]
 constexpr int SZ_V13 = 4 * 13; // 13-vectors: [inst][13]
 constexpr int SZ_V4 = 4 * 4;   // 4-vectors:  [inst][4]
 constexpr int SZ_S = 4 * 10;   // packed symmetric 4x4: [inst][10]
@@ -68,19 +63,21 @@ struct Params {
     double *yref;    // N x SZ_Y
     double *yref_e;  // 1 x SZ_V13
     // linearisation
-    double *AR, *AC;  // N x SZ_A
-    double *BR, *BC;  // N x SZ_B
+    double *AR;  // N x SZ_A   A row-distributed (lane i holds A[i][3..12])
+    double *BR;  // N x SZ_B   B row-distributed (lane i holds B[i][0..3])
     double *b;        // N x SZ_V13
     // Riccati factors
-    double *KP, *KR;  // N x SZ_K
+    double *KR;       // N x SZ_K   gain, lane a < 4 holds K[a][0..12]
     double *Sinv;     // N x SZ_S
     double *d;        // N x SZ_V4
     double *Pchk;     // N_CHK x SZ_P   cost-to-go of the unconstrained tail at the checkpoints
     // interior-point state, N x SZ_V4 each
     double *v, *tl, *tu, *ll, *lu, *rg, *dva, *dvc, *Rh, *g;
     double *dx;  // (N+1) x SZ_V13: step in x of the accepted QP solution (commit buffer)
-    int *status, *iters, *head;  // per instance
-    double *res;
+    int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
+    double *res, *viol;          // per instance
+    int *ilist;                  // compacted list of the instances that need the interior-point method
+    int *nipm;                   // its length
 };
 
 void launch_linearise(const Params& P, hipStream_t st);

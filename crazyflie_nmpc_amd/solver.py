@@ -160,9 +160,9 @@ class BatchSolver:
                                         rs.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_get_stats")
         return st, it, rs
 
-    def get_linearisation(self, form=0):
+    def get_linearisation(self):
         A = np.empty((self.B, self.N, NX, NX)); Bm = np.empty((self.B, self.N, NX, NU)); b = np.empty((self.B, self.N, NX))
-        _check(self._L.cfnmpc_debug_get_linearisation(self._h, int(form), A.ctypes.data_as(C.c_void_p), Bm.ctypes.data_as(C.c_void_p),
+        _check(self._L.cfnmpc_debug_get_linearisation(self._h, A.ctypes.data_as(C.c_void_p), Bm.ctypes.data_as(C.c_void_p),
                                                       b.ctypes.data_as(C.c_void_p)), "cfnmpc_debug_get_linearisation")
         return A, Bm, b
 

@@ -112,9 +112,8 @@ int cfnmpc_sim(int batch, const double *x, const double *u, double T, int steps,
 
 /* Kernel-level access for parity tests (oracle comparison of the linearisation): copies the
  * stage blocks of the last linearisation as dense row-major arrays in the reference's state
- * order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13] (host pointers).  form 0 decodes the
- * row-distributed copies (AR, BR), form 1 the column-distributed ones (AC, BC). */
-int cfnmpc_debug_get_linearisation(cfnmpc_solver *s, int form, double *A, double *Bm, double *b);
+ * order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13] (host pointers). */
+int cfnmpc_debug_get_linearisation(cfnmpc_solver *s, double *A, double *Bm, double *b);
 /* runs only the linearisation kernel */
 int cfnmpc_debug_linearise(cfnmpc_solver *s, void *stream);
 /* number of leading stages the last QP's interior-point sweeps covered, per instance [B] (host) */

@@ -25,8 +25,8 @@ def test_sim_and_linearisation_match_golden_model_vectors():
     row = np.zeros(17); row[3] = 1
     s.set_x0(m["x"]); s.set_yref(np.tile(row, (n, N, 1)), np.tile(row[:13], (n, 1))); s.set_iterate(xit, uit)
     s.linearise_only()
-    for form in (0, 1):
-        A, B, b = s.get_linearisation(form)
+    for _rep in (0,):
+        A, B, b = s.get_linearisation()
         for k in (0, 17, 49):
             assert np.abs(A[:, k] - m["A"]).max() < 1e-13       # sympy-Jacobian sensitivities
             assert np.abs(B[:, k] - m["B"]).max() < 1e-13

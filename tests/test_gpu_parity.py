@@ -42,8 +42,8 @@ def test_linearisation_matches_oracle(oracle, cref, B):
     s.set_x0(x0); s.set_yref(yref, yref_e); s.set_iterate(xit, uit)
     s.linearise_only()
     opts = cref.default_opts()
-    for form in (0, 1):   # row-distributed (AR, BR) and column-distributed (AC, BC) copies
-        A, Bm, b = s.get_linearisation(form)
+    for _rep in (0,):
+        A, Bm, b = s.get_linearisation()
         for i in list(range(min(B, 6))) + [B - 1]:
             Ar, Br, br, _q, _r = cref.linearise(opts, xit[i].copy(), uit[i].copy(), x0[i].copy(), yref[i].copy(), yref_e[i].copy())
             assert np.abs(A[i] - Ar).max() < 1e-12   # FP64, same RK4+VDE arithmetic up to association
