@@ -161,89 +161,145 @@ __device__ __forceinline__ double pick(const double (&a)[N], int idx) {
 // =============================================================================================
 // linearisation
 // =============================================================================================
-__global__ __launch_bounds__(64) void k_linearise(Params P) {
-    __shared__ double tile[4][13 * 17 + 3];  // [instance][row r (internal)][17 columns: 13 x + 4 u]
-    const Lane t = lane_id(P);
-    const double h = P.dt;
-    // this lane's sensitivity column: lanes 3..12 -> state column (internal index = lane),
-    // lanes 0,1,2,13 -> input columns 0,1,2,3; lanes 14,15 idle.  (p columns are unit vectors.)
-    const bool is_x = t.L >= 3 && t.L < 13;
-    const bool is_u = t.L < 3 || t.L == 13;
-    const int ucol = t.L == 13 ? 3 : t.L;
-    const int xcol_ext = ext_of(is_x ? t.L : 3);
-    const int tcol = is_x ? t.L : 13 + ucol;  // column in the LDS tile
-    double* tl_ = tile[t.row];
+// One sensitivity column through the four RK stages (HQ / HW: its q- / w-part can be non-zero;
+// IS_U: input column, driven by df/du).  Column-type sparsity is exploited at compile time
+// because all 64 lanes (= 64 instances) integrate the SAME column.
+template <bool HQ, bool HW, bool IS_U>
+__device__ __forceinline__ void sens_column(const JacPoint (&J)[4], const double* __restrict__ u, int c, double h,
+                                            double* __restrict__ col) {
+    double s0[13], s[13], k1[13], k2[13], k3[13], k4[13], ju[4] = {0, 0, 0, 0};
+    SFOR(i, 0, 13, { s0[i] = (!IS_U && i == c) ? 1.0 : 0.0; });
+    if (IS_U) {
+        const double uc = 2.0 * (c == 0 ? u[0] : (c == 1 ? u[1] : (c == 2 ? u[2] : u[3])));
+        const double sa = (c < 2) ? 1.0 : -1.0;             // w1 w2 | -w3 -w4
+        const double sb = (c == 0 || c == 3) ? 1.0 : -1.0;  // w1 -w2 -w3 w4
+        const double sc_ = (c == 0 || c == 2) ? 1.0 : -1.0; // w1 -w2 w3 -w4
+        ju[0] = KT * uc; ju[1] = KA * sa * uc; ju[2] = KB * sb * uc; ju[3] = KC * sc_ * uc;
+    }
+    jvp<HQ, HW>(J[0], s0, k1);
+    SFOR(i, 0, 4, { k1[9 + i] += ju[i]; });
+    SFOR(i, 0, 13, { s[i] = s0[i] + 0.5 * h * k1[i]; });
+    jvp<HQ, HW>(J[1], s, k2);
+    SFOR(i, 0, 4, { k2[9 + i] += ju[i]; });
+    SFOR(i, 0, 13, { s[i] = s0[i] + 0.5 * h * k2[i]; });
+    jvp<HQ, HW>(J[2], s, k3);
+    SFOR(i, 0, 4, { k3[9 + i] += ju[i]; });
+    SFOR(i, 0, 13, { s[i] = s0[i] + h * k3[i]; });
+    jvp<HQ, HW>(J[3], s, k4);
+    SFOR(i, 0, 4, { k4[9 + i] += ju[i]; });
+    SFOR(i, 0, 13, { col[i] = s0[i] + (h / 6.0) * (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]); });
+}
 
-    for (int k = 0; k < P.N; k++) {
-        // every lane of the row holds the full (x_k, u_k) in EXTERNAL order (model code order)
-        double x[13], u[4], xt[13], kk[13], cc[13], s[13], aphi[13], acol[13], ju[4] = {0, 0, 0, 0};
-        const gdouble* xb = blk(P.xit, t, P.N + 1, k, SZ_V13);
-        SFOR(e, 0, 13, { x[e] = xb[t.q * 13 + int_of(e)]; });
-        SFOR(a, 0, 4, { u[a] = gm(P.uit)[i4(P, t, k, a)]; });
-        if (is_u) {
-            const double uc = 2.0 * pick(u, ucol);
-            const double sa = (ucol < 2) ? 1.0 : -1.0;
-            const double sb = (ucol == 0 || ucol == 3) ? 1.0 : -1.0;
-            const double sc = (ucol == 0 || ucol == 2) ? 1.0 : -1.0;
-            ju[0] = KT * uc; ju[1] = KA * sa * uc; ju[2] = KB * sb * uc; ju[3] = KC * sc * uc;
+// Lane-per-instance (work-efficient: nothing is computed twice); one workgroup = one wavefront
+// = 64 instances = 16 workspace blocks.  All traffic to the wave-blocked layout goes through
+// LDS tiles so that every global load / store instruction covers contiguous runs.
+__global__ __launch_bounds__(64) void k_linearise(Params P) {
+    __shared__ double sx[16 * 52];       // one 13-vector per instance, [block][q][13] (internal order)
+    __shared__ double sc[4][64 * 13];    // up to four sensitivity columns, [inst][row] (internal order)
+    const int tid = threadIdx.x;
+    const int w0 = blockIdx.x * 16;      // first workspace block of this workgroup
+    const int nblk = min(16, P.NW - w0); // valid blocks
+    const int inst = blockIdx.x * 64 + tid;
+    const double h = P.dt;
+    const int N = P.N;
+
+    // cooperative load of one 13-vector field block row (stage k of xit) into sx
+    auto load_x = [&](int k) {
+        for (int e = tid; e < nblk * 52; e += 64) {
+            const int bk = e / 52, off = e - bk * 52;
+            sx[e] = gm(P.xit)[((size_t)(w0 + bk) * (N + 1) + k) * SZ_V13 + off];
         }
-        // the four RK stages, nominal trajectory and this lane's sensitivity column interleaved
-        // so that only one Jacobian point is live at a time
-        JacPoint J;
-        SFOR(e, 0, 13, { s[e] = (is_x && xcol_ext == e) ? 1.0 : 0.0; });
-        f_expl(x, u, kk);
-        jac_point(x, J);
-        jvp<true, true>(J, s, cc);
-        SFOR(i, 0, 4, { cc[9 + i] += ju[i]; });
-        SFOR(e, 0, 13, {
-            aphi[e] = kk[e]; acol[e] = cc[e];
-            xt[e] = x[e] + 0.5 * h * kk[e];
-            s[e] = ((is_x && xcol_ext == e) ? 1.0 : 0.0) + 0.5 * h * cc[e];
-        });
-        f_expl(xt, u, kk);
-        jac_point(xt, J);
-        jvp<true, true>(J, s, cc);
-        SFOR(i, 0, 4, { cc[9 + i] += ju[i]; });
-        SFOR(e, 0, 13, {
-            aphi[e] += 2 * kk[e]; acol[e] += 2 * cc[e];
-            xt[e] = x[e] + 0.5 * h * kk[e];
-            s[e] = ((is_x && xcol_ext == e) ? 1.0 : 0.0) + 0.5 * h * cc[e];
-        });
-        f_expl(xt, u, kk);
-        jac_point(xt, J);
-        jvp<true, true>(J, s, cc);
-        SFOR(i, 0, 4, { cc[9 + i] += ju[i]; });
-        SFOR(e, 0, 13, {
-            aphi[e] += 2 * kk[e]; acol[e] += 2 * cc[e];
-            xt[e] = x[e] + h * kk[e];
-            s[e] = ((is_x && xcol_ext == e) ? 1.0 : 0.0) + h * cc[e];
-        });
-        f_expl(xt, u, kk);
-        jac_point(xt, J);
-        jvp<true, true>(J, s, cc);
-        SFOR(i, 0, 4, { cc[9 + i] += ju[i]; });
-        double phi[13], col[13];  // col in internal row order
-        SFOR(e, 0, 13, { phi[e] = x[e] + (h / 6.0) * (aphi[e] + kk[e]); });
+    };
+    double xn[13];  // x_{k+1} in EXTERNAL order
+    load_x(0);
+    __syncthreads();
+    SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
+    for (int k = 0; k < N; k++) {
+        double x[13], u[4];
+        SFOR(e, 0, 13, { x[e] = xn[e]; });
+        {
+            const gdouble* up = gm(P.uit) + ((size_t)imin(inst, P.NW * 4 - 1) * N + k) * 4;
+            SFOR(a, 0, 4, { u[a] = up[a]; });
+        }
+        __syncthreads();
+        load_x(k + 1);
+        __syncthreads();
+        SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
+        // nominal RK4 (classic tableau, one step per interval)
+        double xt[13], k1[13], k2[13], k3[13], k4[13];
+        JacPoint J[4];
+        f_expl(x, u, k1);
+        jac_point(x, J[0]);
+        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k1[e]; });
+        f_expl(xt, u, k2);
+        jac_point(xt, J[1]);
+        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k2[e]; });
+        f_expl(xt, u, k3);
+        jac_point(xt, J[2]);
+        SFOR(e, 0, 13, { xt[e] = x[e] + h * k3[e]; });
+        f_expl(xt, u, k4);
+        jac_point(xt, J[3]);
+        // b = Phi - x_{k+1} through the tile (internal order)
+        __syncthreads();
         SFOR(r, 0, 13, {
             constexpr int e = ext_of(r);
-            col[r] = ((is_x && xcol_ext == e) ? 1.0 : 0.0) + (h / 6.0) * (acol[e] + cc[e]);
+            const double phi = x[e] + (h / 6.0) * (k1[e] + 2 * k2[e] + 2 * k3[e] + k4[e]);
+            sc[0][tid * 13 + r] = phi - xn[e];
         });
-        // b = Phi - x_{k+1}, distributed (lane i <-> internal state i)
-        {
-            const double xn = ld13(blk(P.xit, t, P.N + 1, k + 1, SZ_V13), t);
-            const double ph = pick(phi, ext_of(t.L < 13 ? t.L : 0));
-            st13(blk(P.b, t, P.N, k, SZ_V13), t, ph - xn);
-        }
-        // row forms through the LDS tile
         __syncthreads();
-        if (is_x || is_u) SFOR(r, 0, 13, { tl_[r * 17 + tcol] = col[r]; });
-        __syncthreads();
-        {
-            gdouble* ar = blk(P.AR, t, P.N, k, SZ_A);
-            SFOR(sl, 0, 10, { if (t.L < ar_n(sl)) ar[4 * ar_pre(sl) + t.q * ar_n(sl) + t.L] = tl_[t.L * 17 + (sl + 3)]; });
-            gdouble* brb = blk(P.BR, t, P.N, k, SZ_B);
-            SFOR(a, 0, 4, { if (t.L < 13) brb[(a * 4 + t.q) * 13 + t.L] = tl_[t.L * 17 + 13 + a]; });
+        for (int e = tid; e < nblk * 52; e += 64) {
+            const int bk = e / 52, off = e - bk * 52;
+            gm(P.b)[((size_t)(w0 + bk) * N + k) * SZ_V13 + off] = sc[0][e];
         }
+        // store `cnt` rows of column tile `ti` into AR slot `sl` / BR column `a`
+        auto store_ar = [&](int ti, int sl, int n_s, int pre) {
+            for (int e = tid; e < nblk * 4 * n_s; e += 64) {
+                const int bk = e / (4 * n_s), off = e - bk * 4 * n_s;
+                const int q = off / n_s, i = off - q * n_s;
+                gm(P.AR)[((size_t)(w0 + bk) * N + k) * SZ_A + 4 * pre + off] = sc[ti][(bk * 4 + q) * 13 + i];
+            }
+        };
+        auto store_br = [&](int ti, int a) {
+            for (int e = tid; e < nblk * 52; e += 64) {
+                const int bk = e / 52, off = e - bk * 52;
+                gm(P.BR)[((size_t)(w0 + bk) * N + k) * SZ_B + a * 52 + off] = sc[ti][e];
+            }
+        };
+        double col[13];
+        // state columns in internal order: v (internal 3..5 = external 7..9), q (6..9 = 3..6), w (10..12)
+        __syncthreads();
+        // (runtime loops on purpose: one column at a time keeps the register footprint small)
+#pragma unroll 1
+        for (int j = 0; j < 3; j++) {  // velocity columns: rows p, v
+            sens_column<false, false, false>(J, u, 7 + j, h, col);
+            SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
+        }
+        __syncthreads();
+        SFOR(j, 0, 3, { store_ar(j, j, ar_n(j), ar_pre(j)); });
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {  // quaternion columns: rows p, v, q
+            sens_column<true, false, false>(J, u, 3 + j, h, col);
+            SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
+        }
+        __syncthreads();
+        SFOR(j, 0, 4, { store_ar(j, 3 + j, ar_n(3 + j), ar_pre(3 + j)); });
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < 3; j++) {  // rate columns: all rows
+            sens_column<true, true, false>(J, u, 10 + j, h, col);
+            SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
+        }
+        __syncthreads();
+        SFOR(j, 0, 3, { store_ar(j, 7 + j, ar_n(7 + j), ar_pre(7 + j)); });
+        __syncthreads();
+#pragma unroll 1
+        for (int a = 0; a < 4; a++) {  // input columns: all rows
+            sens_column<true, true, true>(J, u, a, h, col);
+            SFOR(r, 0, 13, { sc[a][tid * 13 + r] = col[ext_of(r)]; });
+        }
+        __syncthreads();
+        SFOR(a, 0, 4, { store_br(a, a); });
     }
 }
 
@@ -756,7 +812,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
     const bool infeasible = t.valid && (viol > 0.0);
     RowIPM R;
 
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < 3; attempt++) {
         R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
         if (infeasible) {
             // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
@@ -884,7 +940,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
 
         // ---- expand: dynamics-exact roll-out; head stages use the QP inputs, tail stages the
         //      unconstrained feedback law of the start solve, whose inputs must stay inside the box
-        bool tail_ok = true;
+        int kviol = -1;  // last tail stage whose feedback input leaves the box
         {
             double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
             FwdIn<true> cur, nxt;
@@ -902,7 +958,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                 } else {
                     v = feedback<true>(t, cur, x);
                     if (t.L < 4) {
-                        tail_ok = tail_ok && (v >= P.u_min - ucur) && (v <= P.u_max - ucur);
+                        if (!((v >= P.u_min - ucur) && (v <= P.u_max - ucur))) kviol = k;
                         gm(P.v)[i4(P, t, k, t.L)] = v;
                     }
                 }
@@ -914,13 +970,19 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                 ucur = unxt;
             }
             st13(blk(P.dx, t, N + 1, N, SZ_V13), t, x);
-            tail_ok = row_min(tail_ok ? 1.0 : 0.0) > 0.0;
+            kviol = (int)row_max((double)kviol);
         }
-        const bool redo = t.valid && R.status != 4 && !tail_ok && head < N;
+        const bool redo = t.valid && R.status != 4 && kviol >= 0 && head < N;
         if (!__any(redo)) break;
-        // rare: a tail input left the box -> solve again over the full horizon (whole wave):
-        // the head stages' gains were overwritten by the delta sweeps, so redo the start solve
-        head = N; chk = -1;
+        // rare: a tail input left the box -> solve again (whole wave) over the smallest head class
+        // that covers the offending stage (+4), the full horizon as the last resort.  The head
+        // stages' gains were overwritten by the delta sweeps, so the start solve is redone.
+        int want = redo ? kviol + 5 : 0;
+        want = max(want, __shfl_xor(want, 16));
+        want = max(want, __shfl_xor(want, 32));
+        head = attempt == 0 ? max(head_class(P, want), head) : N;
+        chk = -1;
+        SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
         (void)sweep_factor<true>(P, t, N, -1, wt, sb);
         {
             double vv; int lt;
@@ -1027,7 +1089,7 @@ __global__ void k_init_iterate(Params P, int mode) {
 // launchers
 // ---------------------------------------------------------------------------------------------
 void launch_linearise(const Params& P, hipStream_t st) {
-    hipLaunchKernelGGL(k_linearise, dim3(P.NW), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(k_linearise, dim3((P.NW + 15) / 16), dim3(64), 0, st, P);
 }
 void launch_qp(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);

@@ -153,5 +153,6 @@ def test_ragged_batch_and_status(oracle, cref):
     xr = np.repeat(x0[:, None, :], 51, 1).copy(); ur = np.full((B, 50, 4), HOV)
     cref.rti_step(opts, xr, ur, x0.copy(), yref, yref_e, nthreads=0)
     xg, ug = s.get_iterate()
-    same = it > -1
-    assert np.abs(ug - ur).max() < 1e-5
+    # different central paths (active-horizon vs full-horizon sweeps) at the default tol 1e-8:
+    # agreement is bounded by ~sqrt(tol) for nearly degenerate bounds
+    assert np.abs(ug - ur).max() < 5e-4 and np.abs(xg - xr).max() < 5e-4
