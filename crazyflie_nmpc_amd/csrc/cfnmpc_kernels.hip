@@ -801,7 +801,6 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
     double* wt = wtile[t.row];
     double* sb = btile[t.row];
     const int N = P.N;
-    const size_t ibase = (size_t)t.inst * N * 4;  // this instance's 4-vectors
     // wave-uniform head = largest head class among the four rows
     int head = t.valid ? gm(P.head)[t.inst] : 0;
     head = max(head, __shfl_xor(head, 16));
@@ -810,25 +809,55 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
     SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
     const double viol = t.valid ? gm(P.viol)[t.inst] : 0.0;
     const bool infeasible = t.valid && (viol > 0.0);
+    // All interior-point sweeps run on a COMPACT copy of the head stages (row r of this wave =
+    // slot r of compact block blockIdx.x): the instance's own blocks are interleaved with three
+    // unrelated instances, which would waste 3/4 of every cache line on every sweep of every
+    // iteration.  The start solve's gains / inputs in P stay untouched until the QP is accepted.
+    Lane tc = t;
+    tc.wave = blockIdx.x; tc.q = t.row; tc.inst = blockIdx.x * 4 + t.row;
+    Params Q = P;
+    Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
+    const size_t cbase = (size_t)tc.inst * N * 4;  // compact 4-vectors of this row
+    auto gather = [&](int hd, int ck) {
+        for (int k = 0; k < hd; k++) {
+            double ar[10], br[4];
+            ld_ar(blk(P.AR, t, N, k, SZ_A), t, ar);
+            ld_rows4(blk(P.BR, t, N, k, SZ_B), t, br);
+            gdouble* ca = blk(Q.AR, tc, N, k, SZ_A);
+            SFOR(sl, 0, 10, { if (t.L < ar_n(sl)) ca[4 * ar_pre(sl) + tc.q * ar_n(sl) + t.L] = ar[sl]; });
+            gdouble* cb = blk(Q.BR, tc, N, k, SZ_B);
+            SFOR(a, 0, 4, { if (t.L < 13) cb[(a * 4 + tc.q) * 13 + t.L] = br[a]; });
+            if (t.L < 4) {
+                gm(Q.v)[i4(Q, tc, k, t.L)] = gm(P.v)[i4(P, t, k, t.L)];
+                gm(Q.uit)[i4(Q, tc, k, t.L)] = gm(P.uit)[i4(P, t, k, t.L)];
+            }
+        }
+        if (ck >= 0) {
+            const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + ck) * SZ_P;
+            gdouble* qc = gm(Q.Pchk) + ((size_t)tc.wave * N_CHK + ck) * SZ_P;
+            SFOR(j, 0, 13, { if (t.L < 13) qc[(j * 4 + tc.q) * 13 + t.L] = pc[(j * 4 + t.q) * 13 + t.L]; });
+        }
+    };
     RowIPM R;
 
     for (int attempt = 0; attempt < 3; attempt++) {
         R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
+        gather(head, chk);
         if (infeasible) {
             // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
             const double mu0 = fmax(viol, P.lam0_min);
             double mu = 0.0, res = 0.0;
             for (int e = t.L; e < head * 4; e += 16) {
-                const size_t idx = ibase + e;
-                const double uk = gm(P.uit)[idx], v = gm(P.v)[idx];
+                const size_t idx = cbase + e;
+                const double uk = gm(Q.uit)[idx], v = gm(Q.v)[idx];
                 const double lb = P.u_min - uk, ub = P.u_max - uk;
                 const double tl = fmax(v - lb, P.thr0), tu = fmax(ub - v, P.thr0);
                 const double ll = mu0 / tl, lu = mu0 / tu, rg = -ll + lu;
-                gm(P.tl)[idx] = tl; gm(P.tu)[idx] = tu; gm(P.ll)[idx] = ll; gm(P.lu)[idx] = lu; gm(P.rg)[idx] = rg;
+                gm(Q.tl)[idx] = tl; gm(Q.tu)[idx] = tu; gm(Q.ll)[idx] = ll; gm(Q.lu)[idx] = lu; gm(Q.rg)[idx] = rg;
                 const double rl = v - lb - tl, ru = ub - v - tu;
                 const double Dl = ll / tl, Du = lu / tu;
-                gm(P.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
-                gm(P.g)[idx] = rg + ll + Dl * rl - lu - Du * ru;
+                gm(Q.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
+                gm(Q.g)[idx] = rg + ll + Dl * rl - lu - Du * ru;
                 mu += ll * tl + lu * tu;
                 res = fmax(res, fmax(fmax(ll * tl, lu * tu), fmax(fabs(rg), fmax(fabs(rl), fabs(ru)))));
             }
@@ -848,15 +877,15 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             if (!__any(R.act)) break;
             if (R.act) R.iters++;
             // predictor: factorise (R^, g from the element-wise pass), forward
-            const bool fok = sweep_factor<false>(P, t, head, chk, wt, sb);
-            sweep_forward_delta(P, t, head, gm(P.dva));
+            const bool fok = sweep_factor<false>(Q, tc, head, chk, wt, sb);
+            sweep_forward_delta(Q, tc, head, gm(Q.dva));
             // affine step length, mu_aff, centering; corrector right-hand side
             double smu;
             {
                 double a = 1.0;
                 for (int e = t.L; e < head * 4; e += 16) {
-                    const Elem el = ld_elem(P, t, ibase + e);
-                    const double dva = gm(P.dva)[ibase + e];
+                    const Elem el = ld_elem(Q, tc, cbase + e);
+                    const double dva = gm(Q.dva)[cbase + e];
                     const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
                     const double dtl = dva + rl, dtu = -dva + ru;
                     const double dll = -el.ll - (el.ll / el.tl) * dtl, dlu = -el.lu - (el.lu / el.tu) * dtu;
@@ -866,8 +895,8 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                 a = row_min(a);
                 double mu_aff = 0.0;
                 for (int e = t.L; e < head * 4; e += 16) {
-                    const Elem el = ld_elem(P, t, ibase + e);
-                    const double dva = gm(P.dva)[ibase + e];
+                    const Elem el = ld_elem(Q, tc, cbase + e);
+                    const double dva = gm(Q.dva)[cbase + e];
                     const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
                     const double dtl = dva + rl, dtu = -dva + ru;
                     const double dll = -el.ll - (el.ll / el.tl) * dtl, dlu = -el.lu - (el.lu / el.tu) * dtu;
@@ -877,24 +906,24 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                 const double sr = mu_aff / R.mu;
                 smu = sr * sr * sr * R.mu;
                 for (int e = t.L; e < head * 4; e += 16) {
-                    const Elem el = ld_elem(P, t, ibase + e);
-                    const double dva = gm(P.dva)[ibase + e];
+                    const Elem el = ld_elem(Q, tc, cbase + e);
+                    const double dva = gm(Q.dva)[cbase + e];
                     const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
                     const double dtl = dva + rl, dtu = -dva + ru;
                     const double dll = -el.ll - (el.ll / el.tl) * dtl, dlu = -el.lu - (el.lu / el.tu) * dtu;
                     const double cl = dll * dtl, cu = dlu * dtu;
-                    gm(P.g)[ibase + e] = (cl - smu) / el.tl - (cu - smu) / el.tu;
+                    gm(Q.g)[cbase + e] = (cl - smu) / el.tl - (cu - smu) / el.tu;
                 }
             }
             // corrector: re-solve, forward
-            sweep_resolve(P, t, head);
-            sweep_forward_delta(P, t, head, gm(P.dvc));
+            sweep_resolve(Q, tc, head);
+            sweep_forward_delta(Q, tc, head, gm(Q.dvc));
             // step, update, residuals of the new point, next R^ and g
             {
                 double a = 1.0;
                 for (int e = t.L; e < head * 4; e += 16) {
-                    const Elem el = ld_elem(P, t, ibase + e);
-                    const double dva = gm(P.dva)[ibase + e], dv = dva + gm(P.dvc)[ibase + e];
+                    const Elem el = ld_elem(Q, tc, cbase + e);
+                    const double dva = gm(Q.dva)[cbase + e], dv = dva + gm(Q.dvc)[cbase + e];
                     const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
                     const double dtla = dva + rl, dtua = -dva + ru;
                     const double Dl = el.ll / el.tl, Du = el.lu / el.tu;
@@ -907,9 +936,9 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                 a = fmin(1.0, P.tau * row_min(a));
                 double mu = 0.0, res = 0.0;
                 for (int e = t.L; e < head * 4; e += 16) {
-                    const size_t idx = ibase + e;
-                    const Elem el = ld_elem(P, t, idx);
-                    const double dva = gm(P.dva)[idx], dv = dva + gm(P.dvc)[idx];
+                    const size_t idx = cbase + e;
+                    const Elem el = ld_elem(Q, tc, idx);
+                    const double dva = gm(Q.dva)[idx], dv = dva + gm(Q.dvc)[idx];
                     const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
                     const double dtla = dva + rl, dtua = -dva + ru;
                     const double Dl0 = el.ll / el.tl, Du0 = el.lu / el.tu;
@@ -921,9 +950,9 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                     const double rln = v - el.lb - tl, run = el.ub - v - tu;
                     const double Dl = ll / tl, Du = lu / tu;
                     if (R.act) {
-                        gm(P.v)[idx] = v; gm(P.tl)[idx] = tl; gm(P.tu)[idx] = tu; gm(P.ll)[idx] = ll; gm(P.lu)[idx] = lu; gm(P.rg)[idx] = rg;
-                        gm(P.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
-                        gm(P.g)[idx] = rg + ll + Dl * rln - lu - Du * run;
+                        gm(Q.v)[idx] = v; gm(Q.tl)[idx] = tl; gm(Q.tu)[idx] = tu; gm(Q.ll)[idx] = ll; gm(Q.lu)[idx] = lu; gm(Q.rg)[idx] = rg;
+                        gm(Q.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
+                        gm(Q.g)[idx] = rg + ll + Dl * rln - lu - Du * run;
                     }
                     mu += ll * tl + lu * tu;
                     res = fmax(res, fmax(fmax(ll * tl, lu * tu), fmax(fabs(rg), fmax(fabs(rln), fabs(run)))));
@@ -945,11 +974,11 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
             FwdIn<true> cur, nxt;
             load_fwd<true>(P, t, 0, cur);
-            double vcur = gm(P.v)[i4(P, t, 0, t.L & 3)], ucur = gm(P.uit)[i4(P, t, 0, t.L & 3)], vnxt, unxt;
+            double vcur = gm(Q.v)[i4(Q, tc, 0, t.L & 3)], ucur = gm(P.uit)[i4(P, t, 0, t.L & 3)], vnxt, unxt;
             for (int k = 0; k < N; k++) {
                 const int kn = imin(k + 1, N - 1);
                 load_fwd<true>(P, t, kn, nxt);  // prefetch
-                vnxt = gm(P.v)[i4(P, t, kn, t.L & 3)];
+                vnxt = gm(Q.v)[i4(Q, tc, imin(kn, head - 1), t.L & 3)];
                 unxt = gm(P.uit)[i4(P, t, kn, t.L & 3)];
                 st13(blk(P.dx, t, N + 1, k, SZ_V13), t, x);
                 double v;
@@ -957,11 +986,10 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                     v = t.L < 4 ? vcur : 0.0;
                 } else {
                     v = feedback<true>(t, cur, x);
-                    if (t.L < 4) {
-                        if (!((v >= P.u_min - ucur) && (v <= P.u_max - ucur))) kviol = k;
-                        gm(P.v)[i4(P, t, k, t.L)] = v;
-                    }
+                    if (t.L < 4 && !((v >= P.u_min - ucur) && (v <= P.u_max - ucur))) kviol = k;
                 }
+                // candidate inputs of the whole horizon (P.v keeps the unconstrained ones until accepted)
+                if (t.L < 4) gm(Q.dva)[i4(Q, tc, k, t.L)] = v;
                 double vr[4];
                 SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
                 x = propagate<true>(t, cur, x, vr);
@@ -975,20 +1003,18 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         const bool redo = t.valid && R.status != 4 && kviol >= 0 && head < N;
         if (!__any(redo)) break;
         // rare: a tail input left the box -> solve again (whole wave) over the smallest head class
-        // that covers the offending stage (+4), the full horizon as the last resort.  The head
-        // stages' gains were overwritten by the delta sweeps, so the start solve is redone.
+        // that covers the offending stage (+4), the full horizon as the last resort.  Nothing of
+        // the start solve was touched (the sweeps work on the compact copy), so just re-gather.
         int want = redo ? kviol + 5 : 0;
         want = max(want, __shfl_xor(want, 16));
         want = max(want, __shfl_xor(want, 32));
         head = attempt == 0 ? max(head_class(P, want), head) : N;
         chk = -1;
         SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
-        (void)sweep_factor<true>(P, t, N, -1, wt, sb);
-        {
-            double vv; int lt;
-            start_forward(P, t, vv, lt);
-        }
     }
+    // accepted: publish the inputs of the whole horizon
+    if (t.valid && t.L < 4)
+        for (int k = 0; k < N; k++) gm(P.v)[i4(P, t, k, t.L)] = gm(Q.dva)[i4(Q, tc, k, t.L)];
     if (t.L == 0 && infeasible) {
         gm(P.status)[t.inst] = R.status;
         gm(P.iters)[t.inst] = R.iters;

@@ -74,6 +74,8 @@ struct Params {
     // interior-point state, N x SZ_V4 each
     double *v, *tl, *tu, *ll, *lu, *rg, *dva, *dvc, *Rh, *g;
     double *dx;  // (N+1) x SZ_V13: step in x of the accepted QP solution (commit buffer)
+    // compact scratch of the interior-point kernel (same block shapes, indexed by compacted slot)
+    double *cAR, *cBR, *cKR, *cSinv, *cd, *cPchk, *cv, *cuit;
     int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
     double *res, *viol;          // per instance
     int *ilist;                  // compacted list of the instances that need the interior-point method
