@@ -39,6 +39,13 @@ def lib():
             f"{LIB_PATH} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C crazyflie_nmpc_amd/csrc). "
             "crazyflie_nmpc_amd has no CPU fallback.")
+    # PyTorch wheels bundle their own HIP runtime (same soname as /opt/rocm's).  If this library
+    # initialised HIP first, a later `import torch` would bring up a second runtime instance and
+    # find no GPU; loading torch first makes both share one instance (torch is plumbing only).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch absent: the library runs on the system ROCm runtime alone
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ip, dbl, i32 = C.c_void_p, C.c_int, C.c_double, C.c_int
     L.cfnmpc_default_opts.argtypes = [C.POINTER(Opts)]

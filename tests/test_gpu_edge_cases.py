@@ -1,0 +1,149 @@
+"""GPU suite: horizons other than 50 (config C5: N in {30, 50, 100}), tiny and ragged batches,
+error paths (status codes of SURVEY.md section 8b), setters / getters of the batch C-ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HOV = 15.777730167256925
+
+
+def _inputs(oracle, B, N, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    x0 = oracle.sample_hover_x0(rng, B, scale=scale)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    return x0, np.repeat(yr[None], B, 0).copy(), np.repeat(ye[None], B, 0).copy()
+
+
+@pytest.mark.parametrize("N", [30, 100])
+@pytest.mark.parametrize("active_horizon", [0, 1])
+def test_other_horizons_match_oracle(oracle, cref, N, active_horizon):
+    """Mixed-horizon config C5 runs one solver object per horizon bucket; each bucket must agree
+    with the CPU restatement (dt stays 15 ms, Tf = 0.015 N)."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B = 37
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=11 + N, scale=1.5)
+    tol = 1e-11
+    s = BatchSolver(B, default_opts(N=N, tol=tol, active_horizon=active_horizon))
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    opts = cref.default_opts(N=N, tol=tol)
+    xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    x = x0.copy()
+    nipm = 0
+    for t in range(4):
+        s.set_x0(x); s.solve(1)
+        st, it, _ = s.stats()
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        xg, ug = s.get_iterate()
+        assert (st == 0).all() and (st_r == 0).all()
+        assert np.abs(ug - ur).max() < 1e-8 and np.abs(xg - xr).max() < 1e-8, (N, t)
+        nipm += int((it > 0).sum())
+        x = sim(x, s.get_u(0), T=0.015, steps=1)
+        ur[:] = ug; xr[:] = xg
+    assert nipm > 0
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 64, 65])
+def test_tiny_and_ragged_batches(oracle, cref, B):
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    N = 50
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=100 + B, scale=2.0)
+    s = BatchSolver(B, default_opts(active_horizon=0))
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    s.solve(1)
+    xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    st_r, it_r, _, _ = cref.rti_step(cref.default_opts(), xr, ur, x0.copy(), yref, yref_e, nthreads=0)
+    st, it, _ = s.stats()
+    xg, ug = s.get_iterate()
+    assert (st == 0).all() and (np.abs(it - it_r) <= 1).all()
+    assert np.abs(ug - ur).max() < 1e-6 and np.abs(xg - xr).max() < 1e-6
+
+
+def test_iteration_cap_and_nan_status(oracle):
+    """status 2 (max. iterations) and 4 (QP failure), never a silent bad control: a failed
+    instance keeps its iterate, healthy instances in the same wave are unaffected."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 8, 50
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=5, scale=3.0)
+    s = BatchSolver(B, default_opts(max_iter=2))
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    s.solve(1)
+    st, it, rs = s.stats()
+    assert set(np.unique(st)) <= {0, 2} and (st == 2).any() and it.max() <= 2
+    assert (rs[st == 2] > 1e-8).all()
+    # NaN in one instance's measurement
+    s2 = BatchSolver(B)
+    x0b = x0.copy(); x0b[5, 2] = np.nan
+    s2.set_x0(x0b); s2.set_yref(yref, yref_e); s2.init_iterate(INIT_HOVER)
+    xi, ui = s2.get_iterate()
+    s2.solve(1)
+    st, it, rs = s2.stats()
+    assert st[5] == 4 and (np.delete(st, 5) == 0).all()
+    xo, uo = s2.get_iterate()
+    bad_x, bad_u = xo[5], uo[5]
+    assert np.array_equal(np.isnan(bad_x), np.isnan(xi[5])) and np.array_equal(bad_u, ui[5])   # iterate kept
+    s3 = BatchSolver(B)
+    s3.set_x0(x0); s3.set_yref(yref, yref_e); s3.init_iterate(INIT_HOVER); s3.solve(1)
+    x3, u3 = s3.get_iterate()
+    ok = np.arange(B) != 5
+    assert np.abs(uo[ok] - u3[ok]).max() == 0.0            # neighbours in the same wave untouched
+
+
+def test_setters_getters_and_weights(oracle, cref):
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import CfnmpcError
+    B, N = 6, 50
+    rng = np.random.default_rng(3)
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=8, scale=0.5)
+    s = BatchSolver(B)
+    xi = rng.standard_normal((B, N + 1, 13)); ui = rng.uniform(1, 20, (B, N, 4))
+    s.set_iterate(xi, ui)
+    xo, uo = s.get_iterate()
+    assert np.array_equal(xi, xo) and np.array_equal(ui, uo)          # layout round trip is exact
+    for k in (0, 7, 49):
+        assert np.array_equal(s.get_u(k), ui[:, k]) and np.array_equal(s.get_x(k), xi[:, k])
+    assert np.array_equal(s.get_x(N), xi[:, N])
+    with pytest.raises(CfnmpcError):
+        s.get_u(N)
+    # weights: W / WN scaled -> same result as the oracle with the same weights
+    W = np.array(list(default_opts().W)) * 2.0; WN = np.array(list(default_opts().WN)) * 0.5
+    s.set_weights(W, WN)
+    s.set_x0(x0); s.set_yref(yref, yref_e)
+    xit = np.repeat(x0[:, None, :], N + 1, 1).copy(); uit = np.full((B, N, 4), HOV)
+    s.set_iterate(xit, uit); s.solve(1)
+    opts = cref.default_opts()
+    for i in range(17):
+        opts.W[i] = W[i]
+    for i in range(13):
+        opts.WN[i] = WN[i]
+    cref.rti_step(opts, xit, uit, x0.copy(), yref, yref_e, nthreads=0)
+    xg, ug = s.get_iterate()
+    assert np.abs(ug - uit).max() < 1e-5 and np.abs(xg - xit).max() < 1e-5
+    with pytest.raises(CfnmpcError):
+        s.set_weights(np.zeros(17), None)
+
+
+def test_device_pointers_and_repeated_solves(oracle):
+    """torch device tensors go straight through the C-ABI (no host copies); n_rti > 1 equals
+    repeated single steps."""
+    import torch
+    from crazyflie_nmpc_amd import BatchSolver
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 40, 50
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=21)
+    dev = torch.device("cuda", 0)
+    a = BatchSolver(B); b = BatchSolver(B)
+    a.set_x0(torch.from_numpy(x0).to(dev)); a.set_yref(torch.from_numpy(yref).to(dev), torch.from_numpy(yref_e).to(dev))
+    b.set_x0(x0); b.set_yref(yref, yref_e)
+    a.init_iterate(INIT_HOVER); b.init_iterate(INIT_HOVER)
+    a.solve(3)
+    for _ in range(3):
+        b.solve(1)
+    u_dev = torch.empty((B, 4), dtype=torch.float64, device=dev)
+    a.get_u(0, out=u_dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(u_dev.cpu().numpy(), b.get_u(0))
+    xa, ua = a.get_iterate(); xb, ub = b.get_iterate()
+    assert np.array_equal(xa, xb) and np.array_equal(ua, ub)
