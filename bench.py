@@ -100,7 +100,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--active-horizon", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--ah-margin", type=float, default=None)
+    ap.add_argument("--ah-extra", type=int, default=None)
+    ap.add_argument("--streams", type=int, default=1,
                     help="sub-batches per GPU, each with its own solver object and HIP stream (overlaps the "
                          "latency-bound interior-point tail of one shard with the streaming kernels of the others)")
     args = ap.parse_args()
@@ -145,7 +147,12 @@ def main():
             self.u0 = torch.empty((n, 4), dtype=torch.float64, device=dev)
             self.cohort = (n + KICK_PERIOD - 1) // KICK_PERIOD
             self.kicks = torch.from_numpy(sample_x0(rng, self.cohort * KICK_PERIOD).reshape(KICK_PERIOD, self.cohort, 13)).to(dev)
-            self.solver = BatchSolver(n, default_opts(active_horizon=args.active_horizon))
+            kw = dict(active_horizon=args.active_horizon)
+            if args.ah_margin is not None:
+                kw["ah_margin"] = args.ah_margin
+            if args.ah_extra is not None:
+                kw["ah_extra"] = args.ah_extra
+            self.solver = BatchSolver(n, default_opts(**kw))
             yref = torch.from_numpy(np.tile(row, (n, N, 1))).to(dev)
             yref_e = torch.from_numpy(np.tile(row[:13], (n, 1))).to(dev)
             self.solver.set_x0(self.x)

@@ -107,13 +107,16 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->thr0 = 1.0;
     o->lam0_min = 1e-2;
     o->active_horizon = 1;
+    o->ah_margin = 0.10;
+    o->ah_extra = 4;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     if (!out || batch <= 0) return CFNMPC_EINVAL;
     cfnmpc_opts o;
     if (opts) o = *opts; else cfnmpc_default_opts(&o);
-    if (o.N < 5 || o.N > 4096 || !(o.dt > 0) || !(o.u_max > o.u_min) || o.max_iter < 0) return CFNMPC_EINVAL;
+    if (o.N < 5 || o.N > 4096 || !(o.dt > 0) || !(o.u_max > o.u_min) || o.max_iter < 0 ||
+        !(o.ah_margin >= 0.0 && o.ah_margin < 0.5) || o.ah_extra < 0) return CFNMPC_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         std::fprintf(stderr, "cfnmpc: no HIP device available (this library has no CPU path)\n");
@@ -136,6 +139,8 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.u_min = o.u_min; P.u_max = o.u_max; P.tol = o.tol; P.tau = o.tau; P.thr0 = o.thr0;
     P.lam0_min = o.lam0_min; P.max_iter = o.max_iter;
     P.active_horizon = o.active_horizon ? 1 : 0;
+    P.ah_margin = o.ah_margin;
+    P.ah_extra = o.ah_extra;
     // one spare workspace block (index P.NW) parks the idle rows of compacted interior-point waves
     const size_t NW = P.NW + 1, N = P.N;
     int rc = CFNMPC_OK;

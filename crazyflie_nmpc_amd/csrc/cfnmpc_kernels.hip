@@ -132,6 +132,17 @@ __device__ __forceinline__ void ld_ar(const gdouble* b, const Lane& t, double (&
         ar[s] = t.L < ar_n(s) ? v : 0.0;
     });
 }
+// Unmasked variants: for operands that are consumed ONLY as DPP broadcast sources (always read
+// from lanes inside the stored range) the out-of-range lanes may hold anything -- no selects.
+__device__ __forceinline__ void ld_ar_raw(const gdouble* b, const Lane& t, double (&ar)[10]) {
+    SFOR(s, 0, 10, { ar[s] = b[4 * ar_pre(s) + t.q * ar_n(s) + imin(t.L, ar_n(s) - 1)]; });
+}
+__device__ __forceinline__ void ld_rows4_raw(const gdouble* b, const Lane& t, double (&r)[4]) {
+    SFOR(a, 0, 4, { r[a] = b[(a * 4 + t.q) * 13 + imin(t.L, 12)]; });
+}
+__device__ __forceinline__ void ld_cols4_raw(const gdouble* b, const Lane& t, double (&c)[13]) {
+    SFOR(l, 0, 13, { c[l] = b[(l * 4 + t.q) * 4 + (t.L & 3)]; });
+}
 __device__ __forceinline__ void ld_rows4(const gdouble* b, const Lane& t, double (&r)[4]) {  // BR / KP
     SFOR(a, 0, 4, {
         const double v = b[(a * 4 + t.q) * 13 + imin(t.L, 12)];
@@ -306,6 +317,15 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
 // =============================================================================================
 // Riccati sweeps
 // =============================================================================================
+// 1/sqrt(s) to full double accuracy: hardware estimate + two Newton steps (no IEEE div / sqrt
+// sequences in the per-stage critical path)
+__device__ __forceinline__ double rsqrt_nr(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+    const double hs = 0.5 * s;
+    y = y * (1.5 - hs * y * y);
+    y = y * (1.5 - hs * y * y);
+    return y;
+}
 // symmetric positive definite 4x4 (packed upper) -> inverse (packed upper); false if not SPD
 __device__ __forceinline__ bool spd4_inv(const double (&S)[10], double (&Si)[10]) {
     double Lm[4][4], Li[4][4];
@@ -314,9 +334,8 @@ __device__ __forceinline__ bool spd4_inv(const double (&S)[10], double (&Si)[10]
         double s = S[s4(j, j)];
         SFOR(k, 0, j, { s -= Lm[j][k] * Lm[j][k]; });
         ok = ok && (s > 0.0);
-        const double ljj = sqrt(s);
-        const double inv = 1.0 / ljj;
-        Lm[j][j] = ljj;
+        const double inv = rsqrt_nr(s);   // 1 / L_jj
+        Lm[j][j] = s * inv;
         Li[j][j] = inv;
         SFOR(i, j + 1, 4, {
             double tt = S[s4(i, j)];
@@ -348,28 +367,27 @@ struct StageIn {
     double Rh, g;            // lanes a < 4: input Hessian diagonal / gradient element a
     double bv, qv;           // ABSOLUTE: b_k[i] and q_k[i] = Q_i (x_k[i] - yref_k[i]) in lane i
 };
+// wq: this lane's state weight Q_i (lane i < 13), computed once per kernel
 template <bool ABSOLUTE>
-__device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const int k, StageIn<ABSOLUTE>& in) {
-    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
-    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+__device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const int k, const double wq,
+                                           StageIn<ABSOLUTE>& in) {
+    ld_ar_raw(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
+    ld_rows4_raw(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
     const int a = t.L & 3;
     if (ABSOLUTE) {
         const double uk = gm(P.uit)[i4(P, t, k, a)];
         const gdouble* yb = blk(P.yref, t, P.N, k, SZ_Y);
         const double yr = yb[t.q * 17 + 13 + a];
         const double wa = w_u(P, a);
-        in.Rh = t.L < 4 ? wa : 0.0;
-        in.g = t.L < 4 ? wa * (uk - yr) : 0.0;
-        in.bv = ld13(blk(P.b, t, P.N, k, SZ_V13), t);
-        const double xk = ld13(blk(P.xit, t, P.N + 1, k, SZ_V13), t);
+        in.Rh = wa;                 // read in lanes a < 4 only
+        in.g = wa * (uk - yr);
+        in.bv = blk(P.b, t, P.N, k, SZ_V13)[t.q * 13 + imin(t.L, 12)];
+        const double xk = blk(P.xit, t, P.N + 1, k, SZ_V13)[t.q * 13 + imin(t.L, 12)];
         const double yk = yb[t.q * 17 + imin(t.L, 12)];
-        double qv = 0.0;
-        SFOR(j, 0, 13, { if (t.L == j) qv = P.W[ext_of(j)] * (xk - yk); });
-        in.qv = qv;
+        in.qv = wq * (xk - yk);     // q_k[i] in lane i < 13
     } else {
-        const double rh = gm(P.Rh)[i4(P, t, k, a)], gg = gm(P.g)[i4(P, t, k, a)];
-        in.Rh = t.L < 4 ? rh : 0.0;
-        in.g = t.L < 4 ? gg : 0.0;
+        in.Rh = gm(P.Rh)[i4(P, t, k, a)];
+        in.g = gm(P.g)[i4(P, t, k, a)];
         in.bv = 0.0;
         in.qv = 0.0;
     }
@@ -382,19 +400,15 @@ __device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const
 //   wt: LDS [13*17] (transpose of W), sb: LDS [4*16] (columns of B for lanes 0..3).
 template <bool ABSOLUTE>
 __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, const int k, double (&Pa)[13],
-                                             const StageIn<ABSOLUTE>& in, double* wt, double* sb) {
+                                             const StageIn<ABSOLUTE>& in, const double wq, const double is13,
+                                             double* wt, double* sb) {
     const double(&ar)[10] = in.ar;
     const double(&br)[4] = in.br;
     if (ABSOLUTE) {
         // hb' = p' + (P b)' in lane 13
         double pb = 0.0;
-        dotbc<13, 0>(pb, Pa, in.bv);
-        if (t.L >= 13) pb = 0.0;
-        settle(pb);
-        SFOR(j, 0, 13, {
-            const double add = bc<j>(pb);
-            if (t.L == 13) Pa[j] += add;
-        });
+        dotbc<13, 0>(pb, Pa, in.bv);          // lanes 0..12: (P b)[i]
+        SFOR(j, 0, 13, { dotbc<1, j>(Pa[j], &is13, pb); });   // lane 13: p'[j] += (P b)[j]
     }
     // (1) W = Pa A (row form, instruction-level sparsity of A), (2) V = Pa B
     double W[13], V[4];
@@ -418,20 +432,14 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         SFOR(a, 0, 4, { sb[a * 16 + t.L] = br[a]; });
     }
     __syncthreads();
-    SFOR(l, 0, 13, {
+    SFOR(l, 0, 13, {   // lanes 14, 15 carry don't-care values from here on (never broadcast)
         const double w = wt[imin(t.L, 12) * 17 + l];
-        Wt[l] = t.L < 13 ? w : (t.L == 13 ? Pa[l] : 0.0);
+        Wt[l] = t.L == 13 ? Pa[l] : w;
     });
     // (4) M = Q + Wt A  (lane 13: q_k' + hb'A)
     double M[13];
-    if (ABSOLUTE) {
-        SFOR(j, 0, 13, {
-            const double qj = bc<j>(in.qv);
-            M[j] = (t.L == j) ? P.W[ext_of(j)] : (t.L == 13 ? qj : 0.0);
-        });
-    } else {
-        SFOR(j, 0, 13, { M[j] = (t.L == j) ? P.W[ext_of(j)] : 0.0; });
-    }
+    SFOR(j, 0, 13, { M[j] = (t.L == j) ? wq : 0.0; });
+    if (ABSOLUTE) SFOR(j, 0, 13, { dotbc<1, j>(M[j], &is13, in.qv); });   // lane 13: += q_k[j]
     SFOR(j, 0, 3, { M[j] += Wt[j]; });
     dot2bc<6, 0>(M[3], M[4], Wt, ar[0], ar[1]);
     dotbc<6, 0>(M[5], Wt, ar[2]);
@@ -444,16 +452,10 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     SFOR(a, 0, 4, { Gp[a] = 0.0; });
     dot2bc<13, 0>(Gp[0], Gp[1], Wt, br[0], br[1]);
     dot2bc<13, 0>(Gp[2], Gp[3], Wt, br[2], br[3]);
-    SFOR(a, 0, 4, {
-        const double ga = bc<a>(in.g);
-        if (t.L == 13) Gp[a] += ga;
-    });
+    SFOR(a, 0, 4, { dotbc<1, a>(Gp[a], &is13, in.g); });   // lane 13: += g[a]
     // (6) S = R^ + B'V in lanes a < 4, replicated, inverted redundantly by every lane
-    double bcl[13];
-    SFOR(l, 0, 13, {
-        const double v = sb[(t.L & 3) * 16 + l];
-        bcl[l] = t.L < 4 ? v : 0.0;
-    });
+    double bcl[13];   // lanes >= 4 compute don't-care rows of S (never broadcast)
+    SFOR(l, 0, 13, { bcl[l] = sb[(t.L & 3) * 16 + l]; });
     double Srow[4];
     SFOR(c, 0, 4, { Srow[c] = (t.L == c) ? in.Rh : 0.0; });
     dot2bc<13, 0>(Srow[0], Srow[1], bcl, V[0], V[1]);
@@ -514,11 +516,11 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
         });
     }
     bool ok = true;
-    StageIn<ABSOLUTE> cur, nxt;
-    load_stage<ABSOLUTE>(P, t, head - 1, cur);
-    for (int k = head - 1; k >= 0; k--) {
-        load_stage<ABSOLUTE>(P, t, k > 0 ? k - 1 : 0, nxt);  // prefetch (k = 0: harmless reload)
-        ok = factor_stage<ABSOLUTE>(P, t, k, Pa, cur, wt, sb) && ok;
+    // per-lane constants: state weight of this lane's row, indicator of the affine row
+    double wq = 0.0;
+    SFOR(j, 0, 13, { if (t.L == j) wq = P.W[ext_of(j)]; });
+    const double is13 = t.L == 13 ? 1.0 : 0.0;
+    auto after = [&](int k) {
         if (ABSOLUTE) {
             // checkpoints of the unconstrained cost-to-go (matrix part only)
             SFOR(c, 0, N_CHK, {
@@ -528,7 +530,22 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
                 }
             });
         }
-        cur = nxt;
+    };
+    // two stage buffers used alternately (no hand-over copies): while stage k is computed from
+    // one, stage k-1 is being loaded into the other
+    StageIn<ABSOLUTE> bufA, bufB;
+    load_stage<ABSOLUTE>(P, t, head - 1, wq, bufA);
+    int k = head - 1;
+    while (k >= 0) {
+        load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufB);
+        ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufA, wq, is13, wt, sb) && ok;
+        after(k);
+        k--;
+        if (k < 0) break;
+        load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufA);
+        ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufB, wq, is13, wt, sb) && ok;
+        after(k);
+        k--;
     }
     return ok;
 }
@@ -591,9 +608,9 @@ struct ResIn {
     double ar[10], br[4], kr[13], g, sv[4];
 };
 __device__ __forceinline__ void load_res(const Params& P, const Lane& t, const int k, ResIn& in) {
-    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
-    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
-    ld_cols4(blk(P.KR, t, P.N, k, SZ_K), t, in.kr);
+    ld_ar_raw(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
+    ld_rows4_raw(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+    ld_cols4_raw(blk(P.KR, t, P.N, k, SZ_K), t, in.kr);
     const int a = t.L & 3;
     in.g = gm(P.g)[i4(P, t, k, a)];
     const gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S) + t.q * 10;
@@ -656,7 +673,7 @@ __global__ __launch_bounds__(64, 2) void k_factor(Params P) {
 // violation, per wave the head of the horizon the interior-point sweeps must cover (0: none).
 __device__ __forceinline__ void start_forward(const Params& P, const Lane& t, double& viol, int& last_tight) {
     const int N = P.N;
-    const double margin = 0.05 * (P.u_max - P.u_min);
+    const double margin = P.ah_margin * (P.u_max - P.u_min);
     bool sawnan = false;
     viol = 0.0;
     last_tight = -1;
@@ -714,7 +731,7 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         gm(P.status)[t.inst] = bad ? 4 : 0;
         gm(P.iters)[t.inst] = 0;
         gm(P.res)[t.inst] = bad ? nan("") : 0.0;
-        gm(P.head)[t.inst] = infeasible ? head_class(P, last_tight + 3) : 0;
+        gm(P.head)[t.inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
     }
 }
 

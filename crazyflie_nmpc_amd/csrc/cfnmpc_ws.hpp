@@ -56,6 +56,8 @@ struct Params {
     double u_min, u_max, tol, tau, thr0, lam0_min;
     int max_iter;
     int active_horizon;  // 1: interior-point sweeps only over the stages that can saturate
+    double ah_margin;    // ... 'tight' = within this fraction of the box width of a bound
+    int ah_extra;        // ... stages added behind the last tight stage
     // persistent iterate (acados nlp_out, acados_mpc.cpp:77) and per-step inputs
     double *xit;     // (N+1) stages x SZ_V13
     double *uit;     // N x SZ_V4

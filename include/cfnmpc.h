@@ -58,6 +58,9 @@ typedef struct cfnmpc_opts {
                             whose inputs can saturate; the unconstrained tail keeps its
                             Riccati feedback law and is verified afterwards (exact); 0 = all
                             N stages in every sweep (default 1)                              */
+    double ah_margin;    /* active horizon: an unconstrained input closer to a bound than this
+                            fraction of (u_max - u_min) counts as 'tight' (0.10)              */
+    int ah_extra;        /* active horizon: stages added after the last tight stage (4)       */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);
