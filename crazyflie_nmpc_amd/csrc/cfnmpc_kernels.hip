@@ -484,7 +484,7 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
             if (t.L < 13) kr[(t.L * 4 + t.q) * 4 + a] = Kp[a];
             if (t.L == 13) gm(P.d)[i4(P, t, k, a)] = Kp[a];
         });
-        if (t.L == 0) {
+        if (!ABSOLUTE && t.L == 0) {  // only the corrector of the interior-point iteration reads it
             gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S);
             SFOR(e, 0, 10, { sv[t.q * 10 + e] = Si[e]; });
         }
