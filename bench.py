@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--active-horizon", type=int, default=1)
+    ap.add_argument("--workload", choices=["hover", "figure8"], default="hover",
+                    help="hover = config C3 (the metric's configuration); figure8 = config C4 tracking with "
+                         "device-side reference windows")
     ap.add_argument("--ah-margin", type=float, default=None)
     ap.add_argument("--ah-extra", type=int, default=None)
     ap.add_argument("--streams", type=int, default=1,
@@ -153,10 +156,28 @@ def main():
             if args.ah_extra is not None:
                 kw["ah_extra"] = args.ah_extra
             self.solver = BatchSolver(n, default_opts(**kw))
-            yref = torch.from_numpy(np.tile(row, (n, N, 1))).to(dev)
-            yref_e = torch.from_numpy(np.tile(row[:13], (n, 1))).to(dev)
+            self.track = args.workload == "figure8"
+            if self.track:
+                # config C4: figure-8 reference synthesised from the reference's
+                # crazyflie_demo/scripts/figure8.csv (three laps + N+1 hold rows), per-instance phase
+                # offsets, z offset 0.5 m; windows are generated on the device every step
+                from crazyflie_nmpc_amd.trajectories import Figure8, figure8_reference
+                lap = figure8_reference(Figure8(np.load(os.path.join(ROOT, "crazyflie_nmpc_amd", "data", "figure8_coeffs.npy"))), z0=0.5, N=N)
+                lap1 = lap[:-(N + 1)]
+                self.traj = torch.from_numpy(np.concatenate([lap1, lap1, lap1, lap[-(N + 1):]])).to(dev)
+                self.it = torch.from_numpy(rng.integers(0, 436, n).astype(np.int32)).to(dev)
+                self.mode = torch.ones(n, dtype=torch.int32, device=dev)
+                self.des = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+                hover = torch.tensor([0, 0, 0.4, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0], dtype=torch.float64, device=dev)
+                self.pert = 0.3 * (self.kicks - hover)            # perturbations around the reference row
+                self.x = self.traj[self.it.long(), :13] + 0.3 * (self.x - hover)
+                self.x[:, 3:7] /= torch.linalg.norm(self.x[:, 3:7], dim=1, keepdim=True)
+                self.solver.set_yref_windows(self.traj, self.mode, self.it.clone(), self.des, 15.7777)
+            else:
+                yref = torch.from_numpy(np.tile(row, (n, N, 1))).to(dev)
+                yref_e = torch.from_numpy(np.tile(row[:13], (n, 1))).to(dev)
+                self.solver.set_yref(yref, yref_e)
             self.solver.set_x0(self.x)
-            self.solver.set_yref(yref, yref_e)
             self.solver.init_iterate(INIT_HOVER)
             self.t = 0
 
@@ -165,8 +186,16 @@ def main():
                 t, xc = self.t, self.x
                 c0 = (t % KICK_PERIOD) * self.cohort
                 c1 = min(c0 + self.cohort, self.n)
-                if c1 > c0:
+                if c1 > c0 and not self.track:
                     xc[c0:c1].copy_(self.kicks[t % KICK_PERIOD, : c1 - c0])  # disturbance of one cohort
+                if self.track:
+                    if c1 > c0:   # disturbance relative to the vehicle's current reference row
+                        ref = self.traj[self.it[c0:c1].long(), :13]
+                        kick = ref + self.pert[t % KICK_PERIOD, : c1 - c0]
+                        kick[:, 3:7] /= torch.linalg.norm(kick[:, 3:7], dim=1, keepdim=True)
+                        xc[c0:c1].copy_(kick)
+                    # NMPC::iteration window logic on the device (acados_mpc.cpp:460-485)
+                    self.solver.set_yref_windows(self.traj, self.mode, self.it, self.des, 15.7777)
                 self.solver.set_x0(xc)                               # lbx = ubx = x0 (acados_mpc.cpp:581)
                 self.solver.solve(1, self.stream.cuda_stream)        # acados_solve()  (acados_mpc.cpp:611)
                 self.solver.get_u(0, out=self.u0)                    # ocp_nlp_out_get(.., 0, "u")  (:619)
@@ -243,7 +272,9 @@ def main():
             "value": value, "unit": "RTI steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3 hover regulation, closed loop through the RK4 plant, staggered kicks "
+            "config": {"workload": ("C3 hover regulation" if args.workload == "hover" else
+                                    "C4 figure-8 tracking (device-side reference windows)") +
+                                   ", closed loop through the RK4 plant, staggered kicks "
                                    f"(1/{KICK_PERIOD} of the fleet per step)", "batch_per_gpu": B, "horizon_N": N,
                        "streams_per_gpu": S,
                        "nx": 13, "nu": 4, "sharding": f"independent instances, {world} shard(s), no data-path collective",

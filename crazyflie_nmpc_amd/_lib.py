@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libcfnmpc.so")
 # every symbol include/cfnmpc.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "cfnmpc_default_opts", "cfnmpc_create", "cfnmpc_free", "cfnmpc_batch", "cfnmpc_horizon",
-    "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_set_weights", "cfnmpc_init_iterate",
+    "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_set_weights", "cfnmpc_set_yref_windows", "cfnmpc_init_iterate",
     "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_get_u", "cfnmpc_get_x",
     "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise",
     "cfnmpc_debug_get_head", "cfnmpc_set_profiling", "cfnmpc_get_profile", "cfnmpc_version",
@@ -60,6 +60,7 @@ def lib():
     L.cfnmpc_set_x0.argtypes = [vp, vp, i32, vp]
     L.cfnmpc_set_yref.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_set_weights.argtypes = [vp, vp, vp]
+    L.cfnmpc_set_yref_windows.argtypes = [vp, vp, i32, vp, vp, vp, dbl, vp]
     L.cfnmpc_init_iterate.argtypes = [vp, i32, vp]
     L.cfnmpc_set_iterate.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_get_iterate.argtypes = [vp, vp, vp, i32, vp]

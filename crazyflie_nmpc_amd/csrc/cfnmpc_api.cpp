@@ -193,6 +193,16 @@ int cfnmpc_set_yref(cfnmpc_solver* s, const double* yref, const double* yref_e, 
     return put_field(s, yref_e, on_device, 1, 13, 1, s->P.yref_e, (hipStream_t)stream);
 }
 
+int cfnmpc_set_yref_windows(cfnmpc_solver* s, const double* traj, int n_rows, int* mode, int* iter,
+                            const double* des_xyz, double uss, void* stream) {
+    if (!s || !mode || !iter || !des_xyz) return CFNMPC_EINVAL;
+    if (n_rows > 0 && (!traj || n_rows < s->P.N + 1)) return CFNMPC_EINVAL;
+    if (n_rows <= 0 && traj) return CFNMPC_EINVAL;
+    cfn::launch_windows(s->P, traj, n_rows > 0 ? n_rows : 0, mode, iter, des_xyz, uss, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return CFNMPC_OK;
+}
+
 int cfnmpc_set_weights(cfnmpc_solver* s, const double* W, const double* WN) {
     if (!s || (!W && !WN)) return CFNMPC_EINVAL;
     if (W) for (int i = 0; i < 17; i++) { if (!(W[i] > 0.0)) return CFNMPC_EINVAL; }

@@ -1114,6 +1114,50 @@ __global__ void k_get(int B, int S, int E, int perm13, int s0, int Stot, const d
         aos[idx] = blkp[blk_index(i, s0 + s, ei, Stot, E)];
     }
 }
+// Reference windows of the reference node generated on the device (acados_mpc.cpp:430-516), so
+// that a tracking fleet needs no per-step host -> device reference traffic.
+//   mode[i] 0 Regulation   : rows = [des_xyz(i), 1,0,0,0, 0 x 6, uss x 4]                 (:435-454)
+//   mode[i] 1 Tracking     : rows k = 0..N <- traj[iter(i) + k] ; ++iter(i)                (:460-485)
+//              (-> Position_Hold once iter >= n_rows - N; the window of that step is kept, :486)
+//   mode[i] 2 Position_Hold: xyz of the last trajectory row, identity attitude, uss        (:494-513)
+// One thread per (instance, stage); the policy update is done by stage-0 threads afterwards.
+__global__ void k_windows(Params P, const double* __restrict__ traj, int n_rows, int* __restrict__ mode,
+                          int* __restrict__ iter, const double* __restrict__ des, double uss) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = (int)(idx % (P.N + 1));
+    const int i = (int)(idx / (P.N + 1));
+    if (i >= P.B) return;
+    const int m = mode[i];
+    double row[17];
+    bool write = true;
+    if (m == 1) {
+        const int it = iter[i];
+        if (it < n_rows - P.N) {
+            for (int e = 0; e < 17; e++) row[e] = traj[(size_t)(it + k) * 17 + e];
+        } else {
+            write = false;  // switches to Position_Hold; this step keeps the previous window
+        }
+    } else {
+        const double* xyz = (m == 0) ? des + (size_t)i * 3 : traj + (size_t)(n_rows - 1) * 17;
+        for (int e = 0; e < 17; e++) row[e] = 0.0;
+        row[0] = xyz[0]; row[1] = xyz[1]; row[2] = xyz[2]; row[3] = 1.0;
+        for (int e = 13; e < 17; e++) row[e] = uss;
+    }
+    if (!write) return;
+    if (k < P.N) {
+        double* y = P.yref + blk_index(i, k, 0, P.N, 17);
+        for (int e = 0; e < 17; e++) y[e < 13 ? int_of(e) : e] = row[e];
+    } else {
+        double* y = P.yref_e + blk_index(i, 0, 0, 1, 13);
+        for (int e = 0; e < 13; e++) y[int_of(e)] = row[e];
+    }
+}
+__global__ void k_windows_advance(int B, int N, int n_rows, int* __restrict__ mode, int* __restrict__ iter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B || mode[i] != 1) return;
+    if (iter[i] < n_rows - N) iter[i] += 1; else mode[i] = 2;
+}
+
 __global__ void k_init_iterate(Params P, int mode) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.B) return;
@@ -1153,6 +1197,12 @@ void launch_put(int B, int S, int E, int perm13, const double* aos, double* blkp
 }
 void launch_get(int B, int S, int E, int perm13, int s0, int Stot, const double* blkp, double* aos, hipStream_t st) {
     hipLaunchKernelGGL(k_get, dim3(grid_for((size_t)B * S * E)), dim3(256), 0, st, B, S, E, perm13, s0, Stot, blkp, aos);
+}
+void launch_windows(const Params& P, const double* traj, int n_rows, int* mode, int* iter, const double* des,
+                    double uss, hipStream_t st) {
+    const size_t n = (size_t)P.B * (P.N + 1);
+    hipLaunchKernelGGL(k_windows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, traj, n_rows, mode, iter, des, uss);
+    hipLaunchKernelGGL(k_windows_advance, dim3((P.B + 255) / 256), dim3(256), 0, st, P.B, P.N, n_rows, mode, iter);
 }
 void launch_init_iterate(const Params& P, int mode, hipStream_t st) {
     hipLaunchKernelGGL(k_init_iterate, dim3((P.B + 255) / 256), dim3(256), 0, st, P, mode);

@@ -91,6 +91,8 @@ void launch_sim(int B, const double* x, const double* u, double T, int steps, do
 // row are states and are permuted to the internal order.
 void launch_put(int B, int S, int E, int perm13, const double* aos, double* blk, hipStream_t st);
 void launch_get(int B, int S, int E, int perm13, int s0, int Stot, const double* blk, double* aos, hipStream_t st);
+void launch_windows(const Params& P, const double* traj, int n_rows, int* mode, int* iter, const double* des,
+                    double uss, hipStream_t st);
 void launch_init_iterate(const Params& P, int mode, hipStream_t st);
 
 }  // namespace cfn

@@ -102,6 +102,21 @@ class BatchSolver:
             raise ValueError("yref and yref_e must live on the same side")
         _check(self._L.cfnmpc_set_yref(self._h, p, pe, dev, st), "cfnmpc_set_yref")
 
+    def set_yref_windows(self, traj, mode, it, des_xyz, uss):
+        """Device-side reference windows (NMPC::iteration state machine); all arguments are torch
+        device tensors: traj [n_rows][17] float64 or None, mode / it [B] int32 (updated in place),
+        des_xyz [B][3] float64."""
+        import torch
+        assert mode.is_cuda and it.is_cuda and des_xyz.is_cuda and mode.dtype == torch.int32 and it.dtype == torch.int32
+        assert tuple(des_xyz.shape) == (self.B, 3) and des_xyz.is_contiguous() and des_xyz.dtype == torch.float64
+        n_rows, tp = 0, None
+        if traj is not None:
+            assert traj.is_cuda and traj.dtype == torch.float64 and traj.is_contiguous() and traj.shape[1] == 17
+            n_rows, tp = int(traj.shape[0]), C.c_void_p(traj.data_ptr())
+        _check(self._L.cfnmpc_set_yref_windows(self._h, tp, n_rows, C.c_void_p(mode.data_ptr()), C.c_void_p(it.data_ptr()),
+                                               C.c_void_p(des_xyz.data_ptr()), float(uss), _stream_ptr(mode)),
+               "cfnmpc_set_yref_windows")
+
     def set_weights(self, W=None, WN=None):
         w = None if W is None else np.ascontiguousarray(W, dtype=np.float64)
         wn = None if WN is None else np.ascontiguousarray(WN, dtype=np.float64)

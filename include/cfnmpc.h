@@ -78,6 +78,16 @@ unsigned long long cfnmpc_workspace_bytes(const cfnmpc_solver *s);
 int cfnmpc_set_x0(cfnmpc_solver *s, const double *x0, int on_device, void *stream);
 /* ocp_nlp_cost_model_set(.., k, "yref", ..) for k = 0..N (acados_mpc.cpp:590-594) */
 int cfnmpc_set_yref(cfnmpc_solver *s, const double *yref, const double *yref_e, int on_device, void *stream);
+/* Reference windows generated ON THE DEVICE with the reference node's state machine
+ * (NMPC::iteration, acados_mpc.cpp:430-516) -- replaces the host-side fill of yref_sign and the
+ * N+1 ocp_nlp_cost_model_set("yref") calls per step (:590-594) for fleets:
+ *   mode[i] = 0 Regulation (rows = des_xyz[i], identity attitude, zeros, uss), 1 Tracking (rows
+ *   iter[i]..iter[i]+N of traj, then ++iter[i]; becomes 2 once iter[i] >= n_rows - N, keeping the
+ *   previous window for that step), 2 Position_Hold (xyz of the last trajectory row).
+ * All pointers are DEVICE pointers: traj [n_rows][17] (may be NULL with n_rows = 0 if no instance
+ * tracks), mode [B] / iter [B] (int, updated in place), des_xyz [B][3]. */
+int cfnmpc_set_yref_windows(cfnmpc_solver *s, const double *traj, int n_rows, int *mode, int *iter,
+                            const double *des_xyz, double uss, void *stream);
 /* ocp_nlp_cost_model_set(.., k, "W", ..) equivalent (acados_mpc.cpp:596-602, compiled out by
  * SET_WEIGHTS 0 in the reference): diagonal stage / terminal weights for ALL instances and
  * stages; either pointer may be NULL (unchanged).  Entries must be > 0. */

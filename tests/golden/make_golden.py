@@ -34,6 +34,8 @@ def main():
     helix = np.loadtxt(os.path.join(REF, "crazyflie_controller/traj/helix_traj.txt"))
     fig8 = np.loadtxt(os.path.join(REF, "crazyflie_demo/scripts/figure8.csv"), delimiter=",", skiprows=1, usecols=range(33))
     np.savez_compressed(os.path.join(HERE, "traj.npz"), smooth_step=smooth, helix=helix, figure8=fig8)
+    # the figure-8 coefficient table is also package data (bench.py --workload figure8, config C4)
+    np.save(os.path.join(ROOT, "crazyflie_nmpc_amd", "data", "figure8_coeffs.npy"), fig8)
 
     # ---- model vectors
     pts_x = [smooth[k, :13] for k in range(0, 451, 25)]

@@ -142,3 +142,42 @@ def test_figure8_tracking_config4_runs_and_tracks():
         x = sim(x, out["u0"], T=0.015, steps=1)
     err = np.abs(x[:, :3] - ref[nm.iter, :3]).max()
     assert err < 0.15, err                       # metres: the fleet follows the figure-8
+
+
+def test_device_reference_windows_match_node_state_machine():
+    """cfnmpc_set_yref_windows (device) == BatchNMPC.windows() (host mirror of
+    acados_mpc.cpp:430-516) for a fleet mixing Regulation / Tracking / Position_Hold, including the
+    Tracking -> Position_Hold hand-over, and gives the same controls."""
+    import torch
+    from crazyflie_nmpc_amd import BatchSolver, sim
+    from crazyflie_nmpc_amd.node import BatchNMPC, TRACKING, REGULATION
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    from crazyflie_nmpc_amd.synthetic import sample_hover_x0
+    t = np.load(os.path.join(G, "traj.npz"))
+    traj = t["helix"]
+    B = 23
+    rng = np.random.default_rng(9)
+    dev = torch.device("cuda", 0)
+    nm = BatchNMPC(B, traj=traj)
+    nm.policy[:] = np.where(np.arange(B) % 3 == 0, REGULATION, TRACKING)
+    nm.iter[:] = rng.integers(0, 1000, B)
+    nm.iter[1] = 998; nm.iter[2] = 999; nm.iter[4] = 1000      # around the end: N_STEPS - N = 1000
+    nm.des[:] = rng.uniform(-1, 1, (B, 3)) * [1, 1, 0.4] + [0, 0, 0.6]
+    x = sample_hover_x0(rng, B)
+    x[:, :3] += np.where((nm.policy == TRACKING)[:, None], traj[np.minimum(nm.iter, 1049), :3] - [0, 0, 0.4], nm.des - [0, 0, 0.4])
+    s = BatchSolver(B)
+    mode = torch.from_numpy(nm.policy.astype(np.int32)).to(dev)
+    it = torch.from_numpy(nm.iter.astype(np.int32)).to(dev)
+    des = torch.from_numpy(nm.des.copy()).to(dev)
+    trj = torch.from_numpy(traj.copy()).to(dev)
+    nm.solver.set_x0(x); nm.solver.init_iterate(INIT_HOVER)
+    s.set_x0(x); s.init_iterate(INIT_HOVER)
+    for k in range(4):
+        out = nm.iteration(x)                                 # host windows + solve
+        s.set_yref_windows(trj, mode, it, des, nm.uss)       # device windows
+        s.set_x0(x); s.solve(1)
+        torch.cuda.synchronize()
+        assert np.array_equal(mode.cpu().numpy(), nm.policy) and np.array_equal(it.cpu().numpy(), nm.iter), k
+        assert np.array_equal(s.get_u(0), out["u0"]) and np.array_equal(s.get_x(4), out["x4"]), k
+        x = sim(x, out["u0"], T=0.015, steps=1)
+    assert (nm.policy == 2).sum() >= 3                        # the hand-over to Position_Hold happened
