@@ -106,6 +106,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->tau = 0.995;
     o->thr0 = 1.0;
     o->lam0_min = 1e-2;
+    o->mu0_scale = 0.1;
     o->active_horizon = 1;
     o->ah_margin = 0.10;
     o->ah_extra = 4;
@@ -137,7 +138,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     for (int i = 0; i < 17; i++) P.W[i] = o.W[i];
     for (int i = 0; i < 13; i++) P.WN[i] = o.WN[i];
     P.u_min = o.u_min; P.u_max = o.u_max; P.tol = o.tol; P.tau = o.tau; P.thr0 = o.thr0;
-    P.lam0_min = o.lam0_min; P.max_iter = o.max_iter;
+    P.lam0_min = o.lam0_min; P.mu0_scale = o.mu0_scale; P.max_iter = o.max_iter;
     P.active_horizon = o.active_horizon ? 1 : 0;
     P.ah_margin = o.ah_margin;
     P.ah_extra = o.ah_extra;

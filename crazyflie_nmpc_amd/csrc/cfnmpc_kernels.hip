@@ -862,7 +862,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         gather(head, chk);
         if (infeasible) {
             // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
-            const double mu0 = fmax(viol, P.lam0_min);
+            const double mu0 = fmax(P.mu0_scale * viol, P.lam0_min);
             double mu = 0.0, res = 0.0;
             for (int e = t.L; e < head * 4; e += 16) {
                 const size_t idx = cbase + e;

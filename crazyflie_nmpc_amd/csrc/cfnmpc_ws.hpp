@@ -53,7 +53,7 @@ struct Params {
     int B, NW, N;  // instances, waves (= ceil(B/4)), horizon
     double dt;
     double W[17], WN[13];  // external order, as in cfnmpc_opts
-    double u_min, u_max, tol, tau, thr0, lam0_min;
+    double u_min, u_max, tol, tau, thr0, lam0_min, mu0_scale;
     int max_iter;
     int active_horizon;  // 1: interior-point sweeps only over the stages that can saturate
     double ah_margin;    // ... 'tight' = within this fraction of the box width of a bound

@@ -54,6 +54,8 @@ typedef struct cfnmpc_opts {
     double tau;          /* QP: fraction to the boundary (0.995)                           */
     double thr0;         /* QP: slack floor of the starting point (1.0)                    */
     double lam0_min;     /* QP: complementarity floor of the starting point (1e-2)         */
+    double mu0_scale;    /* QP: starting complementarity = max(lam0_min, mu0_scale * largest
+                            bound violation of the unconstrained minimiser) (0.1)          */
     int active_horizon;  /* QP: 1 = interior-point sweeps only over the head of the horizon
                             whose inputs can saturate; the unconstrained tail keeps its
                             Riccati feedback law and is verified afterwards (exact); 0 = all

@@ -327,7 +327,7 @@ def kkt_residual(qp: StageQP, dx, du, lam_l, lam_u):
 # Stage-wise Riccati interior point (the algorithm the HIP kernels implement; plays the role
 # of HPIPM d_ocp_qp_ipm_solve selected at generate_c_code.py:140).  See DESIGN.md section 4.
 # ----------------------------------------------------------------------------------------
-IPM_DEFAULTS = dict(tol=1e-8, max_iter=50, tau=0.995, thr0=1.0, lam0_min=1e-2)
+IPM_DEFAULTS = dict(tol=1e-8, max_iter=50, tau=0.995, thr0=1.0, lam0_min=1e-2, mu0_scale=0.1)
 
 
 def _riccati_factor(qp, Rhat, rhat, absolute=True):
@@ -416,7 +416,7 @@ def riccati_ipm(qp: StageQP, **opts):
     tl = np.maximum(v - lb, o["thr0"])
     tu = np.maximum(ub - v, o["thr0"])
     viol = max(float(np.maximum(lb - v, 0).max()), float(np.maximum(v - ub, 0).max()))
-    mu0 = max(o["lam0_min"], viol)
+    mu0 = max(o["lam0_min"], o["mu0_scale"] * viol)
     ll = mu0 / tl
     lu = mu0 / tu
     rg = -ll + lu  # R v + r + B'pi = 0 at the unconstrained start

@@ -43,6 +43,7 @@ typedef struct {
     double tau;       /* IPM: fraction to the boundary                         */
     double thr0;      /* IPM: slack floor of the starting point                */
     double lam0_min;  /* IPM: floor of the starting complementarity            */
+    double mu0_scale; /* IPM: starting complementarity = max(lam0_min, mu0_scale * max. violation) */
 } cfo_opts;
 
 void cfo_default_opts(cfo_opts *o) {
@@ -59,6 +60,7 @@ void cfo_default_opts(cfo_opts *o) {
     o->tau = 0.995;
     o->thr0 = 1.0;
     o->lam0_min = 1e-2;
+    o->mu0_scale = 0.1;
 }
 
 /* ---------------------------------------------------------------- dynamics */
@@ -407,7 +409,7 @@ static int ipm_solve(qp_t *qp, const cfo_opts *o, int *iters_out, double *res_ou
     if (feas) { free(Rhat); *res_out = 0.0; return 0; }
     if (!(viol == viol)) { free(Rhat); *res_out = NAN; return 4; }
     {
-        const double mu0 = viol > o->lam0_min ? viol : o->lam0_min;
+        const double mu0 = fmax(o->mu0_scale * viol, o->lam0_min);
         for (int i = 0; i < n; i++) {
             tl[i] = fmax(v[i] - qp->lb[i], o->thr0);
             tu[i] = fmax(qp->ub[i] - v[i], o->thr0);

@@ -31,10 +31,10 @@ def test_full_size_properties_and_spot_parity(oracle, cref):
         xg, ug = s.get_iterate()
         assert (st == 0).all(), np.bincount(st)
         assert it.max() <= 30 and np.nanmax(rs) <= 1e-8
-        # x0 is pinned exactly; every input of the new iterate is inside the box (up to the
-        # interior-point slack, which is positive by construction)
+        # x0 is pinned; every input of the new iterate is inside the box up to the QP tolerance
+        # (infeasible-start interior point: the slack residual |v - lb - t| is <= tol = 1e-8)
         assert np.abs(xg[:, 0, :] - x).max() < 1e-14     # xbar_0 + (x0 - xbar_0): one rounding
-        assert ug.min() >= 0.0 and ug.max() <= 22.0
+        assert ug.min() >= -1e-8 and ug.max() <= 22.0 + 1e-8
         # the interior-point method was needed for a sizeable part of the fleet, not for all
         frac = (it > 0).mean()
         assert 0.02 < frac < 0.8, frac
