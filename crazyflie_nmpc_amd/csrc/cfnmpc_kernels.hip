@@ -4,7 +4,8 @@
 // per workgroup (cfnmpc_ws.hpp).  Instances never communicate; every wave runs its own
 // interior-point loop until its four instances are done (wave-uniform trip count via __any).
 //
-// Kernels, one RTI step = five launches on one stream:
+// Kernels, one RTI step = five launches on one stream
+// (k_linearise, k_factor, k_forward, k_compact, k_ipm):
 //   k_linearise : RK4 + forward sensitivities per shooting interval (the role of acados
 //                 sim_erk + CasADi forw_vde, acados_mpc.cpp:84): lane c integrates sensitivity
 //                 COLUMN c; a 13x17 LDS tile re-distributes it into the row form.
@@ -15,8 +16,8 @@
 //   k_ipm       : only waves with an infeasible instance: Mehrotra predictor-corrector over
 //                 stage-wise Riccati sweeps in delta form (HPIPM's role,
 //                 generate_c_code.py:140), expansion, tail verification.
-//   k_commit    : full RTI step (iterate += step) and statistics (acados_solve() epilogue,
-//                 acados_mpc.cpp:611-616).
+//                 Both k_forward (feasible rows) and k_ipm (its rows) end with the full RTI step
+//                 iterate += step (acados_solve() epilogue, acados_mpc.cpp:611-616).
 //   k_sim       : RK4 predictor / plant step (acados_estimator.cpp:573-593).
 //   k_put / k_get / k_init_iterate : layout glue for the C-ABI.
 #include <hip/hip_runtime.h>
@@ -585,19 +586,33 @@ __device__ __forceinline__ double propagate(const Lane& t, const FwdIn<WITH_B>& 
     return xn;
 }
 
-// forward sweep of a homogeneous (delta) solve over [0, head): writes the input step to `out`
+// forward sweep of a homogeneous (delta) solve over [0, head): writes the input step to `out`.
+// Three rotating stage buffers: the loads of stage k+2 are issued before the arithmetic of
+// stage k (these sweeps run with ~1 wave per SIMD, so memory-level parallelism has to come from
+// the wave itself).
 __device__ __forceinline__ void sweep_forward_delta(const Params& P, const Lane& t, const int head, gdouble* out) {
     double x = 0.0;
-    FwdIn<false> cur, nxt;
-    load_fwd<false>(P, t, 0, cur);
-    for (int k = 0; k < head; k++) {
-        load_fwd<false>(P, t, imin(k + 1, head - 1), nxt);  // prefetch
+    FwdIn<false> b0, b1, b2;
+    auto body = [&](const FwdIn<false>& cur, int k) {
         const double dv = feedback<false>(t, cur, x);
         if (t.L < 4) out[i4(P, t, k, t.L)] = dv;
         double vr[4];
         SFOR(a, 0, 4, { vr[a] = bc<a>(dv); });
         x = propagate<false>(t, cur, x, vr);
-        cur = nxt;
+    };
+    load_fwd<false>(P, t, 0, b0);
+    load_fwd<false>(P, t, imin(1, head - 1), b1);
+    int k = 0;
+    while (k < head) {
+        load_fwd<false>(P, t, imin(k + 2, head - 1), b2);
+        body(b0, k);
+        if (++k >= head) break;
+        load_fwd<false>(P, t, imin(k + 2, head - 1), b0);
+        body(b1, k);
+        if (++k >= head) break;
+        load_fwd<false>(P, t, imin(k + 2, head - 1), b1);
+        body(b2, k);
+        ++k;
     }
 }
 
@@ -622,14 +637,11 @@ __device__ __forceinline__ void load_res(const Params& P, const Lane& t, const i
 __device__ __forceinline__ void sweep_resolve(const Params& P, const Lane& t, const int head) {
     double p[13];
     SFOR(j, 0, 13, { p[j] = 0.0; });
-    ResIn cur, nxt;
-    load_res(P, t, head - 1, cur);
-    for (int k = head - 1; k >= 0; k--) {
-        load_res(P, t, imax(k - 1, 0), nxt);  // prefetch
+    const int a = t.L & 3;
+    auto body = [&](const ResIn& cur, int k) {
         const double(&ar)[10] = cur.ar;
         const double(&br)[4] = cur.br;
         const double(&kr)[13] = cur.kr;
-        const int a = t.L & 3;
         double glane = t.L < 4 ? cur.g : 0.0;
         // rho[a] = g[a] + sum_l p[l] B[l][a]   (replicated)
         double rr[4], nrr[4];
@@ -653,7 +665,21 @@ __device__ __forceinline__ void sweep_resolve(const Params& P, const Lane& t, co
         dotbc<13, 0>(pn[12], p, ar[9]);
         SFOR(j, 0, 13, { dotbc<4, 0>(pn[j], nrr, kr[j]); });
         SFOR(j, 0, 13, { p[j] = pn[j]; });
-        cur = nxt;
+    };
+    ResIn b0, b1, b2;
+    load_res(P, t, head - 1, b0);
+    load_res(P, t, imax(head - 2, 0), b1);
+    int k = head - 1;
+    while (k >= 0) {
+        load_res(P, t, imax(k - 2, 0), b2);
+        body(b0, k);
+        if (--k < 0) break;
+        load_res(P, t, imax(k - 2, 0), b0);
+        body(b1, k);
+        if (--k < 0) break;
+        load_res(P, t, imax(k - 2, 0), b1);
+        body(b2, k);
+        --k;
     }
 }
 
@@ -705,6 +731,20 @@ __device__ __forceinline__ void start_forward(const Params& P, const Lane& t, do
     if (row_max(sawnan ? 1.0 : 0.0) > 0.0) viol = nan("");
 }
 
+// full RTI step of one row (acados_solve() epilogue): iterate += accepted step.  `doit` is
+// row-uniform; the step (P.dx, P.v) was written by this very wave, so the reads hit in L2.
+__device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const bool doit) {
+    if (!doit) return;
+    const int N = P.N;
+    for (int k = 0; k <= N; k++) {
+        gdouble* xb = blk(P.xit, t, N + 1, k, SZ_V13);
+        const double dxk = ld13(blk(P.dx, t, N + 1, k, SZ_V13), t);
+        if (t.L < 13) xb[t.q * 13 + t.L] += dxk;
+    }
+    const size_t ibase = (size_t)t.inst * N * 4;
+    for (int e = t.L; e < N * 4; e += 16) gm(P.uit)[ibase + e] += gm(P.v)[ibase + e];
+}
+
 // head class of an instance: the interior-point sweeps must cover stages [0, want)
 __device__ __forceinline__ int head_class(const Params& P, int want) {
     if (want <= 0) return 0;
@@ -733,6 +773,9 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         gm(P.res)[t.inst] = bad ? nan("") : 0.0;
         gm(P.head)[t.inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
     }
+    // rows whose unconstrained minimiser is feasible are done: commit them here (the others are
+    // committed by k_ipm once their QP is accepted; failed rows keep their iterate)
+    commit_row(P, t, t.valid && !bad && !infeasible);
 }
 
 // Stable compaction of the instances that need the interior-point method, grouped by head
@@ -1038,22 +1081,9 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         gm(P.res)[t.inst] = R.res;
         gm(P.head)[t.inst] = head;
     }
+    commit_row(P, t, infeasible && R.status != 4);
 }
 
-// full RTI step: iterate += step (streaming)
-__global__ __launch_bounds__(64) void k_commit(Params P) {
-    const Lane t = lane_id(P);
-    if (!t.valid) return;
-    const int N = P.N;
-    if (gm(P.status)[t.inst] == 4) return;  // failed QP: keep the iterate (status tells the caller)
-    for (int k = 0; k <= N; k++) {
-        gdouble* xb = blk(P.xit, t, N + 1, k, SZ_V13);
-        const double dxk = ld13(blk(P.dx, t, N + 1, k, SZ_V13), t);
-        if (t.L < 13) xb[t.q * 13 + t.L] += dxk;
-    }
-    const size_t ibase = (size_t)t.inst * N * 4;
-    for (int e = t.L; e < N * 4; e += 16) gm(P.uit)[ibase + e] += gm(P.v)[ibase + e];
-}
 
 // =============================================================================================
 // predictor / plant step, layout glue
@@ -1183,7 +1213,6 @@ void launch_qp(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_forward, dim3(P.NW), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, P);
     hipLaunchKernelGGL(k_ipm, dim3(P.NW), dim3(64), 0, st, P);
-    hipLaunchKernelGGL(k_commit, dim3(P.NW), dim3(64), 0, st, P);
 }
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st) {
     hipLaunchKernelGGL(k_sim, dim3((B + 255) / 256), dim3(256), 0, st, B, x, u, T, steps, xn);
