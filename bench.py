@@ -52,41 +52,45 @@ def alg_bytes_qp(N):
     return 8 * (302 * N + 67)
 
 
-def cpu_baseline(seed, n_inst=2048, n_steps=4):
-    """Times the CPU restatement on a bounded sample of the same workload (closed loop)."""
+def cpu_baseline(seed, n_inst=2048, n_steps=4, reps=3):
+    """Times the CPU restatement on a bounded sample of the same workload (closed loop).
+    Best of `reps` repetitions for both figures: GPU boxes are shared hosts and single timings
+    of the host cores vary by up to 10x between runs."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cfnmpc_oracle as o
     import cref
     cref.build()
-    rng = np.random.default_rng(seed)
-    x = o.sample_hover_x0(rng, n_inst)
     yr, ye = o.regulation_yref(N_HORIZON, (0.0, 0.0, 0.4))
     yref = np.repeat(yr[None], n_inst, 0).copy()
     yref_e = np.repeat(ye[None], n_inst, 0).copy()
     opts = cref.default_opts()
-    xit = np.repeat(x[:, None, :], N_HORIZON + 1, 1).copy()
-    uit = np.full((n_inst, N_HORIZON, 4), o.HOV_W)
     cores = os.cpu_count() or 1
-    t_solve = 0.0
-    used = 1
-    iters = []
-    for _ in range(n_steps):
+    best_all, best_one, used, iters = 0.0, 0.0, 1, []
+    for _ in range(reps):
+        rng = np.random.default_rng(seed)
+        x = o.sample_hover_x0(rng, n_inst)
+        xit = np.repeat(x[:, None, :], N_HORIZON + 1, 1).copy()
+        uit = np.full((n_inst, N_HORIZON, 4), o.HOV_W)
+        t_solve = 0.0
+        iters = []
+        for _s in range(n_steps):
+            t0 = time.perf_counter()
+            st, it, rs, used = cref.rti_step(opts, xit, uit, x.copy(), yref, yref_e, nthreads=0)
+            t_solve += time.perf_counter() - t0
+            iters.append(float(it.mean()))
+            x = cref.sim(x, uit[:, 0, :].copy(), 0.015, 1)
+        best_all = max(best_all, n_inst * n_steps / t_solve)
+        # single-thread rate on a small slice of the same states
+        m = min(64, n_inst)
+        xs = np.repeat(x[:m, None, :], N_HORIZON + 1, 1).copy(); us = np.full((m, N_HORIZON, 4), o.HOV_W)
         t0 = time.perf_counter()
-        st, it, rs, used = cref.rti_step(opts, xit, uit, x.copy(), yref, yref_e, nthreads=0)
-        t_solve += time.perf_counter() - t0
-        iters.append(float(it.mean()))
-        x = cref.sim(x, uit[:, 0, :].copy(), 0.015, 1)
-    # single-thread latency on a small slice
-    m = min(64, n_inst)
-    xs = np.repeat(x[:m, None, :], N_HORIZON + 1, 1).copy(); us = np.full((m, N_HORIZON, 4), o.HOV_W)
-    t0 = time.perf_counter()
-    cref.rti_step(opts, xs, us, x[:m].copy(), yref[:m].copy(), yref_e[:m].copy(), nthreads=1)
-    t1 = time.perf_counter() - t0
+        cref.rti_step(opts, xs, us, x[:m].copy(), yref[:m].copy(), yref_e[:m].copy(), nthreads=1)
+        best_one = max(best_one, m / (time.perf_counter() - t0))
     return {
-        "value": n_inst * n_steps / t_solve, "unit": "RTI steps/s", "cores": int(used),
+        "value": best_all, "unit": "RTI steps/s", "cores": int(used),
         "host_cores": int(cores), "kind": "port",
-        "single_thread_steps_per_s": m / t1,
-        "sample": f"{n_inst} instances x {n_steps} closed-loop RTI steps of the same hover workload, "
+        "single_thread_steps_per_s": best_one,
+        "sample": f"best of {reps} x ({n_inst} instances x {n_steps} closed-loop RTI steps of the same hover workload), "
                   f"oracle/cfnmpc_ref.c (CPU restatement, not acados), OpenMP over {used} threads; "
                   f"mean QP iterations {np.mean(iters):.2f}",
     }
