@@ -6,6 +6,6 @@ tests and bench.py: a ctypes binding (`_lib`), a batch solver object (`solver.Ba
 and a ROS-free mirror of the reference node's per-step protocol (`node`).
 There is no CPU fallback: importing `_lib` fails loudly if the HIP library is missing.
 """
-from .solver import BatchSolver, Opts, default_opts, sim  # noqa: F401
+from .solver import BatchSolver, Opts, default_opts, estimate, sim  # noqa: F401
 
-__all__ = ["BatchSolver", "Opts", "default_opts", "sim"]
+__all__ = ["BatchSolver", "Opts", "default_opts", "estimate", "sim"]

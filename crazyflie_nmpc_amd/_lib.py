@@ -14,7 +14,7 @@ SYMBOLS = [
     "cfnmpc_default_opts", "cfnmpc_create", "cfnmpc_free", "cfnmpc_batch", "cfnmpc_horizon",
     "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_set_weights", "cfnmpc_set_yref_windows", "cfnmpc_init_iterate",
     "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_get_u", "cfnmpc_get_x",
-    "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise",
+    "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_estimate", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise",
     "cfnmpc_debug_get_head", "cfnmpc_set_profiling", "cfnmpc_get_profile", "cfnmpc_version",
 ]
 
@@ -69,6 +69,7 @@ def lib():
     L.cfnmpc_get_x.argtypes = [vp, i32, vp, i32, vp]
     L.cfnmpc_get_stats.argtypes = [vp, vp, vp, vp, i32, vp]
     L.cfnmpc_sim.argtypes = [i32, vp, vp, dbl, i32, vp, i32, vp]
+    L.cfnmpc_estimate.argtypes = [i32, vp, vp, vp, dbl, i32, dbl, i32, vp, vp, vp]
     L.cfnmpc_debug_get_linearisation.argtypes = [vp, vp, vp, vp]
     L.cfnmpc_debug_get_head.argtypes = [vp, vp]
     L.cfnmpc_set_profiling.argtypes = [vp, i32]

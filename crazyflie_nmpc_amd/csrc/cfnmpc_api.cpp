@@ -310,6 +310,15 @@ int cfnmpc_sim(int batch, const double* x, const double* u, double T, int steps,
     return rc;
 }
 
+int cfnmpc_estimate(int batch, const double* meas, double* filt, const double* u, double dt, int use_lpf, double delay,
+                    int steps, double* x_est, double* x_pred, void* stream) {
+    if (batch <= 0 || !meas || !filt || !u || !x_est || !x_pred || steps < 1 || !(delay > 0) || !(dt > 0))
+        return CFNMPC_EINVAL;
+    cfn::launch_estimate(batch, meas, filt, u, dt, use_lpf ? 1 : 0, delay, steps, x_est, x_pred, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return CFNMPC_OK;
+}
+
 int cfnmpc_set_profiling(cfnmpc_solver* s, int enable) {
     if (!s) return CFNMPC_EINVAL;
     s->profiling = enable ? 1 : 0;

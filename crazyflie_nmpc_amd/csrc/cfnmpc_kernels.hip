@@ -1116,6 +1116,77 @@ __global__ void k_sim(int B, const double* __restrict__ x, const double* __restr
     for (int e = 0; e < 13; e++) xn[(size_t)i * 13 + e] = xc[e];
 }
 
+// State assembly + delay compensation of the reference estimator, batched, one vehicle per lane
+// (ESTIMATOR::predictor, acados_estimator.cpp:521-634):
+//   meas [B][9] = mocap x y z [m] | onboard roll pitch yaw [deg, as published by the driver]
+//                 | gyro rates wx wy wz [rad/s]
+//   filt [B][9] = previous position (3), previous two velocity outputs v[k-1] (3), v[k-2] (3);
+//                 updated in place (the x/y/z_samples and v*_filter_samples of :370-412)
+//   u    [B][4] = latest motor speeds [kRPM] used for the prediction
+// Steps: pitch sign flip (:495), deg -> rad, Euler -> quaternion with the reference's sign
+// convention and w >= 0 (:327-354) + normalisation (:546), world-velocity low-pass filter
+// (:356-368; use_lpf = 0 selects its finite-difference branch), rotation to the body frame
+// (:414-440), then one RK4 integration over `delay` in `steps` sub-steps (:573-593).
+// Writes x_est (assembled state) and x_pred (delay-compensated state).
+__global__ void k_estimate(int B, const double* __restrict__ meas, double* __restrict__ filt,
+                           const double* __restrict__ u, double dt, int use_lpf, double delay, int steps,
+                           double* __restrict__ x_est, double* __restrict__ x_pred) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const double pi = 3.14159265358979323846;
+    const double* m = meas + (size_t)i * 9;
+    double* f = filt + (size_t)i * 9;
+    const double phi = m[3] / 180.0 * pi, theta = -m[4] / 180.0 * pi, psi = m[5] / 180.0 * pi;
+    const double cph = cos(phi * 0.5), sph = sin(phi * 0.5);
+    const double cth = cos(theta * 0.5), sth = sin(theta * 0.5);
+    const double cps = cos(psi * 0.5), sps = sin(psi * 0.5);
+    double qw = cph * cth * cps + sph * sth * sps;
+    double qx = -(cps * cth * sph - sps * sth * cph);
+    double qy = -(cps * sth * cph + sps * cth * sph);
+    double qz = -(sps * cth * cph - cps * sth * sph);
+    if (qw < 0) { qw = -qw; qx = -qx; qy = -qy; qz = -qz; }
+    const double nrm = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw /= nrm; qx /= nrm; qy /= nrm; qz /= nrm;
+    double ve[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double pk = m[a], pk1 = f[a], v1 = f[3 + a], v2 = f[6 + a];
+        ve[a] = use_lpf ? (0.3306 * v1 - 0.02732 * v2 + 35.7 * pk - 35.7 * pk1) : (pk - pk1) / dt;
+        f[a] = pk; f[6 + a] = v1; f[3 + a] = ve[a];
+    }
+    const double S11 = 2 * (qw * qw + qx * qx) - 1, S12 = 2 * (qx * qy + qw * qz), S13 = 2 * (qx * qz - qw * qy);
+    const double S21 = 2 * (qx * qy - qw * qz), S22 = 2 * (qw * qw + qy * qy) - 1, S23 = 2 * (qy * qz + qw * qx);
+    const double S31 = 2 * (qx * qz + qw * qy), S32 = 2 * (qy * qz - qw * qx), S33 = 2 * (qw * qw + qz * qz) - 1;
+    double xc[13], uc[4], k1[13], k2[13], k3[13], k4[13], xt[13];
+    xc[0] = m[0]; xc[1] = m[1]; xc[2] = m[2];
+    xc[3] = qw; xc[4] = qx; xc[5] = qy; xc[6] = qz;
+    xc[7] = S11 * ve[0] + S12 * ve[1] + S13 * ve[2];
+    xc[8] = S21 * ve[0] + S22 * ve[1] + S23 * ve[2];
+    xc[9] = S31 * ve[0] + S32 * ve[1] + S33 * ve[2];
+    xc[10] = m[6]; xc[11] = m[7]; xc[12] = m[8];
+#pragma unroll
+    for (int e = 0; e < 13; e++) x_est[(size_t)i * 13 + e] = xc[e];
+#pragma unroll
+    for (int e = 0; e < 4; e++) uc[e] = u[(size_t)i * 4 + e];
+    const double h = delay / steps;
+    for (int s_ = 0; s_ < steps; s_++) {
+        f_expl(xc, uc, k1);
+#pragma unroll
+        for (int e = 0; e < 13; e++) xt[e] = xc[e] + 0.5 * h * k1[e];
+        f_expl(xt, uc, k2);
+#pragma unroll
+        for (int e = 0; e < 13; e++) xt[e] = xc[e] + 0.5 * h * k2[e];
+        f_expl(xt, uc, k3);
+#pragma unroll
+        for (int e = 0; e < 13; e++) xt[e] = xc[e] + h * k3[e];
+        f_expl(xt, uc, k4);
+#pragma unroll
+        for (int e = 0; e < 13; e++) xc[e] += (h / 6.0) * (k1[e] + 2 * k2[e] + 2 * k3[e] + k4[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 13; e++) x_pred[(size_t)i * 13 + e] = xc[e];
+}
+
 // AoS [B][S][E] (external order) -> wave-blocked [wave][S][inst 0..3][E]; if perm13 the first 13
 // entries of a row are permuted to the internal state order.  E == 4 fields are instance-major
 // ([inst][S][4]) and handled by the same formula with a different block shape.
@@ -1216,6 +1287,11 @@ void launch_qp(const Params& P, hipStream_t st) {
 }
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st) {
     hipLaunchKernelGGL(k_sim, dim3((B + 255) / 256), dim3(256), 0, st, B, x, u, T, steps, xn);
+}
+void launch_estimate(int B, const double* meas, double* filt, const double* u, double dt, int use_lpf, double delay,
+                     int steps, double* x_est, double* x_pred, hipStream_t st) {
+    hipLaunchKernelGGL(k_estimate, dim3((B + 255) / 256), dim3(256), 0, st, B, meas, filt, u, dt, use_lpf, delay, steps,
+                       x_est, x_pred);
 }
 static inline int grid_for(size_t n) {
     size_t g = (n + 255) / 256;

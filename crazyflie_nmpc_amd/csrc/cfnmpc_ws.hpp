@@ -86,6 +86,8 @@ struct Params {
 
 void launch_linearise(const Params& P, hipStream_t st);
 void launch_qp(const Params& P, hipStream_t st);
+void launch_estimate(int B, const double* meas, double* filt, const double* u, double dt, int use_lpf, double delay,
+                     int steps, double* x_est, double* x_pred, hipStream_t st);
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st);
 // AoS [B][S][E] (external order) <-> wave-blocked vectors; perm13: first 13 entries of each
 // row are states and are permuted to the internal order.

@@ -204,3 +204,19 @@ def sim(x, u, T=0.06, steps=4, out=None):
     _check(L.cfnmpc_sim(B, xa.ctypes.data_as(C.c_void_p), ua.ctypes.data_as(C.c_void_p), float(T), int(steps),
                         out.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_sim")
     return out
+
+
+def estimate(meas, filt, u, dt=0.015, use_lpf=True, delay=0.06, steps=4):
+    """Batched ESTIMATOR::predictor (acados_estimator.cpp:521-634) on torch device tensors:
+    meas [B][9], filt [B][9] (updated in place), u [B][4] -> (x_est, x_pred) [B][13]."""
+    import torch
+    L = _lib.lib()
+    B = meas.shape[0]
+    for a, sh in ((meas, (B, 9)), (filt, (B, 9)), (u, (B, 4))):
+        assert a.is_cuda and a.dtype == torch.float64 and a.is_contiguous() and tuple(a.shape) == sh
+    x_est = torch.empty((B, NX), dtype=torch.float64, device=meas.device)
+    x_pred = torch.empty_like(x_est)
+    _check(L.cfnmpc_estimate(B, C.c_void_p(meas.data_ptr()), C.c_void_p(filt.data_ptr()), C.c_void_p(u.data_ptr()),
+                             float(dt), int(bool(use_lpf)), float(delay), int(steps), C.c_void_p(x_est.data_ptr()),
+                             C.c_void_p(x_pred.data_ptr()), _stream_ptr(meas)), "cfnmpc_estimate")
+    return x_est, x_pred

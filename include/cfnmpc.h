@@ -125,6 +125,17 @@ int cfnmpc_get_profile(cfnmpc_solver *s, double *ms_linearise, double *ms_qp, in
  * xn = RK4(x, u) over T seconds in `steps` sub-steps.  Stateless. */
 int cfnmpc_sim(int batch, const double *x, const double *u, double T, int steps, double *xn, int on_device, void *stream);
 
+/* ESTIMATOR::predictor() for a fleet (acados_estimator.cpp:521-634), DEVICE pointers only:
+ * assembles the 13-state from mocap position, onboard Euler angles [deg, as published by the
+ * driver; the pitch sign flip of :495 is applied inside] and gyro rates, estimates the world
+ * velocity with the reference's low-pass filter (:356-368; the reference always takes this branch
+ * because it passes the absolute start time as "elapsed time"; use_lpf = 0 selects the finite
+ * difference), rotates it into the body frame (:414-440) and integrates the model over `delay`
+ * with the latest inputs (:573-593).  meas [B][9] = x y z roll pitch yaw wx wy wz; filt [B][9] =
+ * previous position, v[k-1], v[k-2] (updated in place); u [B][4]; outputs x_est, x_pred [B][13]. */
+int cfnmpc_estimate(int batch, const double *meas, double *filt, const double *u, double dt, int use_lpf,
+                    double delay, int steps, double *x_est, double *x_pred, void *stream);
+
 /* Kernel-level access for parity tests (oracle comparison of the linearisation): copies the
  * stage blocks of the last linearisation as dense row-major arrays in the reference's state
  * order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13] (host pointers). */

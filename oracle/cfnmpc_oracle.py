@@ -557,3 +557,42 @@ def sample_hover_x0(rng, n, center=(0.0, 0.0, 0.4), scale=1.0):
     vel = scale * rng.uniform(-0.5, 0.5, (n, 3))
     rate = scale * rng.uniform(-1.0, 1.0, (n, 3))
     return np.concatenate([pos, quat, vel, rate], axis=1)
+
+
+# ----------------------------------------------------------------------------------------
+# estimator: state assembly + delay compensation (acados_estimator.cpp:327-368, 414-440, 521-634)
+# ----------------------------------------------------------------------------------------
+def euler2quatern(phi, theta, psi):
+    """acados_estimator.cpp:327-354 (vector part negated, w >= 0)"""
+    cph, sph = np.cos(phi * 0.5), np.sin(phi * 0.5)
+    cth, sth = np.cos(theta * 0.5), np.sin(theta * 0.5)
+    cps, sps = np.cos(psi * 0.5), np.sin(psi * 0.5)
+    q = np.array([cph * cth * cps + sph * sth * sps,
+                  -(cps * cth * sph - sps * sth * cph),
+                  -(cps * sth * cph + sps * cth * sph),
+                  -(sps * cth * cph - cps * sth * sph)])
+    return -q if q[0] < 0 else q
+
+
+def rotate_e2b(q, v):
+    """acados_estimator.cpp:414-440"""
+    w, x, y, z = q
+    S = np.array([[2 * (w * w + x * x) - 1, 2 * (x * y + w * z), 2 * (x * z - w * y)],
+                  [2 * (x * y - w * z), 2 * (w * w + y * y) - 1, 2 * (y * z + w * x)],
+                  [2 * (x * z + w * y), 2 * (y * z - w * x), 2 * (w * w + z * z) - 1]])
+    return S @ v
+
+
+def estimator_step(meas, filt, u, dt=0.015, use_lpf=True, delay=0.06, steps=4):
+    """One predictor() call for one vehicle.  meas = [x y z roll pitch yaw (deg, as published)
+    wx wy wz]; filt = [p_prev(3), v1(3), v2(3)] is updated in place.  Returns (x_est, x_pred)."""
+    phi, theta, psi = np.deg2rad(meas[3]), np.deg2rad(-meas[4]), np.deg2rad(meas[5])   # :493-496 pitch flip
+    q = euler2quatern(phi, theta, psi)
+    q = q / np.linalg.norm(q)                                                            # :546
+    ve = np.zeros(3)
+    for a in range(3):
+        pk, pk1, v1, v2 = meas[a], filt[a], filt[3 + a], filt[6 + a]
+        ve[a] = 0.3306 * v1 - 0.02732 * v2 + 35.7 * pk - 35.7 * pk1 if use_lpf else (pk - pk1) / dt   # :356-368
+        filt[a], filt[6 + a], filt[3 + a] = pk, v1, ve[a]
+    x_est = np.concatenate([meas[0:3], q, rotate_e2b(q, ve), meas[6:9]])
+    return x_est, rk4(x_est, u, dt=delay, steps=steps)

@@ -147,3 +147,36 @@ def test_device_pointers_and_repeated_solves(oracle):
     assert np.array_equal(u_dev.cpu().numpy(), b.get_u(0))
     xa, ua = a.get_iterate(); xb, ub = b.get_iterate()
     assert np.array_equal(xa, xb) and np.array_equal(ua, ub)
+
+
+def test_mixed_horizon_fleet_config5(oracle, cref):
+    """Config C5: N in {30, 50, 100} equiprobable, regulation targets U(-1,1)^2 x U(0.2,1), x0
+    delay-compensated by the predictor (RK4 over 60 ms with the previous inputs); outputs u0, u1, x4
+    (acados_mpc.cpp:619-625) against the CPU restatement, bucket by bucket."""
+    from crazyflie_nmpc_amd import sim
+    from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(20200105)
+    B = 90
+    horizons = rng.choice([30, 50, 100], size=B)
+    targets = np.stack([rng.uniform(-1, 1, B), rng.uniform(-1, 1, B), rng.uniform(0.2, 1.0, B)], axis=1)
+    x_meas = oracle.sample_hover_x0(rng, B)
+    x_meas[:, :3] += targets - [0, 0, 0.4]
+    x0 = sim(x_meas, np.full((B, 4), HOV), T=0.06, steps=4)        # delay compensation (launch: delay = 0.06)
+    fleet = MixedHorizonFleet(horizons, tol=1e-11)
+    fleet.set_regulation(targets, HOV)
+    fleet.set_x0(x0); fleet.init_iterate(INIT_HOVER)
+    fleet.solve(1)
+    st, it, _ = fleet.stats()
+    assert (st == 0).all()
+    u0, u1, x4 = fleet.get_u(0), fleet.get_u(1), fleet.get_x(4)
+    for N in (30, 50, 100):
+        idx = np.where(horizons == N)[0]
+        n = len(idx)
+        assert n > 10
+        rows = np.stack([np.concatenate([targets[i], [1, 0, 0, 0, 0, 0, 0, 0, 0, 0], np.full(4, HOV)]) for i in idx])
+        yref = np.repeat(rows[:, None, :], N, 1).copy(); yref_e = rows[:, :13].copy()
+        xr = np.repeat(x0[idx, None, :], N + 1, 1).copy(); ur = np.full((n, N, 4), HOV)
+        cref.rti_step(cref.default_opts(N=int(N), tol=1e-11), xr, ur, x0[idx].copy(), yref, yref_e, nthreads=0)
+        assert np.abs(u0[idx] - ur[:, 0]).max() < 1e-7 and np.abs(u1[idx] - ur[:, 1]).max() < 1e-7
+        assert np.abs(x4[idx] - xr[:, 4]).max() < 1e-7

@@ -181,3 +181,33 @@ def test_device_reference_windows_match_node_state_machine():
         assert np.array_equal(s.get_u(0), out["u0"]) and np.array_equal(s.get_x(4), out["x4"]), k
         x = sim(x, out["u0"], T=0.015, steps=1)
     assert (nm.policy == 2).sum() >= 3                        # the hand-over to Position_Hold happened
+
+
+def test_estimator_state_assembly_and_predictor_match_oracle(oracle):
+    """cfnmpc_estimate == numpy restatement of ESTIMATOR::predictor over several timer ticks
+    (filter state carried), for both velocity branches."""
+    import torch
+    from crazyflie_nmpc_amd import estimate
+    rng = np.random.default_rng(31)
+    B = 300
+    dev = torch.device("cuda", 0)
+    for use_lpf in (True, False):
+        filt = np.concatenate([rng.uniform(-1, 1, (B, 3)), rng.uniform(-0.5, 0.5, (B, 6))], axis=1)
+        filt_d = torch.from_numpy(filt.copy()).to(dev)
+        pos = filt[:, :3].copy()
+        for tick in range(4):
+            pos = pos + rng.uniform(-0.01, 0.01, (B, 3))
+            meas = np.concatenate([pos, rng.uniform(-25, 25, (B, 3)), rng.uniform(-2, 2, (B, 3))], axis=1)
+            if tick == 0:
+                meas[0, 3:6] = [170.0, -40.0, 175.0]          # exercises the w < 0 sign flip
+            u = rng.uniform(5, 20, (B, 4))
+            xe, xp = estimate(torch.from_numpy(meas).to(dev), filt_d, torch.from_numpy(u).to(dev), dt=0.015,
+                              use_lpf=use_lpf, delay=0.06, steps=4)
+            xe, xp = xe.cpu().numpy(), xp.cpu().numpy()
+            for i in range(0, B, 7):
+                we, wp = oracle.estimator_step(meas[i], filt[i], u[i], 0.015, use_lpf, 0.06, 4)
+                assert np.abs(xe[i] - we).max() < 1e-12 and np.abs(xp[i] - wp).max() < 1e-12
+                assert abs(np.linalg.norm(xe[i, 3:7]) - 1) < 1e-14 and xe[i, 3] >= 0
+            ok = np.arange(0, B, 7)
+            assert np.abs(filt_d.cpu().numpy()[ok] - filt[ok]).max() < 1e-13
+            filt = filt_d.cpu().numpy().copy()               # keep host copy in sync for untested rows
