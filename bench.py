@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--active-horizon", type=int, default=1)
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="nccl = RCCL over xGMI (default); gloo only for functional checks of the N > 1 path on "
+                         "a box with fewer GPUs than ranks (ranks then share devices)")
     ap.add_argument("--workload", choices=["hover", "figure8"], default="hover",
                     help="hover = config C3 (the metric's configuration); figure8 = config C4 tracking with "
                          "device-side reference windows")
@@ -122,14 +125,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     dist = None
+    red_dev = dev  # device of the tiny reduction tensors
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            red_dev = torch.device("cpu")
 
     from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
     from crazyflie_nmpc_amd.synthetic import regulation_row, sample_hover_x0 as sample_x0
@@ -228,7 +239,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -252,7 +263,7 @@ def main():
         ms_qp += b_
 
     stats = torch.tensor([float((st == 0).sum()), float((st != 0).sum()), float(it.sum()), float((it > 0).sum()),
-                          float(heads.sum()), ms_lin, ms_qp], dtype=torch.float64, device=dev)
+                          float(heads.sum()), ms_lin, ms_qp], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)   # RCCL: aggregate reporting only
     stats = stats.cpu().numpy()
