@@ -215,28 +215,45 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
     const double h = P.dt;
     const int N = P.N;
 
-    // cooperative load of one 13-vector field block row (stage k of xit) into sx
-    auto load_x = [&](int k) {
-        for (int e = tid; e < nblk * 52; e += 64) {
+    // Cooperative transfers between the wave-blocked layout and the LDS tiles.  Trip counts are
+    // compile-time (16 blocks x 4 instances x NS lanes = 64 x NS elements) and the loops fully
+    // unrolled, so that all loads / LDS reads of a transfer are in flight together.  The ragged
+    // last workgroup needs no masks: its phantom instances read clamped (finite) data and their
+    // rows go to the spare workspace block NW.
+    const int lim13 = nblk * 52;
+    auto issue_x = [&](int k, int tl, double (&xr)[13]) {  // stage k of xit -> registers (no wait)
+        SFOR(r, 0, 13, {
+            const int e = imin(tl + 64 * r, lim13 - 1);
             const int bk = e / 52, off = e - bk * 52;
-            sx[e] = gm(P.xit)[((size_t)(w0 + bk) * (N + 1) + k) * SZ_V13 + off];
-        }
+            xr[r] = gm(P.xit)[((size_t)(w0 + bk) * (N + 1) + k) * SZ_V13 + off];
+        });
     };
-    double xn[13];  // x_{k+1} in EXTERNAL order
-    load_x(0);
-    __syncthreads();
-    SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
+    auto land_x = [&](const double (&xr)[13]) {
+        SFOR(r, 0, 13, { sx[tid + 64 * r] = xr[r]; });
+    };
+    auto issue_u = [&](int k, double (&u)[4]) {
+        const gdouble* up = gm(P.uit) + ((size_t)imin(inst, P.NW * 4 - 1) * N + k) * 4;
+        SFOR(a, 0, 4, { u[a] = up[a]; });
+    };
+    double xn[13], un[4];  // x_k in EXTERNAL order and u_k on entry to stage k
+    {
+        double xr[13];
+        issue_x(0, tid, xr);
+        land_x(xr);
+        issue_u(0, un);
+        __syncthreads();
+        SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
+        __syncthreads();
+        issue_x(1, tid, xr);
+        land_x(xr);   // sx holds x_{k+1} on entry to stage k
+        __syncthreads();
+    }
     for (int k = 0; k < N; k++) {
         double x[13], u[4];
         SFOR(e, 0, 13, { x[e] = xn[e]; });
-        {
-            const gdouble* up = gm(P.uit) + ((size_t)imin(inst, P.NW * 4 - 1) * N + k) * 4;
-            SFOR(a, 0, 4, { u[a] = up[a]; });
-        }
-        __syncthreads();
-        load_x(k + 1);
-        __syncthreads();
-        SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
+        SFOR(a, 0, 4, { u[a] = un[a]; });
+        int tl = tid;  // opaque per-stage copy: keeps the 162 store offsets from being hoisted out of the
+        asm volatile("" : "+v"(tl));  // stage loop (they would occupy ~160 registers for its whole length)
         // nominal RK4 (classic tableau, one step per interval)
         double xt[13], k1[13], k2[13], k3[13], k4[13];
         JacPoint J[4];
@@ -251,32 +268,49 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
         SFOR(e, 0, 13, { xt[e] = x[e] + h * k3[e]; });
         f_expl(xt, u, k4);
         jac_point(xt, J[3]);
+        SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
         // b = Phi - x_{k+1} through the tile (internal order)
-        __syncthreads();
         SFOR(r, 0, 13, {
             constexpr int e = ext_of(r);
             const double phi = x[e] + (h / 6.0) * (k1[e] + 2 * k2[e] + 2 * k3[e] + k4[e]);
             sc[0][tid * 13 + r] = phi - xn[e];
         });
         __syncthreads();
-        for (int e = tid; e < nblk * 52; e += 64) {
-            const int bk = e / 52, off = e - bk * 52;
-            gm(P.b)[((size_t)(w0 + bk) * N + k) * SZ_V13 + off] = sc[0][e];
-        }
-        // store `cnt` rows of column tile `ti` into AR slot `sl` / BR column `a`
-        auto store_ar = [&](int ti, int sl, int n_s, int pre) {
-            for (int e = tid; e < nblk * 4 * n_s; e += 64) {
-                const int bk = e / (4 * n_s), off = e - bk * 4 * n_s;
-                const int q = off / n_s, i = off - q * n_s;
-                gm(P.AR)[((size_t)(w0 + bk) * N + k) * SZ_A + 4 * pre + off] = sc[ti][(bk * 4 + q) * 13 + i];
-            }
-        };
-        auto store_br = [&](int ti, int a) {
-            for (int e = tid; e < nblk * 52; e += 64) {
+        {
+            double tv[13];
+            SFOR(r, 0, 13, { tv[r] = sc[0][tl + 64 * r]; });
+            SFOR(r, 0, 13, {
+                const int e = tl + 64 * r;
                 const int bk = e / 52, off = e - bk * 52;
-                gm(P.BR)[((size_t)(w0 + bk) * N + k) * SZ_B + a * 52 + off] = sc[ti][e];
-            }
-        };
+                gm(P.b)[((size_t)imin(w0 + bk, P.NW) * N + k) * SZ_V13 + off] = tv[r];
+            });
+        }
+        // rows < NS of column tile `ti` -> AR slot with prefix `pre` (NS = ar_n(slot))
+#define CFN_STORE_AR(ti, NS, pre)                                                                       \
+    {                                                                                                   \
+        double tv[NS];                                                                                  \
+        SFOR(r, 0, NS, {                                                                                \
+            const int e = tl + 64 * r;                                                                 \
+            const int bk = e / (4 * (NS)), off = e - bk * 4 * (NS);                                     \
+            const int q = off / (NS), i = off - q * (NS);                                               \
+            tv[r] = sc[ti][(bk * 4 + q) * 13 + i];                                                      \
+        });                                                                                             \
+        SFOR(r, 0, NS, {                                                                                \
+            const int e = tl + 64 * r;                                                                 \
+            const int bk = e / (4 * (NS)), off = e - bk * 4 * (NS);                                     \
+            gm(P.AR)[((size_t)imin(w0 + bk, P.NW) * N + k) * SZ_A + 4 * (pre) + off] = tv[r];          \
+        });                                                                                             \
+    }
+#define CFN_STORE_BR(ti, a)                                                                             \
+    {                                                                                                   \
+        double tv[13];                                                                                  \
+        SFOR(r, 0, 13, { tv[r] = sc[ti][tl + 64 * r]; });                                              \
+        SFOR(r, 0, 13, {                                                                                \
+            const int e = tl + 64 * r;                                                                 \
+            const int bk = e / 52, off = e - bk * 52;                                                   \
+            gm(P.BR)[((size_t)imin(w0 + bk, P.NW) * N + k) * SZ_B + (a) * 52 + off] = tv[r];            \
+        });                                                                                             \
+    }
         double col[13];
         // state columns in internal order: v (internal 3..5 = external 7..9), q (6..9 = 3..6), w (10..12)
         __syncthreads();
@@ -287,7 +321,7 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
             SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
         }
         __syncthreads();
-        SFOR(j, 0, 3, { store_ar(j, j, ar_n(j), ar_pre(j)); });
+        SFOR(j, 0, 3, { CFN_STORE_AR(j, ar_n(j), ar_pre(j)); });
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < 4; j++) {  // quaternion columns: rows p, v, q
@@ -295,7 +329,7 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
             SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
         }
         __syncthreads();
-        SFOR(j, 0, 4, { store_ar(j, 3 + j, ar_n(3 + j), ar_pre(3 + j)); });
+        SFOR(j, 0, 4, { CFN_STORE_AR(j, ar_n(3 + j), ar_pre(3 + j)); });
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < 3; j++) {  // rate columns: all rows
@@ -303,15 +337,23 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
             SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
         }
         __syncthreads();
-        SFOR(j, 0, 3, { store_ar(j, 7 + j, ar_n(7 + j), ar_pre(7 + j)); });
+        SFOR(j, 0, 3, { CFN_STORE_AR(j, ar_n(7 + j), ar_pre(7 + j)); });
         __syncthreads();
 #pragma unroll 1
         for (int a = 0; a < 4; a++) {  // input columns: all rows
             sens_column<true, true, true>(J, u, a, h, col);
             SFOR(r, 0, 13, { sc[a][tid * 13 + r] = col[ext_of(r)]; });
         }
+        // next stage's inputs: in flight while the input columns drain (few live registers here)
+        double xr[13];
+        issue_x(imin(k + 2, N), tl, xr);
+        issue_u(imin(k + 1, N - 1), un);
         __syncthreads();
-        SFOR(a, 0, 4, { store_br(a, a); });
+        SFOR(a, 0, 4, { CFN_STORE_BR(a, a); });
+        land_x(xr);
+        __syncthreads();
+#undef CFN_STORE_AR
+#undef CFN_STORE_BR
     }
 }
 
