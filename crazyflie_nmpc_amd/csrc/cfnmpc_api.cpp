@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -22,8 +23,17 @@ struct cfnmpc_solver {
     unsigned long long bytes;
     // optional per-kernel timing with HIP events on the launch stream (cfnmpc_set_profiling)
     int profiling;
-    std::vector<hipEvent_t> ev;  // triples (before linearise, between, after qp), one per RTI step
+    std::vector<hipEvent_t> ev;  // triples (start, between the two phases, end), one per RTI step
     size_t ev_used;
+    // preparation-phase overlap (cfnmpc_opts.overlap_linearise): the linearisation for the NEXT
+    // step is written to the alternate (AR, BR, b) set while the interior-point kernel still
+    // reads the current one
+    int overlap;
+    double *AR2, *BR2, *b2;
+    hipStream_t aux;             // low-priority stream of the early linearisation pass
+    hipEvent_t ev_start, ev_aux; // start solve done (on the caller's stream) / early pass done (on aux)
+    bool lin_valid;              // (P.AR, P.BR, P.b) hold the linearisation of the current iterate
+    int chunks_all, chunks_list; // workgroups per 64-instance group in the two linearisation passes
 };
 
 namespace {
@@ -110,6 +120,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->active_horizon = 1;
     o->ah_margin = 0.10;
     o->ah_extra = 4;
+    o->overlap_linearise = 1;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
@@ -128,6 +139,17 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     s->bytes = 0;
     s->profiling = 0;
     s->ev_used = 0;
+    s->overlap = o.overlap_linearise ? 1 : 0;
+    s->AR2 = s->BR2 = s->b2 = nullptr;
+    s->aux = nullptr;
+    s->ev_start = s->ev_aux = nullptr;
+    s->lin_valid = false;
+    s->chunks_all = s->overlap ? 5 : 1;
+    s->chunks_list = 10;
+    if (const char* e = std::getenv("CFNMPC_LIN_CHUNKS")) {   // development aid
+        int a = 0, b = 0;
+        if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { s->chunks_all = a; s->chunks_list = b; }
+    }
     if (hipGetDevice(&s->device) != hipSuccess) { delete s; return CFNMPC_EHIP; }
     cfn::Params& P = s->P;
     std::memset(&P, 0, sizeof P);
@@ -159,6 +181,17 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(cv, NW * 4 * N * 4); ALLOC(cuit, NW * 4 * N * 4);
     ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4); ALLOC(viol, NW * 4);
     ALLOC(ilist, NW * 4); ALLOC(nipm, 4);
+    if (s->overlap) {
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->AR2, NW * N * cfn::SZ_A);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->BR2, NW * N * cfn::SZ_B);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->b2, NW * N * cfn::SZ_V13);
+        int lo = 0, hi = 0;  // lo = least priority (numerically greatest)
+        if (rc == CFNMPC_OK && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+                                hipStreamCreateWithPriority(&s->aux, hipStreamNonBlocking, lo) != hipSuccess ||
+                                hipEventCreateWithFlags(&s->ev_start, hipEventDisableTiming) != hipSuccess ||
+                                hipEventCreateWithFlags(&s->ev_aux, hipEventDisableTiming) != hipSuccess))
+            rc = CFNMPC_EHIP;
+    }
 #undef ALLOC
     s->stage_doubles = (size_t)batch * (N + 1) * 17;
     if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->stage_buf, s->stage_doubles);
@@ -172,6 +205,9 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
 
 int cfnmpc_free(cfnmpc_solver* s) {
     if (!s) return CFNMPC_EINVAL;
+    if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
+    if (s->ev_start) (void)hipEventDestroy(s->ev_start);
+    if (s->ev_aux) (void)hipEventDestroy(s->ev_aux);
     for (void* p : s->allocs) (void)hipFree(p);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     delete s;
@@ -217,11 +253,13 @@ int cfnmpc_init_iterate(cfnmpc_solver* s, int mode, void* stream) {
     if (!s || (mode != CFNMPC_INIT_ACADOS && mode != CFNMPC_INIT_HOVER)) return CFNMPC_EINVAL;
     cfn::launch_init_iterate(s->P, mode, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    s->lin_valid = false;
     return CFNMPC_OK;
 }
 
 int cfnmpc_set_iterate(cfnmpc_solver* s, const double* x, const double* u, int on_device, void* stream) {
     if (!s || !x || !u) return CFNMPC_EINVAL;
+    s->lin_valid = false;
     int rc = put_field(s, x, on_device, s->P.N + 1, 13, 1, s->P.xit, (hipStream_t)stream);
     if (rc != CFNMPC_OK) return rc;
     return put_field(s, u, on_device, s->P.N, 4, 0, s->P.uit, (hipStream_t)stream);
@@ -247,12 +285,38 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
             }
             e = &s->ev[s->ev_used];
             s->ev_used += 3;
-            HIP_TRY(hipEventRecord(e[0], st));
         }
-        cfn::launch_linearise(s->P, st);
+        if (!s->overlap) {
+            // linearise -> QP, everything on the caller's stream
+            if (e) HIP_TRY(hipEventRecord(e[0], st));
+            cfn::launch_linearise(s->P, s->chunks_all, st);
+            if (e) HIP_TRY(hipEventRecord(e[1], st));
+            cfn::launch_qp(s->P, st);
+            if (e) HIP_TRY(hipEventRecord(e[2], st));
+            s->lin_valid = false;   // the iterate moved
+            continue;
+        }
+        // feedback phase on the linearisation prepared by the previous step ...
+        if (!s->lin_valid) cfn::launch_linearise(s->P, s->chunks_all, st);
+        if (e) HIP_TRY(hipEventRecord(e[0], st));
+        cfn::launch_qp_start(s->P, st);
+        HIP_TRY(hipEventRecord(s->ev_start, st));
+        cfn::launch_qp_ipm(s->P, st);
         if (e) HIP_TRY(hipEventRecord(e[1], st));
-        cfn::launch_qp(s->P, st);
+        // ... and preparation of the next step into the alternate set: an early pass over ALL
+        // instances runs beside the interior-point kernel (the instances still inside it are
+        // linearised around a stale iterate there and redone by the list pass afterwards)
+        cfn::Params Q = s->P;
+        Q.AR = s->AR2; Q.BR = s->BR2; Q.b = s->b2;
+        HIP_TRY(hipStreamWaitEvent(s->aux, s->ev_start, 0));
+        cfn::launch_linearise(Q, s->chunks_all, s->aux);
+        HIP_TRY(hipEventRecord(s->ev_aux, s->aux));
+        HIP_TRY(hipStreamWaitEvent(st, s->ev_aux, 0));
+        cfn::launch_linearise_list(Q, s->chunks_list, st);
         if (e) HIP_TRY(hipEventRecord(e[2], st));
+        s->AR2 = s->P.AR; s->BR2 = s->P.BR; s->b2 = s->P.b;
+        s->P.AR = Q.AR; s->P.BR = Q.BR; s->P.b = Q.b;
+        s->lin_valid = true;
     }
     HIP_TRY(hipGetLastError());
     return CFNMPC_OK;
@@ -335,8 +399,8 @@ int cfnmpc_get_profile(cfnmpc_solver* s, double* ms_linearise, double* ms_qp, in
         HIP_TRY(hipEventSynchronize(s->ev[3 * i + 2]));
         HIP_TRY(hipEventElapsedTime(&t0, s->ev[3 * i], s->ev[3 * i + 1]));
         HIP_TRY(hipEventElapsedTime(&t1, s->ev[3 * i + 1], s->ev[3 * i + 2]));
-        a += t0;
-        b += t1;
+        a += s->overlap ? t1 : t0;   // overlap: the QP phase comes first, then the exposed linearisation
+        b += s->overlap ? t0 : t1;
     }
     *ms_linearise = n ? a / n : 0.0;
     *ms_qp = n ? b / n : 0.0;
@@ -345,10 +409,16 @@ int cfnmpc_get_profile(cfnmpc_solver* s, double* ms_linearise, double* ms_qp, in
     return CFNMPC_OK;
 }
 
+#ifdef CFN_PROF
+extern "C++" { namespace cfn { void debug_prof_read(unsigned long long* out, int reset); } }
+int cfnmpc_debug_prof(unsigned long long* out, int reset) { (void)hipDeviceSynchronize(); cfn::debug_prof_read(out, reset); return 0; }
+#endif
+
 int cfnmpc_debug_linearise(cfnmpc_solver* s, void* stream) {
     if (!s) return CFNMPC_EINVAL;
-    cfn::launch_linearise(s->P, (hipStream_t)stream);
+    cfn::launch_linearise(s->P, s->chunks_all, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    s->lin_valid = true;
     return CFNMPC_OK;
 }
 

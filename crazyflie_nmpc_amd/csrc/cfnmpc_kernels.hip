@@ -112,6 +112,9 @@ __device__ __forceinline__ void opaque(double& x) { asm volatile("" : "+v"(x)); 
 // a value produced by one of the asm primitives of cfnmpc_dpp.hpp is about to be read through
 // DPP by compiler-generated code (bc<>): give it the two wait states hipcc cannot know about
 __device__ __forceinline__ void settle(double& x) { asm volatile("s_nop 1" : "+v"(x)); }
+// makes a value live in every lane at this point (stops the compiler from sinking the load that
+// produced it into a divergent branch)
+__device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
 // instance-major 4-vectors (interior-point state, inputs): [inst][stage][4]
 __device__ __forceinline__ size_t i4(const Params& P, const Lane& t, int k, int a) {
     return ((size_t)t.inst * P.N + k) * 4 + a;
@@ -203,114 +206,110 @@ __device__ __forceinline__ void sens_column(const JacPoint (&J)[4], const double
 }
 
 // Lane-per-instance (work-efficient: nothing is computed twice); one workgroup = one wavefront
-// = 64 instances = 16 workspace blocks.  All traffic to the wave-blocked layout goes through
-// LDS tiles so that every global load / store instruction covers contiguous runs.
-__global__ __launch_bounds__(64) void k_linearise(Params P) {
-    __shared__ double sx[16 * 52];       // one 13-vector per instance, [block][q][13] (internal order)
-    __shared__ double sc[4][64 * 13];    // up to four sensitivity columns, [inst][row] (internal order)
+// = 64 instances, blockIdx.y = a chunk of the (mutually independent) shooting intervals.  All
+// traffic to the wave-blocked layout goes through LDS tiles so that every global load / store
+// instruction covers contiguous runs (13 / ar_n doubles per instance).
+//   GATHER = false: instances 64 g .. 64 g + 63 (16 consecutive workspace blocks);
+//   GATHER = true : the instances P.ilist[64 g ..] (the interior-point instances of this step,
+//                   whose iterate only became final after the early pass over everybody).
+// Lanes without an instance work on the spare workspace block NW (finite data, never read).
+template <bool GATHER>
+__device__ __forceinline__ void linearise_body(const Params& P, double* sx, double (*sc)[64 * 13], int* sinst) {
     const int tid = threadIdx.x;
-    const int w0 = blockIdx.x * 16;      // first workspace block of this workgroup
-    const int nblk = min(16, P.NW - w0); // valid blocks
-    const int inst = blockIdx.x * 64 + tid;
     const double h = P.dt;
     const int N = P.N;
+    {
+        const int li = blockIdx.x * 64 + tid;
+        int inst;
+        if (GATHER) inst = li < gm(P.nipm)[0] ? gm(P.ilist)[li] : P.NW * 4 + (tid & 3);
+        else inst = li < P.NW * 4 ? li : P.NW * 4 + (tid & 3);
+        sinst[tid] = inst;
+    }
+    __syncthreads();
+    const int inst = sinst[tid];
+    const int per = (N + gridDim.y - 1) / gridDim.y;
+    const int k0 = blockIdx.y * per, k1 = imin(N, k0 + per);
+    if (k0 >= k1) return;
 
-    // Cooperative transfers between the wave-blocked layout and the LDS tiles.  Trip counts are
-    // compile-time (16 blocks x 4 instances x NS lanes = 64 x NS elements) and the loops fully
-    // unrolled, so that all loads / LDS reads of a transfer are in flight together.  The ragged
-    // last workgroup needs no masks: its phantom instances read clamped (finite) data and their
-    // rows go to the spare workspace block NW.
-    const int lim13 = nblk * 52;
+    // element offset of (local instance li, lane i) in a field with `stages` stages per block, SZ
+    // doubles per (block, stage), NS lanes per instance starting at `pre4` inside the block
+    auto at = [&](int li, int i, int stages, int k, int SZ, int pre4, int NS) -> size_t {
+        const int in = sinst[li];
+        return ((size_t)(in >> 2) * stages + k) * SZ + pre4 + (in & 3) * NS + i;
+    };
+    // Trip counts are compile-time (64 instances x NS lanes) and the loops fully unrolled, so that
+    // all loads / LDS reads of a transfer are in flight together.
     auto issue_x = [&](int k, int tl, double (&xr)[13]) {  // stage k of xit -> registers (no wait)
         SFOR(r, 0, 13, {
-            const int e = imin(tl + 64 * r, lim13 - 1);
-            const int bk = e / 52, off = e - bk * 52;
-            xr[r] = gm(P.xit)[((size_t)(w0 + bk) * (N + 1) + k) * SZ_V13 + off];
+            const int e = tl + 64 * r;
+            const int li = e / 13, i = e - li * 13;
+            xr[r] = gm(P.xit)[at(li, i, N + 1, k, SZ_V13, 0, 13)];
         });
     };
     auto land_x = [&](const double (&xr)[13]) {
         SFOR(r, 0, 13, { sx[tid + 64 * r] = xr[r]; });
     };
     auto issue_u = [&](int k, double (&u)[4]) {
-        const gdouble* up = gm(P.uit) + ((size_t)imin(inst, P.NW * 4 - 1) * N + k) * 4;
+        const gdouble* up = gm(P.uit) + ((size_t)inst * N + k) * 4;
         SFOR(a, 0, 4, { u[a] = up[a]; });
     };
     double xn[13], un[4];  // x_k in EXTERNAL order and u_k on entry to stage k
     {
         double xr[13];
-        issue_x(0, tid, xr);
+        issue_x(k0, tid, xr);
         land_x(xr);
-        issue_u(0, un);
+        issue_u(k0, un);
         __syncthreads();
         SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
         __syncthreads();
-        issue_x(1, tid, xr);
+        issue_x(k0 + 1, tid, xr);
         land_x(xr);   // sx holds x_{k+1} on entry to stage k
         __syncthreads();
     }
-    for (int k = 0; k < N; k++) {
+    for (int k = k0; k < k1; k++) {
         double x[13], u[4];
         SFOR(e, 0, 13, { x[e] = xn[e]; });
         SFOR(a, 0, 4, { u[a] = un[a]; });
         int tl = tid;  // opaque per-stage copy: keeps the 162 store offsets from being hoisted out of the
         asm volatile("" : "+v"(tl));  // stage loop (they would occupy ~160 registers for its whole length)
         // nominal RK4 (classic tableau, one step per interval)
-        double xt[13], k1[13], k2[13], k3[13], k4[13];
+        double xt[13], k1v[13], k2v[13], k3v[13], k4v[13];
         JacPoint J[4];
-        f_expl(x, u, k1);
+        f_expl(x, u, k1v);
         jac_point(x, J[0]);
-        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k1[e]; });
-        f_expl(xt, u, k2);
+        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k1v[e]; });
+        f_expl(xt, u, k2v);
         jac_point(xt, J[1]);
-        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k2[e]; });
-        f_expl(xt, u, k3);
+        SFOR(e, 0, 13, { xt[e] = x[e] + 0.5 * h * k2v[e]; });
+        f_expl(xt, u, k3v);
         jac_point(xt, J[2]);
-        SFOR(e, 0, 13, { xt[e] = x[e] + h * k3[e]; });
-        f_expl(xt, u, k4);
+        SFOR(e, 0, 13, { xt[e] = x[e] + h * k3v[e]; });
+        f_expl(xt, u, k4v);
         jac_point(xt, J[3]);
         SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
         // b = Phi - x_{k+1} through the tile (internal order)
         SFOR(r, 0, 13, {
             constexpr int e = ext_of(r);
-            const double phi = x[e] + (h / 6.0) * (k1[e] + 2 * k2[e] + 2 * k3[e] + k4[e]);
+            const double phi = x[e] + (h / 6.0) * (k1v[e] + 2 * k2v[e] + 2 * k3v[e] + k4v[e]);
             sc[0][tid * 13 + r] = phi - xn[e];
         });
         __syncthreads();
-        {
-            double tv[13];
-            SFOR(r, 0, 13, { tv[r] = sc[0][tl + 64 * r]; });
-            SFOR(r, 0, 13, {
-                const int e = tl + 64 * r;
-                const int bk = e / 52, off = e - bk * 52;
-                gm(P.b)[((size_t)imin(w0 + bk, P.NW) * N + k) * SZ_V13 + off] = tv[r];
-            });
-        }
-        // rows < NS of column tile `ti` -> AR slot with prefix `pre` (NS = ar_n(slot))
-#define CFN_STORE_AR(ti, NS, pre)                                                                       \
+        // rows < NS of column tile `ti` -> `field` (SZ doubles per block and stage) at `pre4`
+#define CFN_STORE(field, SZ, ti, NS, pre4)                                                              \
     {                                                                                                   \
         double tv[NS];                                                                                  \
         SFOR(r, 0, NS, {                                                                                \
-            const int e = tl + 64 * r;                                                                 \
-            const int bk = e / (4 * (NS)), off = e - bk * 4 * (NS);                                     \
-            const int q = off / (NS), i = off - q * (NS);                                               \
-            tv[r] = sc[ti][(bk * 4 + q) * 13 + i];                                                      \
+            const int e = tl + 64 * r;                                                                  \
+            const int li = e / (NS), i = e - li * (NS);                                                 \
+            tv[r] = sc[ti][li * 13 + i];                                                                \
         });                                                                                             \
         SFOR(r, 0, NS, {                                                                                \
-            const int e = tl + 64 * r;                                                                 \
-            const int bk = e / (4 * (NS)), off = e - bk * 4 * (NS);                                     \
-            gm(P.AR)[((size_t)imin(w0 + bk, P.NW) * N + k) * SZ_A + 4 * (pre) + off] = tv[r];          \
+            const int e = tl + 64 * r;                                                                  \
+            const int li = e / (NS), i = e - li * (NS);                                                 \
+            gm(field)[at(li, i, N, k, SZ, pre4, NS)] = tv[r];                                           \
         });                                                                                             \
     }
-#define CFN_STORE_BR(ti, a)                                                                             \
-    {                                                                                                   \
-        double tv[13];                                                                                  \
-        SFOR(r, 0, 13, { tv[r] = sc[ti][tl + 64 * r]; });                                              \
-        SFOR(r, 0, 13, {                                                                                \
-            const int e = tl + 64 * r;                                                                 \
-            const int bk = e / 52, off = e - bk * 52;                                                   \
-            gm(P.BR)[((size_t)imin(w0 + bk, P.NW) * N + k) * SZ_B + (a) * 52 + off] = tv[r];            \
-        });                                                                                             \
-    }
+        CFN_STORE(P.b, SZ_V13, 0, 13, 0);
         double col[13];
         // state columns in internal order: v (internal 3..5 = external 7..9), q (6..9 = 3..6), w (10..12)
         __syncthreads();
@@ -321,7 +320,7 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
             SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
         }
         __syncthreads();
-        SFOR(j, 0, 3, { CFN_STORE_AR(j, ar_n(j), ar_pre(j)); });
+        SFOR(j, 0, 3, { CFN_STORE(P.AR, SZ_A, j, ar_n(j), 4 * ar_pre(j)); });
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < 4; j++) {  // quaternion columns: rows p, v, q
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
             SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
         }
         __syncthreads();
-        SFOR(j, 0, 4, { CFN_STORE_AR(j, ar_n(3 + j), ar_pre(3 + j)); });
+        SFOR(j, 0, 4, { CFN_STORE(P.AR, SZ_A, j, ar_n(3 + j), 4 * ar_pre(3 + j)); });
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < 3; j++) {  // rate columns: all rows
@@ -337,7 +336,7 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
             SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
         }
         __syncthreads();
-        SFOR(j, 0, 3, { CFN_STORE_AR(j, ar_n(7 + j), ar_pre(7 + j)); });
+        SFOR(j, 0, 3, { CFN_STORE(P.AR, SZ_A, j, ar_n(7 + j), 4 * ar_pre(7 + j)); });
         __syncthreads();
 #pragma unroll 1
         for (int a = 0; a < 4; a++) {  // input columns: all rows
@@ -349,12 +348,24 @@ __global__ __launch_bounds__(64) void k_linearise(Params P) {
         issue_x(imin(k + 2, N), tl, xr);
         issue_u(imin(k + 1, N - 1), un);
         __syncthreads();
-        SFOR(a, 0, 4, { CFN_STORE_BR(a, a); });
+        SFOR(a, 0, 4, { CFN_STORE(P.BR, SZ_B, a, 13, a * 52); });
         land_x(xr);
         __syncthreads();
-#undef CFN_STORE_AR
-#undef CFN_STORE_BR
+#undef CFN_STORE
     }
+}
+__global__ __launch_bounds__(64) void k_linearise(Params P) {
+    __shared__ double sx[64 * 13];       // one 13-vector per instance (internal order)
+    __shared__ double sc[4][64 * 13];    // up to four sensitivity columns, [inst][row] (internal order)
+    __shared__ int sinst[64];
+    linearise_body<false>(P, sx, sc, sinst);
+}
+__global__ __launch_bounds__(64) void k_linearise_list(Params P) {
+    __shared__ double sx[64 * 13];
+    __shared__ double sc[4][64 * 13];
+    __shared__ int sinst[64];
+    if ((int)blockIdx.x * 64 >= gm(P.nipm)[0]) return;
+    linearise_body<true>(P, sx, sc, sinst);
 }
 
 // =============================================================================================
@@ -475,10 +486,11 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         SFOR(a, 0, 4, { sb[a * 16 + t.L] = br[a]; });
     }
     __syncthreads();
-    SFOR(l, 0, 13, {   // lanes 14, 15 carry don't-care values from here on (never broadcast)
-        const double w = wt[imin(t.L, 12) * 17 + l];
-        Wt[l] = t.L == 13 ? Pa[l] : w;
-    });
+    // (all 13 reads issued unconditionally, then pinned: otherwise the compiler sinks every
+    //  read into its own branch on "lane != 13")
+    SFOR(l, 0, 13, { Wt[l] = wt[imin(t.L, 12) * 17 + l]; });
+    SFOR(l, 0, 13, { pin(Wt[l]); });
+    SFOR(l, 0, 13, { Wt[l] = t.L == 13 ? Pa[l] : Wt[l]; });   // lanes 14, 15: don't-care (never broadcast)
     // (4) M = Q + Wt A  (lane 13: q_k' + hb'A)
     double M[13];
     SFOR(j, 0, 13, { M[j] = (t.L == j) ? wq : 0.0; });
@@ -522,11 +534,11 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     });
     // (9) stores: gain in "lane a holds K[a][.]" form, Sinv, feed-forward
     {
-        gdouble* kr = blk(P.KR, t, P.N, k, SZ_K);
-        SFOR(a, 0, 4, {
-            if (t.L < 13) kr[(t.L * 4 + t.q) * 4 + a] = Kp[a];
-            if (t.L == 13) gm(P.d)[i4(P, t, k, a)] = Kp[a];
-        });
+        // lanes 0..12 store their column of the gain, lane 13 the feed-forward: one masked
+        // region with per-lane addresses
+        gdouble* kr = blk(P.KR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
+        gdouble* dst = t.L == 13 ? gm(P.d) + i4(P, t, k, 0) : kr;
+        if (t.L < 14) SFOR(a, 0, 4, { dst[a] = Kp[a]; });
         if (!ABSOLUTE && t.L == 0) {  // only the corrector of the interior-point iteration reads it
             gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S);
             SFOR(e, 0, 10, { sv[t.q * 10 + e] = Si[e]; });
@@ -892,7 +904,18 @@ __device__ __forceinline__ Elem ld_elem(const Params& P, const Lane& t, size_t i
     return e;
 }
 
+// -DCFN_PROF (development builds only, tools/ipm_phase_prof.py): phase timers of the longest wave
+#ifdef CFN_PROF
+__device__ unsigned long long g_prof[16];
+#define PROF_T(i) { const unsigned long long now_ = wall_clock64(); pacc[i] += now_ - plast; plast = now_; }
+#else
+#define PROF_T(i)
+#endif
 __global__ __launch_bounds__(64) void k_ipm(Params P) {
+#ifdef CFN_PROF
+    unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
+    const unsigned long long pstart = plast;
+#endif
     __shared__ double wtile[4][13 * 17 + 3];
     __shared__ double btile[4][64];
     const int nipm = gm(P.nipm)[0];
@@ -945,6 +968,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
     for (int attempt = 0; attempt < 3; attempt++) {
         R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
         gather(head, chk);
+        PROF_T(0)
         if (infeasible) {
             // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
             const double mu0 = fmax(P.mu0_scale * viol, P.lam0_min);
@@ -969,6 +993,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             R.status = 2;
         }
 
+        PROF_T(1)
         // ---- interior-point loop, wave-uniform trip count
         while (__any(R.act)) {
             if (R.act) {
@@ -979,8 +1004,11 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             if (!__any(R.act)) break;
             if (R.act) R.iters++;
             // predictor: factorise (R^, g from the element-wise pass), forward
+            PROF_T(1)
             const bool fok = sweep_factor<false>(Q, tc, head, chk, wt, sb);
+            PROF_T(2)
             sweep_forward_delta(Q, tc, head, gm(Q.dva));
+            PROF_T(3)
             // affine step length, mu_aff, centering; corrector right-hand side
             double smu;
             {
@@ -1018,8 +1046,11 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                 }
             }
             // corrector: re-solve, forward
+            PROF_T(4)
             sweep_resolve(Q, tc, head);
+            PROF_T(5)
             sweep_forward_delta(Q, tc, head, gm(Q.dvc));
+            PROF_T(3)
             // step, update, residuals of the new point, next R^ and g
             {
                 double a = 1.0;
@@ -1069,6 +1100,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             }
         }
 
+        PROF_T(4)
         // ---- expand: dynamics-exact roll-out; head stages use the QP inputs, tail stages the
         //      unconstrained feedback law of the start solve, whose inputs must stay inside the box
         int kviol = -1;  // last tail stage whose feedback input leaves the box
@@ -1102,6 +1134,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             st13(blk(P.dx, t, N + 1, N, SZ_V13), t, x);
             kviol = (int)row_max((double)kviol);
         }
+        PROF_T(6)
         const bool redo = t.valid && R.status != 4 && kviol >= 0 && head < N;
         if (!__any(redo)) break;
         // rare: a tail input left the box -> solve again (whole wave) over the smallest head class
@@ -1124,7 +1157,23 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         gm(P.head)[t.inst] = head;
     }
     commit_row(P, t, infeasible && R.status != 4);
+#ifdef CFN_PROF
+    PROF_T(7)
+    if (threadIdx.x == 0) {
+        const unsigned long long tot = plast - pstart;
+        const unsigned long long old = atomicMax(&g_prof[8], tot);
+        if (tot > old) for (int i = 0; i < 8; i++) g_prof[i] = pacc[i];   // (racy, development aid) phases of the longest wave
+        atomicAdd(&g_prof[9], tot);
+        atomicAdd(&g_prof[10], 1ull);
+    }
+#endif
 }
+#ifdef CFN_PROF
+void debug_prof_read(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z); }
+}
+#endif
 
 
 // =============================================================================================
@@ -1318,14 +1367,23 @@ __global__ void k_init_iterate(Params P, int mode) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-void launch_linearise(const Params& P, hipStream_t st) {
-    hipLaunchKernelGGL(k_linearise, dim3((P.NW + 15) / 16), dim3(64), 0, st, P);
+void launch_linearise(const Params& P, int chunks, hipStream_t st) {
+    hipLaunchKernelGGL(k_linearise, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P);
 }
-void launch_qp(const Params& P, hipStream_t st) {
+void launch_linearise_list(const Params& P, int chunks, hipStream_t st) {
+    hipLaunchKernelGGL(k_linearise_list, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P);
+}
+void launch_qp_start(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_forward, dim3(P.NW), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, P);
+}
+void launch_qp_ipm(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_ipm, dim3(P.NW), dim3(64), 0, st, P);
+}
+void launch_qp(const Params& P, hipStream_t st) {
+    launch_qp_start(P, st);
+    launch_qp_ipm(P, st);
 }
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st) {
     hipLaunchKernelGGL(k_sim, dim3((B + 255) / 256), dim3(256), 0, st, B, x, u, T, steps, xn);

@@ -84,8 +84,13 @@ struct Params {
     int *nipm;                   // its length
 };
 
-void launch_linearise(const Params& P, hipStream_t st);
-void launch_qp(const Params& P, hipStream_t st);
+// linearisation of all instances / of the instances in P.ilist; `chunks` = number of workgroups the
+// (independent) shooting intervals of one 64-instance group are spread over
+void launch_linearise(const Params& P, int chunks, hipStream_t st);
+void launch_linearise_list(const Params& P, int chunks, hipStream_t st);
+void launch_qp(const Params& P, hipStream_t st);        // = launch_qp_start + launch_qp_ipm
+void launch_qp_start(const Params& P, hipStream_t st);  // factor, forward (+ full step of feasible rows), compact
+void launch_qp_ipm(const Params& P, hipStream_t st);    // interior-point instances (+ their full step)
 void launch_estimate(int B, const double* meas, double* filt, const double* u, double dt, int use_lpf, double delay,
                      int steps, double* x_est, double* x_pred, hipStream_t st);
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st);

@@ -63,6 +63,12 @@ typedef struct cfnmpc_opts {
     double ah_margin;    /* active horizon: an unconstrained input closer to a bound than this
                             fraction of (u_max - u_min) counts as 'tight' (0.10)              */
     int ah_extra;        /* active horizon: stages added after the last tight stage (4)       */
+    int overlap_linearise; /* 1 (default): every RTI step ends with the PREPARATION of the next one
+                            (the RTI scheme's preparation phase: linearisation around the new
+                            iterate, which does not depend on the next x0 / yref), run on an
+                            internal low-priority stream concurrently with the latency-bound
+                            interior-point kernel; 0: linearise at the start of cfnmpc_solve.
+                            Results are bit-identical either way.                              */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);
@@ -114,10 +120,11 @@ int cfnmpc_get_x(cfnmpc_solver *s, int stage, double *x /*[B][13]*/, int on_devi
  * (max-norm residual of the last QP).  Any pointer may be NULL. */
 int cfnmpc_get_stats(cfnmpc_solver *s, int *status /*[B]*/, int *qp_iter /*[B]*/, double *res /*[B]*/, int on_device, void *stream);
 
-/* Per-kernel timing (the role of nlp_out->total_time, acados_mpc.cpp:616): when enabled,
- * cfnmpc_solve brackets its two kernels (linearise, QP) with HIP events on the launch stream;
- * cfnmpc_get_profile waits for them and returns the average kernel durations [ms] over the RTI
- * steps since the last call, then resets. */
+/* Per-phase timing (the role of nlp_out->total_time, acados_mpc.cpp:616): when enabled,
+ * cfnmpc_solve brackets its two phases (linearisation, QP) with HIP events on the launch stream;
+ * cfnmpc_get_profile waits for them and returns the average durations [ms] over the RTI steps
+ * since the last call, then resets.  With overlap_linearise the linearisation figure is the
+ * time it ADDS to the step (the part not hidden behind the interior-point kernel). */
 int cfnmpc_set_profiling(cfnmpc_solver *s, int enable);
 int cfnmpc_get_profile(cfnmpc_solver *s, double *ms_linearise, double *ms_qp, int *n_steps);
 

@@ -180,3 +180,53 @@ def test_mixed_horizon_fleet_config5(oracle, cref):
         cref.rti_step(cref.default_opts(N=int(N), tol=1e-11), xr, ur, x0[idx].copy(), yref, yref_e, nthreads=0)
         assert np.abs(u0[idx] - ur[:, 0]).max() < 1e-7 and np.abs(u1[idx] - ur[:, 1]).max() < 1e-7
         assert np.abs(x4[idx] - xr[:, 4]).max() < 1e-7
+
+
+@pytest.mark.parametrize("B", [3, 257, 4099])
+def test_overlapped_preparation_is_bit_identical(oracle, B):
+    """cfnmpc_opts.overlap_linearise: linearising for the next step beside the interior-point
+    kernel (early pass over everybody + list pass over the interior-point instances) must give
+    the same bits as linearising at the start of cfnmpc_solve -- through a closed loop with
+    kicks, a multi-step call, and a save / restore of the iterate in the middle (which drops the
+    prepared linearisation)."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    N = 50
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=77 + B, scale=2.0)
+    rng = np.random.default_rng(5)
+    kicks = [oracle.sample_hover_x0(rng, B, scale=2.0) for _ in range(3)]
+    runs = []
+    for ov in (0, 1):
+        s = BatchSolver(B, default_opts(overlap_linearise=ov))
+        s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+        x = x0.copy()
+        log = []
+        nipm = 0
+        for t in range(7):
+            if t in (2, 4):                       # disturb a third of the fleet
+                x[t % 3::3] = kicks[t // 2][t % 3::3]
+            if t == 3:                            # save / restore: invalidates the prepared set
+                xi, ui = s.get_iterate()
+                s.set_iterate(xi, ui)
+            s.set_x0(x)
+            s.solve(2 if t == 5 else 1)
+            st, it, rs = s.stats()
+            xg, ug = s.get_iterate()
+            log.append((st.copy(), it.copy(), rs.copy(), xg, ug))
+            nipm += int((it > 0).sum())
+            x = sim(x, s.get_u(0), T=0.015, steps=1)
+        assert nipm > 0
+        A, Bm, b = s.get_linearisation() if B <= 257 else (None, None, None)
+        runs.append((log, A, Bm, b))
+        s.close()
+    for (a, c) in zip(runs[0][0], runs[1][0]):
+        for p, q in zip(a, c):
+            assert np.array_equal(p, q)
+    if B <= 257:
+        # overlap = 1 holds the linearisation of the CURRENT iterate (prepared for the next step);
+        # overlap = 0 still holds the one the last QP used -- re-linearise it to compare
+        s0 = BatchSolver(B, default_opts(overlap_linearise=0))
+        s0.set_iterate(runs[0][0][-1][3], runs[0][0][-1][4])
+        s0.linearise_only()
+        A0, B0, b0 = s0.get_linearisation()
+        assert np.array_equal(A0, runs[1][1]) and np.array_equal(B0, runs[1][2]) and np.array_equal(b0, runs[1][3])
