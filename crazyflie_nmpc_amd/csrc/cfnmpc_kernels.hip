@@ -380,6 +380,14 @@ __device__ __forceinline__ double rsqrt_nr(double s) {
     y = y * (1.5 - hs * y * y);
     return y;
 }
+// 1/x to full double accuracy: hardware estimate + two Newton steps (instead of the IEEE
+// division sequence; the interior-point iteration is self-correcting at rounding level)
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
 // symmetric positive definite 4x4 (packed upper) -> inverse (packed upper); false if not SPD
 __device__ __forceinline__ bool spd4_inv(const double (&S)[10], double (&Si)[10]) {
     double Lm[4][4], Li[4][4];
@@ -790,13 +798,27 @@ __device__ __forceinline__ void start_forward(const Params& P, const Lane& t, do
 __device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const bool doit) {
     if (!doit) return;
     const int N = P.N;
-    for (int k = 0; k <= N; k++) {
-        gdouble* xb = blk(P.xit, t, N + 1, k, SZ_V13);
-        const double dxk = ld13(blk(P.dx, t, N + 1, k, SZ_V13), t);
-        if (t.L < 13) xb[t.q * 13 + t.L] += dxk;
+    // batches of four (loads first): one memory round trip per batch instead of one per stage
+    const int lx = t.q * 13 + imin(t.L, 12);
+    for (int k0 = 0; k0 <= N; k0 += 4) {
+        double xo[4], dxk[4];
+        SFOR(j, 0, 4, {
+            const int k = imin(k0 + j, N);
+            xo[j] = blk(P.xit, t, N + 1, k, SZ_V13)[lx];
+            dxk[j] = blk(P.dx, t, N + 1, k, SZ_V13)[lx];
+        });
+        SFOR(j, 0, 4, { if (t.L < 13 && k0 + j <= N) blk(P.xit, t, N + 1, k0 + j, SZ_V13)[lx] = xo[j] + dxk[j]; });
     }
     const size_t ibase = (size_t)t.inst * N * 4;
-    for (int e = t.L; e < N * 4; e += 16) gm(P.uit)[ibase + e] += gm(P.v)[ibase + e];
+    for (int e0 = t.L; e0 < N * 4; e0 += 64) {
+        double uo[4], vv[4];
+        SFOR(j, 0, 4, {
+            const size_t idx = ibase + imin(e0 + 16 * j, N * 4 - 1);
+            uo[j] = gm(P.uit)[idx];
+            vv[j] = gm(P.v)[idx];
+        });
+        SFOR(j, 0, 4, { if (e0 + 16 * j < N * 4) gm(P.uit)[ibase + e0 + 16 * j] = uo[j] + vv[j]; });
+    }
 }
 
 // head class of an instance: the interior-point sweeps must cover stages [0, want)
@@ -887,26 +909,41 @@ struct RowIPM {  // uniform over the 16 lanes of a row
 };
 
 __device__ __forceinline__ double ratio(double z, double dz, double a) {
-    const double tt = -z / dz;
+    const double tt = -z * rcp_nr(dz);
     return (dz < 0.0 && tt < a) ? tt : a;
 }
 
 // element-wise passes: lane L of a row handles elements e = L, L+16, ... of the head*4 inputs
 struct Elem {
     double v, tl, tu, ll, lu, rg, lb, ub;
+    double dva, dvc;   // predictor / corrector input steps (passes that need them)
 };
-__device__ __forceinline__ Elem ld_elem(const Params& P, const Lane& t, size_t idx) {
+template <int NSTEP>   // NSTEP = 0: state only, 1: + dva, 2: + dva, dvc
+__device__ __forceinline__ Elem ld_elem(const Params& P, size_t idx) {
     Elem e;
     e.v = gm(P.v)[idx]; e.tl = gm(P.tl)[idx]; e.tu = gm(P.tu)[idx]; e.ll = gm(P.ll)[idx]; e.lu = gm(P.lu)[idx]; e.rg = gm(P.rg)[idx];
     const double uk = gm(P.uit)[idx];
     e.lb = P.u_min - uk;
     e.ub = P.u_max - uk;
+    e.dva = NSTEP >= 1 ? gm(P.dva)[idx] : 0.0;
+    e.dvc = NSTEP >= 2 ? gm(P.dvc)[idx] : 0.0;
     return e;
+}
+// One pass over the n elements of a row, in batches of four per lane with all loads of a batch
+// issued before any arithmetic (these passes run with one wave per SIMD: a plain loop would pay
+// one memory round trip per element).
+template <int NSTEP, class BODY>
+__device__ __forceinline__ void elem_pass(const Params& P, size_t base, int n, int L, BODY&& body) {
+    for (int e0 = L; e0 < n; e0 += 64) {
+        Elem d[4];
+        SFOR(j, 0, 4, { d[j] = ld_elem<NSTEP>(P, base + imin(e0 + 16 * j, n - 1)); });
+        SFOR(j, 0, 4, { if (e0 + 16 * j < n) body(e0 + 16 * j, d[j]); });
+    }
 }
 
 // -DCFN_PROF (development builds only, tools/ipm_phase_prof.py): phase timers of the longest wave
 #ifdef CFN_PROF
-__device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave, [8] its total, [9] sum of totals, [10] waves, [16..23] phase sums
 #define PROF_T(i) { const unsigned long long now_ = wall_clock64(); pacc[i] += now_ - plast; plast = now_; }
 #else
 #define PROF_T(i)
@@ -944,23 +981,36 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
     const size_t cbase = (size_t)tc.inst * N * 4;  // compact 4-vectors of this row
     auto gather = [&](int hd, int ck) {
-        for (int k = 0; k < hd; k++) {
-            double ar[10], br[4];
-            ld_ar(blk(P.AR, t, N, k, SZ_A), t, ar);
-            ld_rows4(blk(P.BR, t, N, k, SZ_B), t, br);
-            gdouble* ca = blk(Q.AR, tc, N, k, SZ_A);
-            SFOR(sl, 0, 10, { if (t.L < ar_n(sl)) ca[4 * ar_pre(sl) + tc.q * ar_n(sl) + t.L] = ar[sl]; });
-            gdouble* cb = blk(Q.BR, tc, N, k, SZ_B);
-            SFOR(a, 0, 4, { if (t.L < 13) cb[(a * 4 + tc.q) * 13 + t.L] = br[a]; });
-            if (t.L < 4) {
-                gm(Q.v)[i4(Q, tc, k, t.L)] = gm(P.v)[i4(P, t, k, t.L)];
-                gm(Q.uit)[i4(Q, tc, k, t.L)] = gm(P.uit)[i4(P, t, k, t.L)];
-            }
+        // two stages per batch, loads first (the source lines are cold: one HBM round trip each)
+        for (int k0 = 0; k0 < hd; k0 += 2) {
+            double ar[2][10], br[2][4], vv[2], uu[2];
+            SFOR(j, 0, 2, {
+                const int k = imin(k0 + j, hd - 1);
+                ld_ar(blk(P.AR, t, N, k, SZ_A), t, ar[j]);
+                ld_rows4(blk(P.BR, t, N, k, SZ_B), t, br[j]);
+                vv[j] = gm(P.v)[i4(P, t, k, t.L & 3)];
+                uu[j] = gm(P.uit)[i4(P, t, k, t.L & 3)];
+            });
+            SFOR(j, 0, 2, {
+                const int k = k0 + j;
+                if (k < hd) {
+                    gdouble* ca = blk(Q.AR, tc, N, k, SZ_A);
+                    SFOR(sl, 0, 10, { if (t.L < ar_n(sl)) ca[4 * ar_pre(sl) + tc.q * ar_n(sl) + t.L] = ar[j][sl]; });
+                    gdouble* cb = blk(Q.BR, tc, N, k, SZ_B);
+                    SFOR(a, 0, 4, { if (t.L < 13) cb[(a * 4 + tc.q) * 13 + t.L] = br[j][a]; });
+                    if (t.L < 4) {
+                        gm(Q.v)[i4(Q, tc, k, t.L)] = vv[j];
+                        gm(Q.uit)[i4(Q, tc, k, t.L)] = uu[j];
+                    }
+                }
+            });
         }
         if (ck >= 0) {
             const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + ck) * SZ_P;
             gdouble* qc = gm(Q.Pchk) + ((size_t)tc.wave * N_CHK + ck) * SZ_P;
-            SFOR(j, 0, 13, { if (t.L < 13) qc[(j * 4 + tc.q) * 13 + t.L] = pc[(j * 4 + t.q) * 13 + t.L]; });
+            double pv[13];
+            SFOR(j, 0, 13, { pv[j] = pc[(j * 4 + t.q) * 13 + imin(t.L, 12)]; });
+            SFOR(j, 0, 13, { if (t.L < 13) qc[(j * 4 + tc.q) * 13 + t.L] = pv[j]; });
         }
     };
     RowIPM R;
@@ -973,19 +1023,31 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
             const double mu0 = fmax(P.mu0_scale * viol, P.lam0_min);
             double mu = 0.0, res = 0.0;
-            for (int e = t.L; e < head * 4; e += 16) {
-                const size_t idx = cbase + e;
-                const double uk = gm(Q.uit)[idx], v = gm(Q.v)[idx];
-                const double lb = P.u_min - uk, ub = P.u_max - uk;
-                const double tl = fmax(v - lb, P.thr0), tu = fmax(ub - v, P.thr0);
-                const double ll = mu0 / tl, lu = mu0 / tu, rg = -ll + lu;
-                gm(Q.tl)[idx] = tl; gm(Q.tu)[idx] = tu; gm(Q.ll)[idx] = ll; gm(Q.lu)[idx] = lu; gm(Q.rg)[idx] = rg;
-                const double rl = v - lb - tl, ru = ub - v - tu;
-                const double Dl = ll / tl, Du = lu / tu;
-                gm(Q.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
-                gm(Q.g)[idx] = rg + ll + Dl * rl - lu - Du * ru;
-                mu += ll * tl + lu * tu;
-                res = fmax(res, fmax(fmax(ll * tl, lu * tu), fmax(fabs(rg), fmax(fabs(rl), fabs(ru)))));
+            for (int e0 = t.L; e0 < head * 4; e0 += 64) {
+                double uk[4], vv[4];
+                SFOR(j, 0, 4, {
+                    const size_t idx = cbase + imin(e0 + 16 * j, head * 4 - 1);
+                    uk[j] = gm(Q.uit)[idx];
+                    vv[j] = gm(Q.v)[idx];
+                });
+                SFOR(j, 0, 4, {
+                    const int e = e0 + 16 * j;
+                    if (e < head * 4) {
+                        const size_t idx = cbase + e;
+                        const double v = vv[j];
+                        const double lb = P.u_min - uk[j], ub = P.u_max - uk[j];
+                        const double tl = fmax(v - lb, P.thr0), tu = fmax(ub - v, P.thr0);
+                        const double itl = rcp_nr(tl), itu = rcp_nr(tu);
+                        const double ll = mu0 * itl, lu = mu0 * itu, rg = -ll + lu;
+                        gm(Q.tl)[idx] = tl; gm(Q.tu)[idx] = tu; gm(Q.ll)[idx] = ll; gm(Q.lu)[idx] = lu; gm(Q.rg)[idx] = rg;
+                        const double rl = v - lb - tl, ru = ub - v - tu;
+                        const double Dl = ll * itl, Du = lu * itu;
+                        gm(Q.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
+                        gm(Q.g)[idx] = rg + ll + Dl * rl - lu - Du * ru;
+                        mu += ll * tl + lu * tu;
+                        res = fmax(res, fmax(fmax(ll * tl, lu * tu), fmax(fabs(rg), fmax(fabs(rl), fabs(ru)))));
+                    }
+                });
             }
             R.mu = row_sum(mu) / (8.0 * head);
             R.res = row_max(res);
@@ -1009,40 +1071,53 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             PROF_T(2)
             sweep_forward_delta(Q, tc, head, gm(Q.dva));
             PROF_T(3)
-            // affine step length, mu_aff, centering; corrector right-hand side
+            // affine step length, mu_aff, centering; corrector right-hand side.  Three dependent
+            // passes (row reductions in between); a row with at most 64 inputs (head <= 16) keeps
+            // its elements in registers across them.
             double smu;
             {
-                double a = 1.0;
-                for (int e = t.L; e < head * 4; e += 16) {
-                    const Elem el = ld_elem(Q, tc, cbase + e);
-                    const double dva = gm(Q.dva)[cbase + e];
+                const int n = head * 4;
+                struct Aff { double dtl, dtu, dll, dlu, itl, itu; };
+                auto aff = [&](const Elem& el) {
+                    Aff f;
                     const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
-                    const double dtl = dva + rl, dtu = -dva + ru;
-                    const double dll = -el.ll - (el.ll / el.tl) * dtl, dlu = -el.lu - (el.lu / el.tu) * dtu;
-                    a = ratio(el.tl, dtl, a); a = ratio(el.tu, dtu, a);
-                    a = ratio(el.ll, dll, a); a = ratio(el.lu, dlu, a);
-                }
-                a = row_min(a);
-                double mu_aff = 0.0;
-                for (int e = t.L; e < head * 4; e += 16) {
-                    const Elem el = ld_elem(Q, tc, cbase + e);
-                    const double dva = gm(Q.dva)[cbase + e];
-                    const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
-                    const double dtl = dva + rl, dtu = -dva + ru;
-                    const double dll = -el.ll - (el.ll / el.tl) * dtl, dlu = -el.lu - (el.lu / el.tu) * dtu;
-                    mu_aff += (el.ll + a * dll) * (el.tl + a * dtl) + (el.lu + a * dlu) * (el.tu + a * dtu);
-                }
-                mu_aff = row_sum(mu_aff) / (8.0 * head);
-                const double sr = mu_aff / R.mu;
-                smu = sr * sr * sr * R.mu;
-                for (int e = t.L; e < head * 4; e += 16) {
-                    const Elem el = ld_elem(Q, tc, cbase + e);
-                    const double dva = gm(Q.dva)[cbase + e];
-                    const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
-                    const double dtl = dva + rl, dtu = -dva + ru;
-                    const double dll = -el.ll - (el.ll / el.tl) * dtl, dlu = -el.lu - (el.lu / el.tu) * dtu;
-                    const double cl = dll * dtl, cu = dlu * dtu;
-                    gm(Q.g)[cbase + e] = (cl - smu) / el.tl - (cu - smu) / el.tu;
+                    f.dtl = el.dva + rl; f.dtu = -el.dva + ru;
+                    f.itl = rcp_nr(el.tl); f.itu = rcp_nr(el.tu);
+                    f.dll = -el.ll - (el.ll * f.itl) * f.dtl; f.dlu = -el.lu - (el.lu * f.itu) * f.dtu;
+                    return f;
+                };
+                double a = 1.0, mu_aff = 0.0;
+                auto passA = [&](const Elem& el, const Aff& f) {
+                    a = ratio(el.tl, f.dtl, a); a = ratio(el.tu, f.dtu, a);
+                    a = ratio(el.ll, f.dll, a); a = ratio(el.lu, f.dlu, a);
+                };
+                auto passB = [&](const Elem& el, const Aff& f) {
+                    mu_aff += (el.ll + a * f.dll) * (el.tl + a * f.dtl) + (el.lu + a * f.dlu) * (el.tu + a * f.dtu);
+                };
+                auto passC = [&](int e, const Elem& el, const Aff& f) {
+                    const double cl = f.dll * f.dtl, cu = f.dlu * f.dtu;
+                    gm(Q.g)[cbase + e] = (cl - smu) * f.itl - (cu - smu) * f.itu;
+                };
+                auto centre = [&]() {
+                    mu_aff = row_sum(mu_aff) / (8.0 * head);
+                    const double sr = mu_aff * rcp_nr(R.mu);
+                    smu = sr * sr * sr * R.mu;
+                };
+                if (n <= 64) {
+                    Elem d[4];
+                    Aff f[4];
+                    SFOR(j, 0, 4, { d[j] = ld_elem<1>(Q, cbase + imin(t.L + 16 * j, n - 1)); });
+                    SFOR(j, 0, 4, { f[j] = aff(d[j]); if (t.L + 16 * j < n) passA(d[j], f[j]); });
+                    a = row_min(a);
+                    SFOR(j, 0, 4, { if (t.L + 16 * j < n) passB(d[j], f[j]); });
+                    centre();
+                    SFOR(j, 0, 4, { if (t.L + 16 * j < n) passC(t.L + 16 * j, d[j], f[j]); });
+                } else {
+                    elem_pass<1>(Q, cbase, n, t.L, [&](int, const Elem& el) { passA(el, aff(el)); });
+                    a = row_min(a);
+                    elem_pass<1>(Q, cbase, n, t.L, [&](int, const Elem& el) { passB(el, aff(el)); });
+                    centre();
+                    elem_pass<1>(Q, cbase, n, t.L, [&](int e, const Elem& el) { passC(e, el, aff(el)); });
                 }
             }
             // corrector: re-solve, forward
@@ -1051,37 +1126,33 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             PROF_T(5)
             sweep_forward_delta(Q, tc, head, gm(Q.dvc));
             PROF_T(3)
-            // step, update, residuals of the new point, next R^ and g
+            // step, update, residuals of the new point, next R^ and g (two dependent passes)
             {
-                double a = 1.0;
-                for (int e = t.L; e < head * 4; e += 16) {
-                    const Elem el = ld_elem(Q, tc, cbase + e);
-                    const double dva = gm(Q.dva)[cbase + e], dv = dva + gm(Q.dvc)[cbase + e];
+                const int n = head * 4;
+                struct Stp { double dv, dtl, dtu, dll, dlu; };
+                auto stp = [&](const Elem& el) {
+                    Stp f;
+                    f.dv = el.dva + el.dvc;
                     const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
-                    const double dtla = dva + rl, dtua = -dva + ru;
-                    const double Dl = el.ll / el.tl, Du = el.lu / el.tu;
+                    const double dtla = el.dva + rl, dtua = -el.dva + ru;
+                    const double itl = rcp_nr(el.tl), itu = rcp_nr(el.tu);
+                    const double Dl = el.ll * itl, Du = el.lu * itu;
                     const double cl = (-el.ll - Dl * dtla) * dtla, cu = (-el.lu - Du * dtua) * dtua;
-                    const double dtl = dv + rl, dtu = -dv + ru;
-                    const double dll = (smu - cl) / el.tl - el.ll - Dl * dtl, dlu = (smu - cu) / el.tu - el.lu - Du * dtu;
-                    a = ratio(el.tl, dtl, a); a = ratio(el.tu, dtu, a);
-                    a = ratio(el.ll, dll, a); a = ratio(el.lu, dlu, a);
-                }
-                a = fmin(1.0, P.tau * row_min(a));
-                double mu = 0.0, res = 0.0;
-                for (int e = t.L; e < head * 4; e += 16) {
+                    f.dtl = f.dv + rl; f.dtu = -f.dv + ru;
+                    f.dll = (smu - cl) * itl - el.ll - Dl * f.dtl; f.dlu = (smu - cu) * itu - el.lu - Du * f.dtu;
+                    return f;
+                };
+                double a = 1.0, mu = 0.0, res = 0.0;
+                auto passD = [&](const Elem& el, const Stp& f) {
+                    a = ratio(el.tl, f.dtl, a); a = ratio(el.tu, f.dtu, a);
+                    a = ratio(el.ll, f.dll, a); a = ratio(el.lu, f.dlu, a);
+                };
+                auto passE = [&](int e, const Elem& el, const Stp& f) {
                     const size_t idx = cbase + e;
-                    const Elem el = ld_elem(Q, tc, idx);
-                    const double dva = gm(Q.dva)[idx], dv = dva + gm(Q.dvc)[idx];
-                    const double rl = el.v - el.lb - el.tl, ru = el.ub - el.v - el.tu;
-                    const double dtla = dva + rl, dtua = -dva + ru;
-                    const double Dl0 = el.ll / el.tl, Du0 = el.lu / el.tu;
-                    const double cl = (-el.ll - Dl0 * dtla) * dtla, cu = (-el.lu - Du0 * dtua) * dtua;
-                    const double dtl = dv + rl, dtu = -dv + ru;
-                    const double dll = (smu - cl) / el.tl - el.ll - Dl0 * dtl, dlu = (smu - cu) / el.tu - el.lu - Du0 * dtu;
-                    const double v = el.v + a * dv, tl = el.tl + a * dtl, tu = el.tu + a * dtu;
-                    const double ll = el.ll + a * dll, lu = el.lu + a * dlu, rg = el.rg * (1.0 - a);
+                    const double v = el.v + a * f.dv, tl = el.tl + a * f.dtl, tu = el.tu + a * f.dtu;
+                    const double ll = el.ll + a * f.dll, lu = el.lu + a * f.dlu, rg = el.rg * (1.0 - a);
                     const double rln = v - el.lb - tl, run = el.ub - v - tu;
-                    const double Dl = ll / tl, Du = lu / tu;
+                    const double Dl = ll * rcp_nr(tl), Du = lu * rcp_nr(tu);
                     if (R.act) {
                         gm(Q.v)[idx] = v; gm(Q.tl)[idx] = tl; gm(Q.tu)[idx] = tu; gm(Q.ll)[idx] = ll; gm(Q.lu)[idx] = lu; gm(Q.rg)[idx] = rg;
                         gm(Q.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
@@ -1089,6 +1160,18 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                     }
                     mu += ll * tl + lu * tu;
                     res = fmax(res, fmax(fmax(ll * tl, lu * tu), fmax(fabs(rg), fmax(fabs(rln), fabs(run)))));
+                };
+                if (n <= 64) {
+                    Elem d[4];
+                    Stp f[4];
+                    SFOR(j, 0, 4, { d[j] = ld_elem<2>(Q, cbase + imin(t.L + 16 * j, n - 1)); });
+                    SFOR(j, 0, 4, { f[j] = stp(d[j]); if (t.L + 16 * j < n) passD(d[j], f[j]); });
+                    a = fmin(1.0, P.tau * row_min(a));
+                    SFOR(j, 0, 4, { if (t.L + 16 * j < n) passE(t.L + 16 * j, d[j], f[j]); });
+                } else {
+                    elem_pass<2>(Q, cbase, n, t.L, [&](int, const Elem& el) { passD(el, stp(el)); });
+                    a = fmin(1.0, P.tau * row_min(a));
+                    elem_pass<2>(Q, cbase, n, t.L, [&](int e, const Elem& el) { passE(e, el, stp(el)); });
                 }
                 mu = row_sum(mu) / (8.0 * head);
                 res = row_max(res);
@@ -1148,8 +1231,14 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
     }
     // accepted: publish the inputs of the whole horizon
-    if (t.valid && t.L < 4)
-        for (int k = 0; k < N; k++) gm(P.v)[i4(P, t, k, t.L)] = gm(Q.dva)[i4(Q, tc, k, t.L)];
+    if (t.valid) {
+        const size_t pb = (size_t)t.inst * N * 4;
+        for (int e0 = t.L; e0 < N * 4; e0 += 64) {
+            double vv[4];
+            SFOR(j, 0, 4, { vv[j] = gm(Q.dva)[cbase + imin(e0 + 16 * j, N * 4 - 1)]; });
+            SFOR(j, 0, 4, { if (e0 + 16 * j < N * 4) gm(P.v)[pb + e0 + 16 * j] = vv[j]; });
+        }
+    }
     if (t.L == 0 && infeasible) {
         gm(P.status)[t.inst] = R.status;
         gm(P.iters)[t.inst] = R.iters;
@@ -1165,13 +1254,14 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         if (tot > old) for (int i = 0; i < 8; i++) g_prof[i] = pacc[i];   // (racy, development aid) phases of the longest wave
         atomicAdd(&g_prof[9], tot);
         atomicAdd(&g_prof[10], 1ull);
+        for (int i = 0; i < 8; i++) atomicAdd(&g_prof[16 + i], pacc[i]);
     }
 #endif
 }
 #ifdef CFN_PROF
 void debug_prof_read(unsigned long long* out, int reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z); }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z); }
 }
 #endif
 

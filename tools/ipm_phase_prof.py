@@ -21,7 +21,7 @@ cohort = B // KP
 kicks = torch.from_numpy(sample_hover_x0(rng, cohort * KP).reshape(KP, cohort, 13)).to(dev)
 u0 = torch.empty((B, 4), dtype=torch.float64, device=dev); xn = torch.empty_like(x)
 names = ["gather", "elem(init,loop ctl)", "factor", "forward x2", "elem passes", "resolve", "rollout", "publish+commit"]
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 32)()
 for t in range(30):
     x[(t % KP) * cohort:(t % KP + 1) * cohort].copy_(kicks[t % KP])
     s.set_x0(x)
@@ -31,4 +31,5 @@ for t in range(30):
         L.cfnmpc_debug_prof(out, 0)
         v = np.array(list(out), dtype=np.float64) / 100.0  # wall_clock64: 100 MHz -> us
         print(f"step {t}: longest wave {v[8]:.0f} us, mean wave {v[9] / max(out[10], 1):.0f} us over {out[10]} waves")
-        print("   " + "  ".join(f"{n} {v[i]:.0f}" for i, n in enumerate(names)))
+        print("   longest: " + "  ".join(f"{n} {v[i]:.0f}" for i, n in enumerate(names)))
+        print("   mean   : " + "  ".join(f"{n} {v[16 + i] / max(out[10], 1):.0f}" for i, n in enumerate(names)))
