@@ -22,6 +22,7 @@
 //   k_put / k_get / k_init_iterate : layout glue for the C-ABI.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "cfnmpc_dpp.hpp"
@@ -854,6 +855,141 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
     commit_row(P, t, t.valid && !bad && !infeasible);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Start solve, forward sweep -- lane-per-instance, matrix-free.
+// The forward sweep only needs the PRODUCT  dx+ = A dx + B du + b, never A and B themselves, and
+// that product is the directional derivative of the RK4 map at (x_k, u_k) along (dx, du): one
+// forward-mode pass through the four RK stages (~10^3 flops) instead of reading the 149 stored
+// entries of (A, B) per stage.  Per instance and stage the sweep then reads K (52), d (4), b (13),
+// x_k (13), u_k (4) and writes the input step and the candidate new state -- less than half the
+// bytes of the row-distributed sweep -- and with one instance per lane there are no cross-lane
+// reductions at all.  (The interior-point kernel keeps the stored A, B: its sweeps run many times
+// per QP on a compact copy.)
+// P.dx receives the CANDIDATE ITERATE x_k + dx_k (not the step): feasible instances copy it into
+// the iterate in the second loop; the interior-point kernel writes its own steps.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_forward_mf(Params P) {
+    const int N = P.N;
+    const int raw = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = raw < P.B;
+    const int inst = valid ? raw : P.NW * 4 + (threadIdx.x & 3);   // idle lanes: spare block
+    const size_t w = (size_t)(inst >> 2);
+    const int q = inst & 3;
+    const double h = P.dt;
+    const double margin = P.ah_margin * (P.u_max - P.u_min);
+    const gdouble* xitp = gm(P.xit) + w * (N + 1) * SZ_V13 + q * 13;
+    gdouble* cand = gm(P.dx) + w * (N + 1) * SZ_V13 + q * 13;
+    const gdouble* bp = gm(P.b) + w * N * SZ_V13 + q * 13;
+    const gdouble* kp = gm(P.KR) + w * N * SZ_K + q * 4;
+    const size_t i4b = (size_t)inst * N * 4;
+
+    struct In { double K[4][13], d[4], b[13], x[13], u[4]; };   // K, b, x in INTERNAL order
+    auto load = [&](int k, In& in) {
+        SFOR(l, 0, 13, { SFOR(a, 0, 4, { in.K[a][l] = kp[(size_t)k * SZ_K + l * 16 + a]; }); });
+        SFOR(a, 0, 4, { in.d[a] = gm(P.d)[i4b + (size_t)k * 4 + a]; in.u[a] = gm(P.uit)[i4b + (size_t)k * 4 + a]; });
+        SFOR(i, 0, 13, { in.b[i] = bp[(size_t)k * SZ_V13 + i]; in.x[i] = xitp[(size_t)k * SZ_V13 + i]; });
+    };
+    double dx[13];   // internal order
+    {
+        const gdouble* x0p = gm(P.x0) + w * SZ_V13 + q * 13;
+        SFOR(i, 0, 13, { dx[i] = x0p[i] - xitp[i]; });
+    }
+    double viol = 0.0;
+    int last_tight = -1;
+    bool sawnan = false;
+    In cur, nxt;
+    load(0, cur);
+    for (int k = 0; k < N; k++) {
+        load(imin(k + 1, N - 1), nxt);   // prefetch
+        // candidate state of stage k
+        SFOR(i, 0, 13, { cand[(size_t)k * SZ_V13 + i] = cur.x[i] + dx[i]; });
+        // du = -K dx - d, bounds
+        double du[4];
+        SFOR(a, 0, 4, {
+            double acc = 0.0;
+            SFOR(l, 0, 13, { acc = __builtin_fma(cur.K[a][l], dx[l], acc); });
+            du[a] = -cur.d[a] - acc;
+            const double lb = P.u_min - cur.u[a], ub = P.u_max - cur.u[a];
+            viol = fmax(viol, fmax(lb - du[a], du[a] - ub));
+            if (du[a] < lb + margin || du[a] > ub - margin) last_tight = k;
+            sawnan = sawnan || !(du[a] == du[a]);
+            gm(P.v)[i4b + (size_t)k * 4 + a] = du[a];
+        });
+        // directional derivative of the RK4 step along (dx, du); model vectors in EXTERNAL order
+        double x[13], s[13], xt[13], st[13], kk[13], dk[13], acc[13];
+        SFOR(e, 0, 13, { x[e] = cur.x[int_of(e)]; s[e] = dx[int_of(e)]; });
+        double jud[4];
+        {
+            const double p0 = cur.u[0] * du[0], p1 = cur.u[1] * du[1], p2 = cur.u[2] * du[2], p3 = cur.u[3] * du[3];
+            jud[0] = 2.0 * KT * (p0 + p1 + p2 + p3);
+            jud[1] = 2.0 * KA * (p0 + p1 - p2 - p3);
+            jud[2] = 2.0 * KB * (p0 - p1 - p2 + p3);
+            jud[3] = 2.0 * KC * (p0 - p1 + p2 - p3);
+        }
+        JacPoint J;
+        // stage 1
+        f_expl(x, cur.u, kk);
+        jac_point(x, J);
+        jvp<true, true>(J, s, dk);
+        SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
+        SFOR(e, 0, 13, { acc[e] = dk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
+        // stage 2
+        f_expl(xt, cur.u, kk);
+        jac_point(xt, J);
+        jvp<true, true>(J, st, dk);
+        SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
+        SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
+        // stage 3
+        f_expl(xt, cur.u, kk);
+        jac_point(xt, J);
+        jvp<true, true>(J, st, dk);
+        SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
+        SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; xt[e] = x[e] + h * kk[e]; st[e] = s[e] + h * dk[e]; });
+        // stage 4
+        jac_point(xt, J);
+        jvp<true, true>(J, st, dk);
+        SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
+        SFOR(i, 0, 13, {
+            constexpr int e = ext_of(i);
+            dx[i] = s[e] + (h / 6.0) * (acc[e] + dk[e]) + cur.b[i];
+        });
+        cur = nxt;
+    }
+    {
+        const gdouble* xN = xitp + (size_t)N * SZ_V13;
+        SFOR(i, 0, 13, { cand[(size_t)N * SZ_V13 + i] = xN[i] + dx[i]; });
+    }
+    if (sawnan) viol = nan("");
+    const bool okf = valid && gm(P.status)[imin(raw, P.B - 1)] == 0;
+    const bool bad = valid && (!okf || !(viol == viol));
+    const bool infeasible = valid && !bad && (viol > 0.0);
+    if (valid) {
+        gm(P.viol)[inst] = infeasible ? viol : 0.0;
+        gm(P.status)[inst] = bad ? 4 : 0;
+        gm(P.iters)[inst] = 0;
+        gm(P.res)[inst] = bad ? nan("") : 0.0;
+        gm(P.head)[inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
+    }
+    // instances whose unconstrained minimiser is feasible are done: full RTI step (the others
+    // are committed by k_ipm once their QP is accepted; failed ones keep their iterate)
+    if (valid && !bad && !infeasible) {
+        gdouble* xw = gm(P.xit) + w * (N + 1) * SZ_V13 + q * 13;
+        for (int k0 = 0; k0 <= N; k0 += 2) {
+            double c[2][13];
+            SFOR(j, 0, 2, { SFOR(i, 0, 13, { c[j][i] = cand[(size_t)imin(k0 + j, N) * SZ_V13 + i]; }); });
+            SFOR(j, 0, 2, { if (k0 + j <= N) SFOR(i, 0, 13, { xw[(size_t)(k0 + j) * SZ_V13 + i] = c[j][i]; }); });
+        }
+        for (int k0 = 0; k0 < N; k0 += 4) {
+            double uo[4][4], vv[4][4];
+            SFOR(j, 0, 4, {
+                const size_t idx = i4b + (size_t)imin(k0 + j, N - 1) * 4;
+                SFOR(a, 0, 4, { uo[j][a] = gm(P.uit)[idx + a]; vv[j][a] = gm(P.v)[idx + a]; });
+            });
+            SFOR(j, 0, 4, { if (k0 + j < N) SFOR(a, 0, 4, { gm(P.uit)[i4b + (size_t)(k0 + j) * 4 + a] = uo[j][a] + vv[j][a]; }); });
+        }
+    }
+}
+
 // Stable compaction of the instances that need the interior-point method, grouped by head
 // class (largest first) so that the four rows of a wave work on similar horizons.  One block.
 __global__ __launch_bounds__(1024) void k_compact(Params P) {
@@ -1465,7 +1601,9 @@ void launch_linearise_list(const Params& P, int chunks, hipStream_t st) {
 }
 void launch_qp_start(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
-    hipLaunchKernelGGL(k_forward, dim3(P.NW), dim3(64), 0, st, P);
+    static const bool rows = std::getenv("CFNMPC_FORWARD_ROWS") != nullptr;   // development aid: A/B against the row-distributed sweep
+    if (rows) hipLaunchKernelGGL(k_forward, dim3(P.NW), dim3(64), 0, st, P);
+    else hipLaunchKernelGGL(k_forward_mf, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, P);
 }
 void launch_qp_ipm(const Params& P, hipStream_t st) {
