@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--workload", choices=["hover", "figure8"], default="hover",
                     help="hover = config C3 (the metric's configuration); figure8 = config C4 tracking with "
                          "device-side reference windows")
+    ap.add_argument("--overlap", type=int, default=None, help="cfnmpc_opts.overlap_linearise (default: library default)")
     ap.add_argument("--ah-margin", type=float, default=None)
     ap.add_argument("--ah-extra", type=int, default=None)
     ap.add_argument("--streams", type=int, default=1,
@@ -166,6 +167,8 @@ def main():
             self.cohort = (n + KICK_PERIOD - 1) // KICK_PERIOD
             self.kicks = torch.from_numpy(sample_x0(rng, self.cohort * KICK_PERIOD).reshape(KICK_PERIOD, self.cohort, 13)).to(dev)
             kw = dict(active_horizon=args.active_horizon)
+            if args.overlap is not None:
+                kw["overlap_linearise"] = args.overlap
             if args.ah_margin is not None:
                 kw["ah_margin"] = args.ah_margin
             if args.ah_extra is not None:

@@ -120,7 +120,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->active_horizon = 1;
     o->ah_margin = 0.10;
     o->ah_extra = 4;
-    o->overlap_linearise = 1;
+    o->overlap_linearise = 0;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {

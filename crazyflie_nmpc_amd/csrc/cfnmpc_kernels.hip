@@ -235,8 +235,13 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     // element offset of (local instance li, lane i) in a field with `stages` stages per block, SZ
     // doubles per (block, stage), NS lanes per instance starting at `pre4` inside the block
     auto at = [&](int li, int i, int stages, int k, int SZ, int pre4, int NS) -> size_t {
-        const int in = sinst[li];
-        return ((size_t)(in >> 2) * stages + k) * SZ + pre4 + (in & 3) * NS + i;
+        if (GATHER) {
+            const int in = sinst[li];
+            return ((size_t)(in >> 2) * stages + k) * SZ + pre4 + (in & 3) * NS + i;
+        }
+        // consecutive instances: block and slot follow from the local index (no table look-up)
+        const int bk = imin((int)blockIdx.x * 16 + (li >> 2), P.NW);
+        return ((size_t)bk * stages + k) * SZ + pre4 + (li & 3) * NS + i;
     };
     // Trip counts are compile-time (64 instances x NS lanes) and the loops fully unrolled, so that
     // all loads / LDS reads of a transfer are in flight together.
@@ -869,30 +874,51 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
 // the iterate in the second loop; the interior-point kernel writes its own steps.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_forward_mf(Params P) {
+    // 13-vectors travel through LDS tiles [instance][13] so that every global access of the wave
+    // is a contiguous run (as in k_linearise); K, d, u, v are 32-byte runs per lane already.
+    __shared__ double xs[64 * 13], bs[64 * 13], cs[64 * 13];
+    __shared__ int sflag[64];
     const int N = P.N;
-    const int raw = blockIdx.x * 64 + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int raw = blockIdx.x * 64 + tid;
     const bool valid = raw < P.B;
-    const int inst = valid ? raw : P.NW * 4 + (threadIdx.x & 3);   // idle lanes: spare block
+    const int inst = valid ? raw : P.NW * 4 + (tid & 3);   // idle lanes: spare block
     const size_t w = (size_t)(inst >> 2);
     const int q = inst & 3;
+    const int w0 = blockIdx.x * 16;
     const double h = P.dt;
     const double margin = P.ah_margin * (P.u_max - P.u_min);
-    const gdouble* xitp = gm(P.xit) + w * (N + 1) * SZ_V13 + q * 13;
-    gdouble* cand = gm(P.dx) + w * (N + 1) * SZ_V13 + q * 13;
-    const gdouble* bp = gm(P.b) + w * N * SZ_V13 + q * 13;
     const gdouble* kp = gm(P.KR) + w * N * SZ_K + q * 4;
     const size_t i4b = (size_t)inst * N * 4;
-
-    struct In { double K[4][13], d[4], b[13], x[13], u[4]; };   // K, b, x in INTERNAL order
+    // element e = 13 * (local instance) + i of a 13-vector field with `stages` stages per block
+    auto at13 = [&](int e, int stages, int k) -> size_t {
+        const int bk = e / 52, off = e - bk * 52;
+        return ((size_t)imin(w0 + bk, P.NW) * stages + k) * SZ_V13 + off;
+    };
+    auto issue13 = [&](const double* f, int stages, int k, int tl, double (&r)[13]) {
+        SFOR(j, 0, 13, { r[j] = gm(f)[at13(tl + 64 * j, stages, k)]; });
+    };
+    auto land13 = [&](double* tile, const double (&r)[13]) {
+        SFOR(j, 0, 13, { tile[tid + 64 * j] = r[j]; });
+    };
+    struct In { double K[4][13], d[4], u[4]; };   // K: column index in INTERNAL order
     auto load = [&](int k, In& in) {
         SFOR(l, 0, 13, { SFOR(a, 0, 4, { in.K[a][l] = kp[(size_t)k * SZ_K + l * 16 + a]; }); });
         SFOR(a, 0, 4, { in.d[a] = gm(P.d)[i4b + (size_t)k * 4 + a]; in.u[a] = gm(P.uit)[i4b + (size_t)k * 4 + a]; });
-        SFOR(i, 0, 13, { in.b[i] = bp[(size_t)k * SZ_V13 + i]; in.x[i] = xitp[(size_t)k * SZ_V13 + i]; });
     };
     double dx[13];   // internal order
     {
-        const gdouble* x0p = gm(P.x0) + w * SZ_V13 + q * 13;
-        SFOR(i, 0, 13, { dx[i] = x0p[i] - xitp[i]; });
+        double r0[13], r1[13];
+        issue13(P.x0, 1, 0, tid, r0);
+        issue13(P.xit, N + 1, 0, tid, r1);
+        land13(bs, r0);
+        land13(xs, r1);
+        __syncthreads();
+        SFOR(i, 0, 13, { dx[i] = bs[tid * 13 + i] - xs[tid * 13 + i]; });
+        __syncthreads();
+        issue13(P.b, N, 0, tid, r0);
+        land13(bs, r0);
+        __syncthreads();
     }
     double viol = 0.0;
     int last_tight = -1;
@@ -900,9 +926,12 @@ __global__ __launch_bounds__(64) void k_forward_mf(Params P) {
     In cur, nxt;
     load(0, cur);
     for (int k = 0; k < N; k++) {
-        load(imin(k + 1, N - 1), nxt);   // prefetch
+        int tl = tid;   // opaque per-stage copy (keeps the transfer offsets out of loop-invariant registers)
+        asm volatile("" : "+v"(tl));
+        double xi[13], bi[13];
+        SFOR(i, 0, 13, { xi[i] = xs[tid * 13 + i]; bi[i] = bs[tid * 13 + i]; });
         // candidate state of stage k
-        SFOR(i, 0, 13, { cand[(size_t)k * SZ_V13 + i] = cur.x[i] + dx[i]; });
+        SFOR(i, 0, 13, { cs[tid * 13 + i] = xi[i] + dx[i]; });
         // du = -K dx - d, bounds
         double du[4];
         SFOR(a, 0, 4, {
@@ -915,12 +944,18 @@ __global__ __launch_bounds__(64) void k_forward_mf(Params P) {
             sawnan = sawnan || !(du[a] == du[a]);
             gm(P.v)[i4b + (size_t)k * 4 + a] = du[a];
         });
+        // next stage's inputs (issued here: the gain of stage k is dead, its registers are free)
+        const double uc[4] = {cur.u[0], cur.u[1], cur.u[2], cur.u[3]};
+        load(imin(k + 1, N - 1), nxt);
+        double xr[13], br[13];
+        issue13(P.xit, N + 1, k + 1, tl, xr);
+        issue13(P.b, N, imin(k + 1, N - 1), tl, br);
         // directional derivative of the RK4 step along (dx, du); model vectors in EXTERNAL order
         double x[13], s[13], xt[13], st[13], kk[13], dk[13], acc[13];
-        SFOR(e, 0, 13, { x[e] = cur.x[int_of(e)]; s[e] = dx[int_of(e)]; });
+        SFOR(e, 0, 13, { x[e] = xi[int_of(e)]; s[e] = dx[int_of(e)]; });
         double jud[4];
         {
-            const double p0 = cur.u[0] * du[0], p1 = cur.u[1] * du[1], p2 = cur.u[2] * du[2], p3 = cur.u[3] * du[3];
+            const double p0 = uc[0] * du[0], p1 = uc[1] * du[1], p2 = uc[2] * du[2], p3 = uc[3] * du[3];
             jud[0] = 2.0 * KT * (p0 + p1 + p2 + p3);
             jud[1] = 2.0 * KA * (p0 + p1 - p2 - p3);
             jud[2] = 2.0 * KB * (p0 - p1 - p2 + p3);
@@ -928,19 +963,19 @@ __global__ __launch_bounds__(64) void k_forward_mf(Params P) {
         }
         JacPoint J;
         // stage 1
-        f_expl(x, cur.u, kk);
+        f_expl(x, uc, kk);
         jac_point(x, J);
         jvp<true, true>(J, s, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
         SFOR(e, 0, 13, { acc[e] = dk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
         // stage 2
-        f_expl(xt, cur.u, kk);
+        f_expl(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
         SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
         // stage 3
-        f_expl(xt, cur.u, kk);
+        f_expl(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
@@ -951,18 +986,34 @@ __global__ __launch_bounds__(64) void k_forward_mf(Params P) {
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
         SFOR(i, 0, 13, {
             constexpr int e = ext_of(i);
-            dx[i] = s[e] + (h / 6.0) * (acc[e] + dk[e]) + cur.b[i];
+            dx[i] = s[e] + (h / 6.0) * (acc[e] + dk[e]) + bi[i];
         });
+        // candidate tile out, next stage's tiles in
+        __syncthreads();
+        {
+            double cv[13];
+            SFOR(j, 0, 13, { cv[j] = cs[tl + 64 * j]; });
+            SFOR(j, 0, 13, { gm(P.dx)[at13(tl + 64 * j, N + 1, k)] = cv[j]; });
+        }
+        land13(xs, xr);
+        land13(bs, br);
+        __syncthreads();
         cur = nxt;
     }
-    {
-        const gdouble* xN = xitp + (size_t)N * SZ_V13;
-        SFOR(i, 0, 13, { cand[(size_t)N * SZ_V13 + i] = xN[i] + dx[i]; });
-    }
+    // candidate of the terminal stage (xs holds x_N)
+    SFOR(i, 0, 13, { cs[tid * 13 + i] = xs[tid * 13 + i] + dx[i]; });
     if (sawnan) viol = nan("");
     const bool okf = valid && gm(P.status)[imin(raw, P.B - 1)] == 0;
     const bool bad = valid && (!okf || !(viol == viol));
     const bool infeasible = valid && !bad && (viol > 0.0);
+    const bool commit = valid && !bad && !infeasible;
+    sflag[tid] = commit ? 1 : 0;
+    __syncthreads();
+    {
+        double cv[13];
+        SFOR(j, 0, 13, { cv[j] = cs[tid + 64 * j]; });
+        SFOR(j, 0, 13, { gm(P.dx)[at13(tid + 64 * j, N + 1, N)] = cv[j]; });
+    }
     if (valid) {
         gm(P.viol)[inst] = infeasible ? viol : 0.0;
         gm(P.status)[inst] = bad ? 4 : 0;
@@ -971,14 +1022,20 @@ __global__ __launch_bounds__(64) void k_forward_mf(Params P) {
         gm(P.head)[inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
     }
     // instances whose unconstrained minimiser is feasible are done: full RTI step (the others
-    // are committed by k_ipm once their QP is accepted; failed ones keep their iterate)
-    if (valid && !bad && !infeasible) {
-        gdouble* xw = gm(P.xit) + w * (N + 1) * SZ_V13 + q * 13;
+    // are committed by k_ipm once their QP is accepted; failed ones keep their iterate).  The
+    // wave copies candidate -> iterate cooperatively, element e belonging to instance e / 13.
+    if (__any(commit)) {
+        bool mine[13];
+        SFOR(j, 0, 13, { mine[j] = sflag[(tid + 64 * j) / 13] != 0; });
         for (int k0 = 0; k0 <= N; k0 += 2) {
             double c[2][13];
-            SFOR(j, 0, 2, { SFOR(i, 0, 13, { c[j][i] = cand[(size_t)imin(k0 + j, N) * SZ_V13 + i]; }); });
-            SFOR(j, 0, 2, { if (k0 + j <= N) SFOR(i, 0, 13, { xw[(size_t)(k0 + j) * SZ_V13 + i] = c[j][i]; }); });
+            SFOR(jj, 0, 2, { SFOR(j, 0, 13, { c[jj][j] = gm(P.dx)[at13(tid + 64 * j, N + 1, imin(k0 + jj, N))]; }); });
+            SFOR(jj, 0, 2, {
+                if (k0 + jj <= N) SFOR(j, 0, 13, { if (mine[j]) gm(P.xit)[at13(tid + 64 * j, N + 1, k0 + jj)] = c[jj][j]; });
+            });
         }
+    }
+    if (commit) {
         for (int k0 = 0; k0 < N; k0 += 4) {
             double uo[4][4], vv[4][4];
             SFOR(j, 0, 4, {

@@ -63,12 +63,14 @@ typedef struct cfnmpc_opts {
     double ah_margin;    /* active horizon: an unconstrained input closer to a bound than this
                             fraction of (u_max - u_min) counts as 'tight' (0.10)              */
     int ah_extra;        /* active horizon: stages added after the last tight stage (4)       */
-    int overlap_linearise; /* 1 (default): every RTI step ends with the PREPARATION of the next one
-                            (the RTI scheme's preparation phase: linearisation around the new
-                            iterate, which does not depend on the next x0 / yref), run on an
-                            internal low-priority stream concurrently with the latency-bound
-                            interior-point kernel; 0: linearise at the start of cfnmpc_solve.
-                            Results are bit-identical either way.                              */
+    int overlap_linearise; /* 0 (default): linearise at the start of cfnmpc_solve.  1: every RTI step
+                            ends with the PREPARATION of the next one (the RTI scheme's preparation
+                            phase: linearisation around the new iterate, which does not depend on
+                            the next x0 / yref), run on an internal low-priority stream beside the
+                            latency-bound interior-point kernel (early pass over all instances +
+                            list pass over the interior-point ones, double-buffered A/B/b).
+                            Results are bit-identical either way; on MI355X the two kernels slow
+                            each other down about as much as the overlap saves.     */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);
