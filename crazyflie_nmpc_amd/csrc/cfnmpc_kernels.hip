@@ -1,28 +1,33 @@
 // cfnmpc_kernels.hip -- HIP kernels of the batched Crazyflie SQP-RTI step (gfx950, FP64).
 //
-// Mapping: one NMPC instance per 16-lane DPP row, four instances per wavefront, one wavefront
-// per workgroup (cfnmpc_ws.hpp).  Instances never communicate; every wave runs its own
-// interior-point loop until its four instances are done (wave-uniform trip count via __any).
+// Two mappings, chosen per kernel by what the kernel carries from stage to stage:
+//   * row groups (cfnmpc_ws.hpp): one NMPC instance per 16-lane DPP row, four instances per
+//     wavefront, lane i = row i of every 13-row object -- for the Riccati recursions, which carry
+//     the 13 x 13 cost-to-go (k_factor, k_ipm);
+//   * lane per instance: 64 instances per wavefront, all model arithmetic in registers, 13-vectors
+//     through LDS tiles -- for the kernels that carry at most a 13-vector (k_linearise, k_forward).
+// One wavefront per workgroup; instances never communicate.
 //
-// Kernels, one RTI step = five launches on one stream
-// (k_linearise, k_factor, k_forward, k_compact, k_ipm):
-//   k_linearise : RK4 + forward sensitivities per shooting interval (the role of acados
-//                 sim_erk + CasADi forw_vde, acados_mpc.cpp:84): lane c integrates sensitivity
-//                 COLUMN c; a 13x17 LDS tile re-distributes it into the row form.
-//   k_factor    : start solve, backward: augmented Riccati factorisation of the unconstrained
-//                 QP over all N stages, next stage software-prefetched (2 waves/SIMD).
-//   k_forward   : start solve, forward: unconstrained inputs, feasibility / active-horizon
-//                 decision per wave (streaming sweep, high occupancy).
-//   k_ipm       : only waves with an infeasible instance: Mehrotra predictor-corrector over
-//                 stage-wise Riccati sweeps in delta form (HPIPM's role,
-//                 generate_c_code.py:140), expansion, tail verification.
-//                 Both k_forward (feasible rows) and k_ipm (its rows) end with the full RTI step
-//                 iterate += step (acados_solve() epilogue, acados_mpc.cpp:611-616).
-//   k_sim       : RK4 predictor / plant step (acados_estimator.cpp:573-593).
-//   k_put / k_get / k_init_iterate : layout glue for the C-ABI.
+// Kernels, one RTI step = five launches on one stream:
+//   k_linearise : RK4 + forward sensitivities per shooting interval (the role of acados sim_erk +
+//                 CasADi forw_vde, acados_mpc.cpp:84), written in the row-distributed A / B form.
+//   k_factor    : start solve, backward: augmented Riccati factorisation of the unconstrained QP
+//                 over all N stages, next stage software-prefetched (2 waves/SIMD).
+//   k_forward   : start solve, forward, MATRIX-FREE: dx+ = A dx + B du + b is evaluated as the
+//                 directional derivative of the RK4 map (one forward-mode pass) instead of reading
+//                 A and B; unconstrained inputs, feasibility / active-horizon decision, full RTI
+//                 step of the instances whose unconstrained minimiser respects the input box.
+//   k_compact   : list of the instances that need the interior-point method, by head class.
+//   k_ipm       : those instances only: Mehrotra predictor-corrector over stage-wise Riccati
+//                 sweeps in delta form (HPIPM's role, generate_c_code.py:140) on a compact copy of
+//                 the head stages, expansion, tail verification, full RTI step
+//                 (acados_solve() epilogue, acados_mpc.cpp:611-616).
+//   k_linearise_list : cfnmpc_opts.overlap_linearise only -- re-linearises the interior-point
+//                 instances after the early pass that ran beside k_ipm.
+//   k_sim / k_estimate : RK4 plant step / predictor (acados_estimator.cpp:573-593).
+//   k_put / k_get / k_init_iterate / k_windows : layout glue and reference windows for the C-ABI.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <type_traits>
 
 #include "cfnmpc_dpp.hpp"
@@ -763,42 +768,6 @@ __global__ __launch_bounds__(64, 2) void k_factor(Params P) {
     if (t.L == 0 && t.valid) gm(P.status)[t.inst] = ok ? 0 : 4;
 }
 
-// Unconstrained inputs and state step of the start solve; per instance the largest bound
-// violation, per wave the head of the horizon the interior-point sweeps must cover (0: none).
-__device__ __forceinline__ void start_forward(const Params& P, const Lane& t, double& viol, int& last_tight) {
-    const int N = P.N;
-    const double margin = P.ah_margin * (P.u_max - P.u_min);
-    bool sawnan = false;
-    viol = 0.0;
-    last_tight = -1;
-    double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
-    FwdIn<true> cur, nxt;
-    load_fwd<true>(P, t, 0, cur);
-    double ucur = gm(P.uit)[i4(P, t, 0, t.L & 3)], unxt;
-    for (int k = 0; k < N; k++) {
-        load_fwd<true>(P, t, imin(k + 1, N - 1), nxt);  // prefetch
-        unxt = gm(P.uit)[i4(P, t, imin(k + 1, N - 1), t.L & 3)];
-        st13(blk(P.dx, t, N + 1, k, SZ_V13), t, x);
-        const double v = feedback<true>(t, cur, x);
-        if (t.L < 4) {
-            const double lb = P.u_min - ucur, ub = P.u_max - ucur;
-            gm(P.v)[i4(P, t, k, t.L)] = v;
-            viol = fmax(viol, fmax(lb - v, v - ub));
-            if (v < lb + margin || v > ub - margin) last_tight = k;
-            sawnan = sawnan || !(v == v);
-        }
-        double vr[4];
-        SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
-        x = propagate<true>(t, cur, x, vr);
-        cur = nxt;
-        ucur = unxt;
-    }
-    st13(blk(P.dx, t, N + 1, N, SZ_V13), t, x);
-    viol = row_max(viol);
-    last_tight = (int)row_max((double)last_tight);
-    if (row_max(sawnan ? 1.0 : 0.0) > 0.0) viol = nan("");
-}
-
 // full RTI step of one row (acados_solve() epilogue): iterate += accepted step.  `doit` is
 // row-uniform; the step (P.dx, P.v) was written by this very wave, so the reads hit in L2.
 __device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const bool doit) {
@@ -840,26 +809,6 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
     return head;
 }
 
-__global__ __launch_bounds__(64) void k_forward(Params P) {
-    const Lane t = lane_id(P);
-    double viol;
-    int last_tight;
-    start_forward(P, t, viol, last_tight);
-    const bool okf = t.valid && gm(P.status)[imin(t.inst, P.B - 1)] == 0;
-    const bool bad = t.valid && (!okf || !(viol == viol));
-    const bool infeasible = t.valid && !bad && (viol > 0.0);
-    if (t.valid && t.L == 0) {
-        gm(P.viol)[t.inst] = infeasible ? viol : 0.0;
-        gm(P.status)[t.inst] = bad ? 4 : 0;
-        gm(P.iters)[t.inst] = 0;
-        gm(P.res)[t.inst] = bad ? nan("") : 0.0;
-        gm(P.head)[t.inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
-    }
-    // rows whose unconstrained minimiser is feasible are done: commit them here (the others are
-    // committed by k_ipm once their QP is accepted; failed rows keep their iterate)
-    commit_row(P, t, t.valid && !bad && !infeasible);
-}
-
 // ---------------------------------------------------------------------------------------------
 // Start solve, forward sweep -- lane-per-instance, matrix-free.
 // The forward sweep only needs the PRODUCT  dx+ = A dx + B du + b, never A and B themselves, and
@@ -873,7 +822,7 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
 // P.dx receives the CANDIDATE ITERATE x_k + dx_k (not the step): feasible instances copy it into
 // the iterate in the second loop; the interior-point kernel writes its own steps.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_forward_mf(Params P) {
+__global__ __launch_bounds__(64) void k_forward(Params P) {
     // 13-vectors travel through LDS tiles [instance][13] so that every global access of the wave
     // is a contiguous run (as in k_linearise); K, d, u, v are 32-byte runs per lane already.
     __shared__ double xs[64 * 13], bs[64 * 13], cs[64 * 13];
@@ -1658,9 +1607,7 @@ void launch_linearise_list(const Params& P, int chunks, hipStream_t st) {
 }
 void launch_qp_start(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
-    static const bool rows = std::getenv("CFNMPC_FORWARD_ROWS") != nullptr;   // development aid: A/B against the row-distributed sweep
-    if (rows) hipLaunchKernelGGL(k_forward, dim3(P.NW), dim3(64), 0, st, P);
-    else hipLaunchKernelGGL(k_forward_mf, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+    hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, P);
 }
 void launch_qp_ipm(const Params& P, hipStream_t st) {
