@@ -298,7 +298,7 @@ def main():
                        "nx": 13, "nu": 4, "sharding": f"independent instances, {world} shard(s), no data-path collective",
                        "qp": "Riccati Mehrotra IPM, tol 1e-8, active-horizon sweeps" if args.active_horizon else
                              "Riccati Mehrotra IPM, tol 1e-8, full-horizon sweeps"},
-            "roofline": {"bound": "hbm", "kernel": "QP phase = k_factor + k_forward + k_compact + k_ipm + k_commit "
+            "roofline": {"bound": "hbm", "kernel": "QP phase = k_factor + k_forward + k_compact + k_ipm "
                                                      "(HIP events on the launch stream, summed over the sub-batch launches)",
                          "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
