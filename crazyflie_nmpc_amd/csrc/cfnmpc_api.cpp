@@ -410,7 +410,11 @@ int cfnmpc_get_profile(cfnmpc_solver* s, double* ms_linearise, double* ms_qp, in
 }
 
 #ifdef CFN_PROF
-extern "C++" { namespace cfn { void debug_prof_read(unsigned long long* out, int reset); } }
+extern "C++" { namespace cfn { void debug_prof_read(unsigned long long* out, int reset);
+                               float debug_bench_sweep(const Params& P, int waves, int head, int reps, int which); } }
+float cfnmpc_debug_bench_sweep(cfnmpc_solver* s, int waves, int head, int reps, int which) {
+    return cfn::debug_bench_sweep(s->P, waves, head, reps, which);
+}
 int cfnmpc_debug_prof(unsigned long long* out, int reset) { (void)hipDeviceSynchronize(); cfn::debug_prof_read(out, reset); return 0; }
 #endif
 

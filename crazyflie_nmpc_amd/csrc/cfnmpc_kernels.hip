@@ -433,6 +433,44 @@ __device__ __forceinline__ bool spd4_inv(const double (&S)[10], double (&Si)[10]
     return ok;
 }
 
+// The same inverse in stages, so that the caller can place independent work between the four
+// pivots (each is a dependent chain through v_rsq_f64 and two Newton steps; with one or two waves
+// per SIMD nothing else hides that latency).  Operation order identical to spd4_inv.
+struct Chol4 {
+    double Lm[4][4], Li[4][4];
+    bool ok;
+};
+template <int J>
+__device__ __forceinline__ void chol4_pivot(const double (&S)[10], Chol4& c) {
+    double s = S[s4(J, J)];
+    SFOR(k, 0, J, { s -= c.Lm[J][k] * c.Lm[J][k]; });
+    c.ok = (J == 0 ? true : c.ok) && (s > 0.0);
+    const double inv = rsqrt_nr(s);   // 1 / L_jj
+    c.Lm[J][J] = s * inv;
+    c.Li[J][J] = inv;
+    SFOR(i, J + 1, 4, {
+        double tt = S[s4(i, J)];
+        SFOR(k, 0, J, { tt -= c.Lm[i][k] * c.Lm[J][k]; });
+        c.Lm[i][J] = tt * inv;
+    });
+}
+__device__ __forceinline__ void chol4_finish(Chol4& c, double (&Si)[10]) {
+    SFOR(j, 0, 4, {
+        SFOR(i, j + 1, 4, {
+            double tt = 0;
+            SFOR(k, j, i, { tt -= c.Lm[i][k] * c.Li[k][j]; });
+            c.Li[i][j] = tt * c.Li[i][i];
+        });
+    });
+    SFOR(i, 0, 4, {
+        SFOR(j, i, 4, {
+            double tt = 0;
+            SFOR(k, j, 4, { tt += c.Li[k][i] * c.Li[k][j]; });
+            Si[s4(i, j)] = tt;
+        });
+    });
+}
+
 // Everything one factorisation stage reads from HBM (so that the caller can prefetch it).
 template <bool ABSOLUTE>
 struct StageIn {
@@ -466,6 +504,13 @@ __device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const
     }
 }
 
+// LDS tile of the W transpose, one per row group: lane L writes its row W[L][0..12] as one
+// contiguous run (16-byte stores, row stride WT_ROW = 14 doubles: the 13 runs of a row group fall
+// on disjoint banks) and reads column l as wt[l * WT_ROW + L] (consecutive lanes = consecutive
+// banks).  WT_TILE = 204 doubles staggers the four row groups of a wave by 24 banks, so that their
+// 26-bank runs collide two-fold at most (they collided four-fold with a 224-double tile).
+constexpr int WT_ROW = 14, WT_TILE = 204;
+static_assert(WT_TILE >= 13 * WT_ROW && WT_TILE % 2 == 0, "W transpose tile");
 // One stage of the augmented backward recursion.
 //   Pa[13]: lanes 0..12 row i of P_{k+1}; lane 13 the affine row p_{k+1}' -- on exit the same for
 //           stage k.  ABSOLUTE: start solve with the QP's own affine terms (q_k, b_k, r_k);
@@ -499,37 +544,29 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     // (3) Wt = transpose of W over lanes 0..12; lane 13 keeps the affine row.  The same LDS
     //     round trip hands the columns of B to lanes 0..3.
     double Wt[13];
+#if defined(CFN_VAR) && CFN_VAR == 1   // timing variant: no LDS round trip (wrong numbers)
+    SFOR(l, 0, 13, { Wt[l] = W[l]; });
+#else
     __syncthreads();
     if (t.L < 13) {
-        SFOR(j, 0, 13, { wt[j * 17 + t.L] = W[j]; });
+        SFOR(j, 0, 13, { wt[t.L * WT_ROW + j] = W[j]; });
         SFOR(a, 0, 4, { sb[a * 16 + t.L] = br[a]; });
     }
     __syncthreads();
     // (all 13 reads issued unconditionally, then pinned: otherwise the compiler sinks every
     //  read into its own branch on "lane != 13")
-    SFOR(l, 0, 13, { Wt[l] = wt[imin(t.L, 12) * 17 + l]; });
+    SFOR(l, 0, 13, { Wt[l] = wt[l * WT_ROW + imin(t.L, 12)]; });
     SFOR(l, 0, 13, { pin(Wt[l]); });
     SFOR(l, 0, 13, { Wt[l] = t.L == 13 ? Pa[l] : Wt[l]; });   // lanes 14, 15: don't-care (never broadcast)
-    // (4) M = Q + Wt A  (lane 13: q_k' + hb'A)
-    double M[13];
-    SFOR(j, 0, 13, { M[j] = (t.L == j) ? wq : 0.0; });
-    if (ABSOLUTE) SFOR(j, 0, 13, { dotbc<1, j>(M[j], &is13, in.qv); });   // lane 13: += q_k[j]
-    SFOR(j, 0, 3, { M[j] += Wt[j]; });
-    dot2bc<6, 0>(M[3], M[4], Wt, ar[0], ar[1]);
-    dotbc<6, 0>(M[5], Wt, ar[2]);
-    dot2bc<10, 0>(M[6], M[7], Wt, ar[3], ar[4]);
-    dot2bc<10, 0>(M[8], M[9], Wt, ar[5], ar[6]);
-    dot2bc<13, 0>(M[10], M[11], Wt, ar[7], ar[8]);
-    dotbc<13, 0>(M[12], Wt, ar[9]);
-    // (5) G' = Wt B ; lane 13: rho = g + B'hb
-    double Gp[4];
-    SFOR(a, 0, 4, { Gp[a] = 0.0; });
-    dot2bc<13, 0>(Gp[0], Gp[1], Wt, br[0], br[1]);
-    dot2bc<13, 0>(Gp[2], Gp[3], Wt, br[2], br[3]);
-    SFOR(a, 0, 4, { dotbc<1, a>(Gp[a], &is13, in.g); });   // lane 13: += g[a]
-    // (6) S = R^ + B'V in lanes a < 4, replicated, inverted redundantly by every lane
+#endif
+    // (4) S = R^ + B'V in lanes a < 4, replicated; every lane inverts it redundantly (4x4 Cholesky),
+    //     one pivot at a time BETWEEN the blocks of (5) and (6), which hide the pivots' latency
     double bcl[13];   // lanes >= 4 compute don't-care rows of S (never broadcast)
+#if defined(CFN_VAR) && CFN_VAR == 1
+    SFOR(l, 0, 13, { bcl[l] = V[l & 3]; });
+#else
     SFOR(l, 0, 13, { bcl[l] = sb[(t.L & 3) * 16 + l]; });
+#endif
     double Srow[4];
     SFOR(c, 0, 4, { Srow[c] = (t.L == c) ? in.Rh : 0.0; });
     dot2bc<13, 0>(Srow[0], Srow[1], bcl, V[0], V[1]);
@@ -537,7 +574,35 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     SFOR(c, 0, 4, { settle(Srow[c]); });
     double S[10], Si[10];
     SFOR(a, 0, 4, { SFOR(c, a, 4, { S[s4(a, c)] = bc<a>(Srow[c]); }); });
-    const bool ok = spd4_inv(S, Si);
+    Chol4 ch;
+    chol4_pivot<0>(S, ch);
+    // (5) M = Q + Wt A  (lane 13: q_k' + hb'A)
+    double M[13];
+    SFOR(j, 0, 13, { M[j] = (t.L == j) ? wq : 0.0; });
+    if (ABSOLUTE) SFOR(j, 0, 13, { dotbc<1, j>(M[j], &is13, in.qv); });   // lane 13: += q_k[j]
+    SFOR(j, 0, 3, { M[j] += Wt[j]; });
+    dot2bc<6, 0>(M[3], M[4], Wt, ar[0], ar[1]);
+    dotbc<6, 0>(M[5], Wt, ar[2]);
+    chol4_pivot<1>(S, ch);
+    dot2bc<10, 0>(M[6], M[7], Wt, ar[3], ar[4]);
+    dot2bc<10, 0>(M[8], M[9], Wt, ar[5], ar[6]);
+    chol4_pivot<2>(S, ch);
+    dot2bc<13, 0>(M[10], M[11], Wt, ar[7], ar[8]);
+    dotbc<13, 0>(M[12], Wt, ar[9]);
+    chol4_pivot<3>(S, ch);
+    // (6) G' = Wt B ; lane 13: rho = g + B'hb
+    double Gp[4];
+    SFOR(a, 0, 4, { Gp[a] = 0.0; });
+    dot2bc<13, 0>(Gp[0], Gp[1], Wt, br[0], br[1]);
+    dot2bc<13, 0>(Gp[2], Gp[3], Wt, br[2], br[3]);
+    SFOR(a, 0, 4, { dotbc<1, a>(Gp[a], &is13, in.g); });   // lane 13: += g[a]
+#if defined(CFN_VAR) && CFN_VAR == 4   // timing variant: no 4x4 inverse
+    const bool ok = true;
+    SFOR(e, 0, 10, { Si[e] = S[e]; });
+#else
+    chol4_finish(ch, Si);
+    const bool ok = ch.ok;
+#endif
     // (7) K' = G' Sinv  (lane 13: feed-forward d)
     double Kp[4], nGp[4];
     SFOR(a, 0, 4, {
@@ -552,6 +617,9 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         updbc<j>(Pa[j], Kp, nGp);
     });
     // (9) stores: gain in "lane a holds K[a][.]" form, Sinv, feed-forward
+#if defined(CFN_VAR) && CFN_VAR == 2   // timing variant: no stores
+    if (Pa[0] == 1.2345e-300)
+#endif
     {
         // lanes 0..12 store their column of the gain, lane 13 the feed-forward: one masked
         // region with per-lane addresses
@@ -611,12 +679,18 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
     load_stage<ABSOLUTE>(P, t, head - 1, wq, bufA);
     int k = head - 1;
     while (k >= 0) {
+#if !(defined(CFN_VAR) && CFN_VAR == 3)   // timing variant 3: no loads inside the loop
         load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufB);
+#else
+        bufB = bufA;
+#endif
         ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufA, wq, is13, wt, sb) && ok;
         after(k);
         k--;
         if (k < 0) break;
+#if !(defined(CFN_VAR) && CFN_VAR == 3)
         load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufA);
+#endif
         ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufB, wq, is13, wt, sb) && ok;
         after(k);
         k--;
@@ -760,7 +834,7 @@ __device__ __forceinline__ void sweep_resolve(const Params& P, const Lane& t, co
 // start solve: backward factorisation, forward sweep
 // =============================================================================================
 __global__ __launch_bounds__(64, 2) void k_factor(Params P) {
-    __shared__ double wtile[4][13 * 17 + 3];
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
     const Lane t = lane_id(P);
     bool ok = sweep_factor<true>(P, t, P.N, -1, wtile[t.row], btile[t.row]);
@@ -1095,7 +1169,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
     const unsigned long long pstart = plast;
 #endif
-    __shared__ double wtile[4][13 * 17 + 3];
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
     const int nipm = gm(P.nipm)[0];
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 4);
@@ -1401,6 +1475,32 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
 #endif
 }
 #ifdef CFN_PROF
+// isolated sweeps on one wave per SIMD (development aid): every wave repeats the sweep `reps` times
+__global__ __launch_bounds__(64) void k_bench_sweep(Params P, int head, int reps, int which) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    const Lane t = lane_id(P);
+    bool ok = true;
+    for (int r = 0; r < reps; r++) {
+        if (which == 0) ok = sweep_factor<false>(P, t, head, -1, wtile[t.row], btile[t.row]) && ok;
+        if (which == 1) sweep_forward_delta(P, t, head, gm(P.dva));
+        if (which == 2) sweep_resolve(P, t, head);
+    }
+    if (!ok && t.L == 77) gm(P.res)[0] = 1.0;
+}
+float debug_bench_sweep(const Params& P, int waves, int head, int reps, int which) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_bench_sweep, dim3(waves), dim3(64), 0, 0, P, head, 1, which);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_bench_sweep, dim3(waves), dim3(64), 0, 0, P, head, reps, which);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
 void debug_prof_read(unsigned long long* out, int reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 32);
     if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z); }
