@@ -876,6 +876,12 @@ __device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const
     }
 }
 
+// class index of a head (0: full horizon, 1..N_CHK: checkpoint stages from large to small)
+__device__ __forceinline__ int head_cls(const Params& P, int h) {
+    int r = 0;
+    SFOR(cc, 0, N_CHK, { if (h == chk_stage(N_CHK - 1 - cc) && h < P.N) r = 1 + cc; });
+    return r;
+}
 // head class of an instance: the interior-point sweeps must cover stages [0, want)
 __device__ __forceinline__ int head_class(const Params& P, int want) {
     if (want <= 0) return 0;
@@ -1050,6 +1056,15 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         gm(P.res)[inst] = bad ? nan("") : 0.0;
         gm(P.head)[inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
     }
+    {   // first half of the stable compaction by head class: per-group class counts and ranks
+        const int hc = infeasible ? head_cls(P, head_class(P, last_tight + 1 + P.ah_extra)) : -1;
+        const unsigned long long below = (1ull << tid) - 1ull;
+        SFOR(c, 0, N_CHK + 1, {
+            const unsigned long long m = __ballot(hc == c);
+            if (hc == c) gm(P.rank)[inst] = __popcll(m & below);
+            if (tid == c) gm(P.blkcnt)[blockIdx.x * 8 + c] = __popcll(m);
+        });
+    }
     // instances whose unconstrained minimiser is feasible are done: full RTI step (the others
     // are committed by k_ipm once their QP is accepted; failed ones keep their iterate).  The
     // wave copies candidate -> iterate cooperatively, element e belonging to instance e / 13.
@@ -1077,28 +1092,24 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
 }
 
 // Stable compaction of the instances that need the interior-point method, grouped by head
-// class (largest first) so that the four rows of a wave work on similar horizons.  One block.
+// class (largest first) so that the four rows of a wave work on similar horizons.  k_forward
+// left per-group class counts and per-instance ranks; k_compact (one block) turns the counts
+// into per-group bases, k_scatter places every instance.
 __global__ __launch_bounds__(1024) void k_compact(Params P) {
     constexpr int NC = N_CHK + 1;
     __shared__ int cnt[NC][1024];
     __shared__ int base[NC + 1];
     const int tid = threadIdx.x;
-    const int chunk = (P.B + 1023) / 1024;
-    const int lo = tid * chunk, hi = min(lo + chunk, P.B);
+    const int ng = (P.B + 63) / 64;                 // groups of k_forward
+    const int chunk = (ng + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(lo + chunk, ng);
     int c[NC];
     for (int j = 0; j < NC; j++) c[j] = 0;
-    auto cls = [&](int h) {  // 0: full horizon, 1..N_CHK: checkpoints from large to small
-        int r = 0;
-        SFOR(cc, 0, N_CHK, { if (h == chk_stage(N_CHK - 1 - cc) && h < P.N) r = 1 + cc; });
-        return r;
-    };
-    for (int i = lo; i < hi; i++) {
-        const int h = gm(P.head)[i];
-        if (h > 0) c[cls(h)]++;
-    }
+    for (int g = lo; g < hi; g++)
+        for (int j = 0; j < NC; j++) c[j] += gm(P.blkcnt)[g * 8 + j];
     for (int j = 0; j < NC; j++) cnt[j][tid] = c[j];
     __syncthreads();
-    // exclusive scan over threads, per class (Hillis-Steele on 1024 entries)
+    // inclusive scan over threads, per class (Hillis-Steele on 1024 entries)
     for (int off = 1; off < 1024; off <<= 1) {
         int v[NC];
         for (int j = 0; j < NC; j++) v[j] = tid >= off ? cnt[j][tid - off] : 0;
@@ -1113,12 +1124,21 @@ __global__ __launch_bounds__(1024) void k_compact(Params P) {
         gm(P.nipm)[0] = acc;
     }
     __syncthreads();
+    // counts -> bases, in place
     int pos[NC];
     for (int j = 0; j < NC; j++) pos[j] = base[j] + cnt[j][tid] - c[j];
-    for (int i = lo; i < hi; i++) {
-        const int h = gm(P.head)[i];
-        if (h > 0) gm(P.ilist)[pos[cls(h)]++] = i;
-    }
+    for (int g = lo; g < hi; g++)
+        for (int j = 0; j < NC; j++) {
+            const int n = gm(P.blkcnt)[g * 8 + j];
+            gm(P.blkcnt)[g * 8 + j] = pos[j];
+            pos[j] += n;
+        }
+}
+__global__ __launch_bounds__(256) void k_scatter(Params P) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.B) return;
+    const int h = gm(P.head)[i];
+    if (h > 0) gm(P.ilist)[gm(P.blkcnt)[(i >> 6) * 8 + head_cls(P, h)] + gm(P.rank)[i]] = i;
 }
 
 // =============================================================================================
@@ -1715,6 +1735,7 @@ void launch_qp_start(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, P);
+    hipLaunchKernelGGL(k_scatter, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
 }
 void launch_qp_ipm(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_ipm, dim3(P.NW), dim3(64), 0, st, P);

@@ -82,6 +82,8 @@ struct Params {
     double *res, *viol;          // per instance
     int *ilist;                  // compacted list of the instances that need the interior-point method
     int *nipm;                   // its length
+    int *blkcnt;                 // per 64-instance group of k_forward: instances per head class [group][8]
+    int *rank;                   // per instance: rank among the same-class instances of its group
 };
 
 // linearisation of all instances / of the instances in P.ilist; `chunks` = number of workgroups the
