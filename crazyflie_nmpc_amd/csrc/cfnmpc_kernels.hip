@@ -930,12 +930,15 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
     const gdouble* kp = gm(P.KR) + w * N * SZ_K + q * 4;
     const size_t i4b = (size_t)inst * N * 4;
     // element e = 13 * (local instance) + i of a 13-vector field with `stages` stages per block
-    auto at13 = [&](int e, int stages, int k) -> size_t {
+    // (wave-uniform 64-bit base + 32-bit byte offset per lane: saddr form of the global access)
+    auto el13 = [&](const double* f, int e, int stages, int k) -> gdouble* {
         const int bk = e / 52, off = e - bk * 52;
-        return ((size_t)imin(w0 + bk, P.NW) * stages + k) * SZ_V13 + off;
+        const unsigned bo = (unsigned)(imin(bk, P.NW - w0) * (stages * SZ_V13) + off) * 8u;
+        const char* base = (const char*)(gm(f) + ((size_t)w0 * stages + k) * SZ_V13);
+        return (gdouble*)(base + bo);
     };
     auto issue13 = [&](const double* f, int stages, int k, int tl, double (&r)[13]) {
-        SFOR(j, 0, 13, { r[j] = gm(f)[at13(tl + 64 * j, stages, k)]; });
+        SFOR(j, 0, 13, { r[j] = *el13(f, tl + 64 * j, stages, k); });
     };
     auto land13 = [&](double* tile, const double (&r)[13]) {
         SFOR(j, 0, 13, { tile[tid + 64 * j] = r[j]; });
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         {
             double cv[13];
             SFOR(j, 0, 13, { cv[j] = cs[tl + 64 * j]; });
-            SFOR(j, 0, 13, { gm(P.dx)[at13(tl + 64 * j, N + 1, k)] = cv[j]; });
+            SFOR(j, 0, 13, { *el13(P.dx, tl + 64 * j, N + 1, k) = cv[j]; });
         }
         land13(xs, xr);
         land13(bs, br);
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
     {
         double cv[13];
         SFOR(j, 0, 13, { cv[j] = cs[tid + 64 * j]; });
-        SFOR(j, 0, 13, { gm(P.dx)[at13(tid + 64 * j, N + 1, N)] = cv[j]; });
+        SFOR(j, 0, 13, { *el13(P.dx, tid + 64 * j, N + 1, N) = cv[j]; });
     }
     if (valid) {
         gm(P.viol)[inst] = infeasible ? viol : 0.0;
@@ -1077,9 +1080,9 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         SFOR(j, 0, 13, { mine[j] = sflag[(tid + 64 * j) / 13] != 0; });
         for (int k0 = 0; k0 <= N; k0 += 2) {
             double c[2][13];
-            SFOR(jj, 0, 2, { SFOR(j, 0, 13, { c[jj][j] = gm(P.dx)[at13(tid + 64 * j, N + 1, imin(k0 + jj, N))]; }); });
+            SFOR(jj, 0, 2, { SFOR(j, 0, 13, { c[jj][j] = *el13(P.dx, tid + 64 * j, N + 1, imin(k0 + jj, N)); }); });
             SFOR(jj, 0, 2, {
-                if (k0 + jj <= N) SFOR(j, 0, 13, { if (mine[j]) gm(P.xit)[at13(tid + 64 * j, N + 1, k0 + jj)] = c[jj][j]; });
+                if (k0 + jj <= N) SFOR(j, 0, 13, { if (mine[j]) *el13(P.xit, tid + 64 * j, N + 1, k0 + jj) = c[jj][j]; });
             });
         }
     }
