@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <fstream>
+#include <vector>
 
 #include "../../include/acados_sim_solver_crazyflie.h"
 #include "cf_nmpc_node.hpp"
@@ -55,6 +57,7 @@ int main(int argc, char** argv) {
         if (acados_cfnmpc_init_iterate(1)) return 3;
     }
     double Ts = 0.015;
+    std::vector<double> solve_ms;   // wall time of acados_solve() per step (nlp_out->total_time, acados_mpc.cpp:616)
     for (int t = 0; t < steps; t++) {
         cf::CrazyflieState msg;
         for (int i = 0; i < 3; i++) { msg.pos[i] = x[i]; msg.vel[i] = x[7 + i]; msg.rates[i] = x[10 + i]; }
@@ -68,6 +71,7 @@ int main(int argc, char** argv) {
                      nmpc.last_cmd_vel.linear_z, nmpc.last_cmd_vel.angular_z);
         std::fprintf(out, ",%d,%d,%d,%d", nmpc.last_motvel.w1, nmpc.last_motvel.w2, nmpc.last_motvel.w3, nmpc.last_motvel.w4);
         std::fprintf(out, ",%.6g,%d\n", nmpc.acados_out.KKT_res, nlp_out->qp_iter);
+        solve_ms.push_back(1e3 * nmpc.acados_out.cpu_time);
         // plant: one sampling period of the model with u0 (FP64 u, App. B1)
         sim_in_set(crazyflie_sim_config, crazyflie_sim_dims, crazyflie_sim_in, "T", &Ts);
         sim_in_set(crazyflie_sim_config, crazyflie_sim_dims, crazyflie_sim_in, "x", x);
@@ -77,6 +81,11 @@ int main(int argc, char** argv) {
         sim_out_get(crazyflie_sim_config, crazyflie_sim_dims, crazyflie_sim_out, "xn", x);
     }
     std::fclose(out);
+    if (!solve_ms.empty()) {   // config C1: single-instance latency against the node's 15 ms period
+        std::sort(solve_ms.begin(), solve_ms.end());
+        std::fprintf(stderr, "acados_solve() wall time over %zu steps [ms]: median %.3f  p90 %.3f  max %.3f\n", solve_ms.size(),
+                     solve_ms[solve_ms.size() / 2], solve_ms[solve_ms.size() * 9 / 10], solve_ms.back());
+    }
     crazyflie_acados_sim_free();
     return 0;
 }

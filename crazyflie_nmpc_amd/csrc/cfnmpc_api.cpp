@@ -144,7 +144,15 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     s->aux = nullptr;
     s->ev_start = s->ev_aux = nullptr;
     s->lin_valid = false;
-    s->chunks_all = s->overlap ? 5 : 1;
+    // the shooting intervals of a 64-instance group are independent: spread them over enough
+    // workgroups to fill the 1024 SIMDs when the batch alone does not (a single instance then
+    // linearises its 50 intervals in parallel instead of one after the other)
+    {
+        const int groups = (batch + 63) / 64;
+        int c = s->overlap ? 5 : 1;
+        if (groups * c < 1024) c = (1024 + groups - 1) / groups;
+        s->chunks_all = c < 1 ? 1 : (c > o.N ? o.N : c);
+    }
     s->chunks_list = 10;
     if (const char* e = std::getenv("CFNMPC_LIN_CHUNKS")) {   // development aid
         int a = 0, b = 0;
