@@ -548,35 +548,36 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     dot2bc<10, 0>(W[8], W[9], Pa, ar[5], ar[6]);
     dot2bc<13, 0>(W[10], W[11], Pa, ar[7], ar[8]);
     dotbc<13, 0>(W[12], Pa, ar[9]);
+    // (3) Wt = transpose of W over lanes 0..12 through the LDS tile (lane 13 keeps the affine row);
+    //     the same round trip hands the columns of B to lanes 0..3.  The tile is written BEFORE V
+    //     is formed and S is formed BEFORE the transposed rows are used, so that both LDS
+    //     latencies sit behind 52 broadcast FMAs each.
+    double Wt[13];
+#if defined(CFN_VAR) && CFN_VAR == 1   // timing variant: no LDS round trip (wrong numbers)
     SFOR(a, 0, 4, { V[a] = 0.0; });
     dot2bc<13, 0>(V[0], V[1], Pa, br[0], br[1]);
     dot2bc<13, 0>(V[2], V[3], Pa, br[2], br[3]);
-    // (3) Wt = transpose of W over lanes 0..12; lane 13 keeps the affine row.  The same LDS
-    //     round trip hands the columns of B to lanes 0..3.
-    double Wt[13];
-#if defined(CFN_VAR) && CFN_VAR == 1   // timing variant: no LDS round trip (wrong numbers)
     SFOR(l, 0, 13, { Wt[l] = W[l]; });
+    double bcl[13];
+    SFOR(l, 0, 13, { bcl[l] = V[l & 3]; });
 #else
     __syncthreads();
     if (t.L < 13) {
         SFOR(j, 0, 13, { wt[t.L * WT_ROW + j] = W[j]; });
         SFOR(a, 0, 4, { sb[a * 16 + t.L] = br[a]; });
     }
+    SFOR(a, 0, 4, { V[a] = 0.0; });
+    dot2bc<13, 0>(V[0], V[1], Pa, br[0], br[1]);
+    dot2bc<13, 0>(V[2], V[3], Pa, br[2], br[3]);
     __syncthreads();
+    double bcl[13];   // lanes >= 4 compute don't-care rows of S (never broadcast)
+    SFOR(l, 0, 13, { bcl[l] = sb[(t.L & 3) * 16 + l]; });
     // (all 13 reads issued unconditionally, then pinned: otherwise the compiler sinks every
     //  read into its own branch on "lane != 13")
     SFOR(l, 0, 13, { Wt[l] = wt[l * WT_ROW + imin(t.L, 12)]; });
-    SFOR(l, 0, 13, { pin(Wt[l]); });
-    SFOR(l, 0, 13, { Wt[l] = t.L == 13 ? Pa[l] : Wt[l]; });   // lanes 14, 15: don't-care (never broadcast)
 #endif
     // (4) S = R^ + B'V in lanes a < 4, replicated; every lane inverts it redundantly (4x4 Cholesky),
     //     one pivot at a time BETWEEN the blocks of (5) and (6), which hide the pivots' latency
-    double bcl[13];   // lanes >= 4 compute don't-care rows of S (never broadcast)
-#if defined(CFN_VAR) && CFN_VAR == 1
-    SFOR(l, 0, 13, { bcl[l] = V[l & 3]; });
-#else
-    SFOR(l, 0, 13, { bcl[l] = sb[(t.L & 3) * 16 + l]; });
-#endif
     double Srow[4];
     SFOR(c, 0, 4, { Srow[c] = (t.L == c) ? in.Rh : 0.0; });
     dot2bc<13, 0>(Srow[0], Srow[1], bcl, V[0], V[1]);
@@ -584,6 +585,10 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     SFOR(c, 0, 4, { settle(Srow[c]); });
     double S[10], Si[10];
     SFOR(a, 0, 4, { SFOR(c, a, 4, { S[s4(a, c)] = bc<a>(Srow[c]); }); });
+#if !(defined(CFN_VAR) && CFN_VAR == 1)
+    SFOR(l, 0, 13, { pin(Wt[l]); });
+    SFOR(l, 0, 13, { Wt[l] = t.L == 13 ? Pa[l] : Wt[l]; });   // lanes 14, 15: don't-care (never broadcast)
+#endif
     Chol4 ch;
     chol4_pivot<0>(S, ch);
     // (5) M = Q + Wt A  (lane 13: q_k' + hb'A)
