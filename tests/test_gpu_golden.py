@@ -97,7 +97,12 @@ def test_acados_dropin_replay_matches_batch_api(tmp_path):
             save_traj_text(trajfile, t["smooth_step"])
             traj = np.loadtxt(trajfile)
         out_csv = tmp_path / f"{mode}.csv"
-        subprocess.check_call([exe, mode, trajfile, str(steps), str(tmp_path / "x0.txt"), "1", str(out_csv)])
+        run = subprocess.run([exe, mode, trajfile, str(steps), str(tmp_path / "x0.txt"), "1", str(out_csv)],
+                             check=True, capture_output=True, text=True)
+        # single-instance latency (config C1): acados_solve() must fit the node's 15 ms period
+        lat = [ln for ln in run.stderr.splitlines() if "acados_solve() wall time" in ln]
+        assert lat, run.stderr
+        assert float(lat[0].split("median")[1].split()[0]) < 15.0, lat[0]
         R = np.loadtxt(out_csv, delimiter=",")
         assert R.shape == (steps, 3 + 4 + 4 + 13 + 4 + 4 + 2)
         assert (R[:, 1] == 0).all()                                  # acados_solve() status
