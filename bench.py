@@ -308,7 +308,7 @@ def main():
             "qp_stats": {"status_ok_frac": stats[0] / total_inst, "mean_ipm_iters": stats[2] / total_inst,
                          "frac_needing_ipm": stats[3] / total_inst, "mean_head_stages": stats[4] / total_inst},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU restatement is timed at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(seed)
             except Exception as e:  # the baseline is a report, never a dependency of the GPU number
