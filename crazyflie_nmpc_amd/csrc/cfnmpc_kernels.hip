@@ -219,12 +219,6 @@ __device__ __forceinline__ void sens_column(const JacPoint (&J)[4], const double
 //   GATHER = true : the instances P.ilist[64 g ..] (the interior-point instances of this step,
 //                   whose iterate only became final after the early pass over everybody).
 // Lanes without an instance work on the spare workspace block NW (finite data, never read).
-// timing variant (development builds): -DCFN_LIN_VAR=1 drops the global stores of k_linearise
-#if defined(CFN_LIN_VAR) && CFN_LIN_VAR == 1
-#define LIN_STORE(v) ((v) == 1.2345e-300)
-#else
-#define LIN_STORE(v) true
-#endif
 template <bool GATHER>
 __device__ __forceinline__ void linearise_body(const Params& P, double* sx, double (*sc)[64 * 13], int* sinst) {
     const int tid = threadIdx.x;
@@ -327,7 +321,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         SFOR(r, 0, NS, {                                                                                \
             const int e = tl + 64 * r;                                                                  \
             const int li = e / (NS), i = e - li * (NS);                                                 \
-            if (LIN_STORE(tv[r])) *el(field, li, i, N, k, SZ, pre4, NS) = tv[r];                        \
+            *el(field, li, i, N, k, SZ, pre4, NS) = tv[r];                                              \
         });                                                                                             \
     }
         CFN_STORE(P.b, SZ_V13, 0, 13, 0);
@@ -409,43 +403,10 @@ __device__ __forceinline__ double rcp_nr(double x) {
     r = r * (2.0 - x * r);
     return r;
 }
-// symmetric positive definite 4x4 (packed upper) -> inverse (packed upper); false if not SPD
-__device__ __forceinline__ bool spd4_inv(const double (&S)[10], double (&Si)[10]) {
-    double Lm[4][4], Li[4][4];
-    bool ok = true;
-    SFOR(j, 0, 4, {
-        double s = S[s4(j, j)];
-        SFOR(k, 0, j, { s -= Lm[j][k] * Lm[j][k]; });
-        ok = ok && (s > 0.0);
-        const double inv = rsqrt_nr(s);   // 1 / L_jj
-        Lm[j][j] = s * inv;
-        Li[j][j] = inv;
-        SFOR(i, j + 1, 4, {
-            double tt = S[s4(i, j)];
-            SFOR(k, 0, j, { tt -= Lm[i][k] * Lm[j][k]; });
-            Lm[i][j] = tt * inv;
-        });
-    });
-    SFOR(j, 0, 4, {
-        SFOR(i, j + 1, 4, {
-            double tt = 0;
-            SFOR(k, j, i, { tt -= Lm[i][k] * Li[k][j]; });
-            Li[i][j] = tt * Li[i][i];
-        });
-    });
-    SFOR(i, 0, 4, {
-        SFOR(j, i, 4, {
-            double tt = 0;
-            SFOR(k, j, 4, { tt += Li[k][i] * Li[k][j]; });
-            Si[s4(i, j)] = tt;
-        });
-    });
-    return ok;
-}
-
-// The same inverse in stages, so that the caller can place independent work between the four
-// pivots (each is a dependent chain through v_rsq_f64 and two Newton steps; with one or two waves
-// per SIMD nothing else hides that latency).  Operation order identical to spd4_inv.
+// Symmetric positive definite 4x4 (packed upper) -> inverse (packed upper) by Cholesky, in stages,
+// so that the caller can place independent work between the four pivots (each is a dependent
+// chain through v_rsq_f64 and two Newton steps; with one or two waves per SIMD nothing else hides
+// that latency).  c.ok = false if a pivot is not positive.
 struct Chol4 {
     double Lm[4][4], Li[4][4];
     bool ok;
@@ -553,14 +514,6 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     //     is formed and S is formed BEFORE the transposed rows are used, so that both LDS
     //     latencies sit behind 52 broadcast FMAs each.
     double Wt[13];
-#if defined(CFN_VAR) && CFN_VAR == 1   // timing variant: no LDS round trip (wrong numbers)
-    SFOR(a, 0, 4, { V[a] = 0.0; });
-    dot2bc<13, 0>(V[0], V[1], Pa, br[0], br[1]);
-    dot2bc<13, 0>(V[2], V[3], Pa, br[2], br[3]);
-    SFOR(l, 0, 13, { Wt[l] = W[l]; });
-    double bcl[13];
-    SFOR(l, 0, 13, { bcl[l] = V[l & 3]; });
-#else
     __syncthreads();
     if (t.L < 13) {
         SFOR(j, 0, 13, { wt[t.L * WT_ROW + j] = W[j]; });
@@ -575,7 +528,6 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     // (all 13 reads issued unconditionally, then pinned: otherwise the compiler sinks every
     //  read into its own branch on "lane != 13")
     SFOR(l, 0, 13, { Wt[l] = wt[l * WT_ROW + imin(t.L, 12)]; });
-#endif
     // (4) S = R^ + B'V in lanes a < 4, replicated; every lane inverts it redundantly (4x4 Cholesky),
     //     one pivot at a time BETWEEN the blocks of (5) and (6), which hide the pivots' latency
     double Srow[4];
@@ -585,10 +537,8 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     SFOR(c, 0, 4, { settle(Srow[c]); });
     double S[10], Si[10];
     SFOR(a, 0, 4, { SFOR(c, a, 4, { S[s4(a, c)] = bc<a>(Srow[c]); }); });
-#if !(defined(CFN_VAR) && CFN_VAR == 1)
     SFOR(l, 0, 13, { pin(Wt[l]); });
     SFOR(l, 0, 13, { Wt[l] = t.L == 13 ? Pa[l] : Wt[l]; });   // lanes 14, 15: don't-care (never broadcast)
-#endif
     Chol4 ch;
     chol4_pivot<0>(S, ch);
     // (5) M = Q + Wt A  (lane 13: q_k' + hb'A)
@@ -611,13 +561,8 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     dot2bc<13, 0>(Gp[0], Gp[1], Wt, br[0], br[1]);
     dot2bc<13, 0>(Gp[2], Gp[3], Wt, br[2], br[3]);
     SFOR(a, 0, 4, { dotbc<1, a>(Gp[a], &is13, in.g); });   // lane 13: += g[a]
-#if defined(CFN_VAR) && CFN_VAR == 4   // timing variant: no 4x4 inverse
-    const bool ok = true;
-    SFOR(e, 0, 10, { Si[e] = S[e]; });
-#else
     chol4_finish(ch, Si);
     const bool ok = ch.ok;
-#endif
     // (7) K' = G' Sinv  (lane 13: feed-forward d)
     double Kp[4], nGp[4];
     SFOR(a, 0, 4, {
@@ -632,9 +577,6 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         updbc<j>(Pa[j], Kp, nGp);
     });
     // (9) stores: gain in "lane a holds K[a][.]" form, Sinv, feed-forward
-#if defined(CFN_VAR) && CFN_VAR == 2   // timing variant: no stores
-    if (Pa[0] == 1.2345e-300)
-#endif
     {
         // lanes 0..12 store their column of the gain, lane 13 the feed-forward: one masked
         // region with per-lane addresses
@@ -694,18 +636,12 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
     load_stage<ABSOLUTE>(P, t, head - 1, wq, bufA);
     int k = head - 1;
     while (k >= 0) {
-#if !(defined(CFN_VAR) && CFN_VAR == 3)   // timing variant 3: no loads inside the loop
         load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufB);
-#else
-        bufB = bufA;
-#endif
         ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufA, wq, is13, wt, sb) && ok;
         after(k);
         k--;
         if (k < 0) break;
-#if !(defined(CFN_VAR) && CFN_VAR == 3)
         load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufA);
-#endif
         ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufB, wq, is13, wt, sb) && ok;
         after(k);
         k--;

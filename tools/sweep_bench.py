@@ -1,6 +1,7 @@
 """Development aid: isolated timing of the interior-point sweeps (factor / forward / resolve) with
-one wave per SIMD, for libraries built with -DCFN_PROF [-DCFN_VAR=n] (timing variants of the factor
-stage: 1 no LDS transpose, 2 no stores, 3 no loads, 4 no 4x4 inverse).
+one or two waves per SIMD, for a library built with -DCFN_PROF (the timing variants quoted in DESIGN.md
+-- factor stage without the LDS transpose / stores / loads / 4x4 inverse -- were one-off edits of
+factor_stage, git history of this file's commit).
     python tools/sweep_bench.py lib0.so [lib1.so ...]"""
 import os, sys, ctypes as C, subprocess
 if len(sys.argv) > 2:   # one process per library (the library is loaded once per process)
