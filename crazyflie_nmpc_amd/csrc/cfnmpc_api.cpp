@@ -121,6 +121,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->ah_margin = 0.10;
     o->ah_extra = 4;
     o->overlap_linearise = 0;
+    o->active_set = 1;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
@@ -172,6 +173,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.active_horizon = o.active_horizon ? 1 : 0;
     P.ah_margin = o.ah_margin;
     P.ah_extra = o.ah_extra;
+    P.active_set = o.active_set ? 1 : 0;
     // one spare workspace block (index P.NW) parks the idle rows of compacted interior-point waves
     const size_t NW = P.NW + 1, N = P.N;
     int rc = CFNMPC_OK;
@@ -186,7 +188,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(Rh, NW * 4 * N * 4); ALLOC(g, NW * 4 * N * 4); ALLOC(dx, NW * (N + 1) * cfn::SZ_V13);
     ALLOC(cAR, NW * N * cfn::SZ_A); ALLOC(cBR, NW * N * cfn::SZ_B); ALLOC(cKR, NW * N * cfn::SZ_K);
     ALLOC(cSinv, NW * N * cfn::SZ_S); ALLOC(cd, NW * 4 * N * 4); ALLOC(cPchk, NW * cfn::N_CHK * cfn::SZ_P);
-    ALLOC(cv, NW * 4 * N * 4); ALLOC(cuit, NW * 4 * N * 4);
+    ALLOC(cv, NW * 4 * N * 4); ALLOC(cuit, NW * 4 * N * 4); ALLOC(cdx, NW * (N + 1) * cfn::SZ_V13);
     ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4); ALLOC(viol, NW * 4);
     ALLOC(ilist, NW * 4); ALLOC(nipm, 4);
     ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * 8); ALLOC(rank, NW * 4);

@@ -78,6 +78,8 @@ struct Params {
     double *dx;  // (N+1) x SZ_V13: step in x of the accepted QP solution (commit buffer)
     // compact scratch of the interior-point kernel (same block shapes, indexed by compacted slot)
     double *cAR, *cBR, *cKR, *cSinv, *cd, *cPchk, *cv, *cuit;
+    double *cdx;     // (N+1) x SZ_V13 per compact block: state deltas of the active-set solve
+    int active_set;  // 1: try the primal-dual active-set solve before the interior-point iteration
     int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
     double *res, *viol;          // per instance
     int *ilist;                  // compacted list of the instances that need the interior-point method

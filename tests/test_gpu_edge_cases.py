@@ -16,17 +16,21 @@ def _inputs(oracle, B, N, seed, scale=1.0):
 
 @pytest.mark.parametrize("N", [30, 100])
 @pytest.mark.parametrize("active_horizon", [0, 1])
-def test_other_horizons_match_oracle(oracle, cref, N, active_horizon):
+@pytest.mark.parametrize("active_set", [0, 1])
+def test_other_horizons_match_oracle(oracle, cref, N, active_horizon, active_set):
     """Mixed-horizon config C5 runs one solver object per horizon bucket; each bucket must agree
-    with the CPU restatement (dt stays 15 ms, Tf = 0.015 N)."""
+    with the CPU restatement (dt stays 15 ms, Tf = 0.015 N).  With the interior point on both
+    sides (active_set = 0) the agreement is FP64-level; the active-set solve is exact, so there the
+    bound is the restatement's interior-point accuracy at tol 1e-11 (measured 5e-8)."""
     from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
     from crazyflie_nmpc_amd.solver import INIT_HOVER
     B = 37
     x0, yref, yref_e = _inputs(oracle, B, N, seed=11 + N, scale=1.5)
     tol = 1e-11
-    s = BatchSolver(B, default_opts(N=N, tol=tol, active_horizon=active_horizon))
+    s = BatchSolver(B, default_opts(N=N, tol=tol, active_horizon=active_horizon, active_set=active_set))
     s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
     opts = cref.default_opts(N=N, tol=tol)
+    bound = 5e-6 if active_set else 1e-8
     xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
     x = x0.copy()
     nipm = 0
@@ -36,7 +40,7 @@ def test_other_horizons_match_oracle(oracle, cref, N, active_horizon):
         st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
         xg, ug = s.get_iterate()
         assert (st == 0).all() and (st_r == 0).all()
-        assert np.abs(ug - ur).max() < 1e-8 and np.abs(xg - xr).max() < 1e-8, (N, t)
+        assert np.abs(ug - ur).max() < bound and np.abs(xg - xr).max() < bound, (N, t)
         nipm += int((it > 0).sum())
         x = sim(x, s.get_u(0), T=0.015, steps=1)
         ur[:] = ug; xr[:] = xg
@@ -44,20 +48,26 @@ def test_other_horizons_match_oracle(oracle, cref, N, active_horizon):
 
 
 @pytest.mark.parametrize("B", [1, 2, 3, 5, 64, 65])
-def test_tiny_and_ragged_batches(oracle, cref, B):
+@pytest.mark.parametrize("active_set", [0, 1])
+def test_tiny_and_ragged_batches(oracle, cref, B, active_set):
     from crazyflie_nmpc_amd import BatchSolver, default_opts
     from crazyflie_nmpc_amd.solver import INIT_HOVER
     N = 50
     x0, yref, yref_e = _inputs(oracle, B, N, seed=100 + B, scale=2.0)
-    s = BatchSolver(B, default_opts(active_horizon=0))
+    s = BatchSolver(B, default_opts(active_horizon=0, active_set=active_set))
     s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
     s.solve(1)
     xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
     st_r, it_r, _, _ = cref.rti_step(cref.default_opts(), xr, ur, x0.copy(), yref, yref_e, nthreads=0)
     st, it, _ = s.stats()
     xg, ug = s.get_iterate()
-    assert (st == 0).all() and (np.abs(it - it_r) <= 1).all()
-    assert np.abs(ug - ur).max() < 1e-6 and np.abs(xg - xr).max() < 1e-6
+    assert (st == 0).all() and ((it > 0) == (it_r > 0)).all()
+    if active_set:
+        assert (it <= it_r).all()           # never more solves than interior-point iterations here
+        assert np.abs(ug - ur).max() < 5e-4 and np.abs(xg - xr).max() < 5e-4   # restatement stops at tol 1e-8
+    else:
+        assert (np.abs(it - it_r) <= 1).all()
+        assert np.abs(ug - ur).max() < 1e-6 and np.abs(xg - xr).max() < 1e-6
 
 
 def test_iteration_cap_and_nan_status(oracle):
@@ -67,7 +77,7 @@ def test_iteration_cap_and_nan_status(oracle):
     from crazyflie_nmpc_amd.solver import INIT_HOVER
     B, N = 8, 50
     x0, yref, yref_e = _inputs(oracle, B, N, seed=5, scale=3.0)
-    s = BatchSolver(B, default_opts(max_iter=2))
+    s = BatchSolver(B, default_opts(max_iter=2, active_set=0))
     s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
     s.solve(1)
     st, it, rs = s.stats()
