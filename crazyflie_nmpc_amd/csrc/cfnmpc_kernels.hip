@@ -1001,6 +1001,7 @@ __device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const
     }
 }
 
+constexpr int N_BIN = (N_CHK + 1) * 3, BIN_STRIDE = 32;   // compaction bins: head class x difficulty
 // class index of a head (0: full horizon, 1..N_CHK: checkpoint stages from large to small)
 __device__ __forceinline__ int head_cls(const Params& P, int h) {
     int r = 0;
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         __syncthreads();
     }
     double viol = 0.0;
-    int last_tight = -1;
+    int last_tight = -1, nviol = 0;
     bool sawnan = false;
     In cur, nxt;
     load(0, cur);
@@ -1103,6 +1104,7 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
             du[a] = -cur.d[a] - acc;
             const double lb = P.u_min - cur.u[a], ub = P.u_max - cur.u[a];
             viol = fmax(viol, fmax(lb - du[a], du[a] - ub));
+            nviol += (du[a] < lb || du[a] > ub) ? 1 : 0;
             if (du[a] < lb + margin || du[a] > ub - margin) last_tight = k;
             sawnan = sawnan || !(du[a] == du[a]);
             gm(P.v)[i4b + (size_t)k * 4 + a] = du[a];
@@ -1184,13 +1186,16 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         gm(P.res)[inst] = bad ? nan("") : 0.0;
         gm(P.head)[inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
     }
-    {   // first half of the stable compaction by head class: per-group class counts and ranks
-        const int hc = infeasible ? head_cls(P, head_class(P, last_tight + 1 + P.ah_extra)) : -1;
+    {   // first half of the stable compaction: per-group bin counts and ranks.  Bin = head class
+        // (largest first) x difficulty (number of violated inputs of the unconstrained minimiser:
+        // >= 4, 2..3, 1 -- the active-set solve needs more passes the more bounds are involved,
+        // and a wave lasts as long as the slowest of its four rows)
+        const int hc = infeasible ? head_cls(P, head_class(P, last_tight + 1 + P.ah_extra)) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
         const unsigned long long below = (1ull << tid) - 1ull;
-        SFOR(c, 0, N_CHK + 1, {
+        SFOR(c, 0, N_BIN, {
             const unsigned long long m = __ballot(hc == c);
-            if (hc == c) gm(P.rank)[inst] = __popcll(m & below);
-            if (tid == c) gm(P.blkcnt)[blockIdx.x * 8 + c] = __popcll(m);
+            if (hc == c) gm(P.rank)[inst] = (c << 8) | __popcll(m & below);
+            if (tid == c) gm(P.blkcnt)[blockIdx.x * BIN_STRIDE + c] = __popcll(m);
         });
     }
     // instances whose unconstrained minimiser is feasible are done: full RTI step (the others
@@ -1223,22 +1228,22 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
 // class (largest first) so that the four rows of a wave work on similar horizons.  k_forward
 // left per-group class counts and per-instance ranks; k_compact (one block) turns the counts
 // into per-group bases, k_scatter places every instance.
-__global__ __launch_bounds__(1024) void k_compact(Params P) {
-    constexpr int NC = N_CHK + 1;
-    __shared__ int cnt[NC][1024];
+__global__ __launch_bounds__(256) void k_compact(Params P) {
+    constexpr int NC = N_BIN, NT = 256;
+    __shared__ int cnt[NC][NT];
     __shared__ int base[NC + 1];
     const int tid = threadIdx.x;
     const int ng = (P.B + 63) / 64;                 // groups of k_forward
-    const int chunk = (ng + 1023) / 1024;
+    const int chunk = (ng + NT - 1) / NT;
     const int lo = tid * chunk, hi = min(lo + chunk, ng);
     int c[NC];
     for (int j = 0; j < NC; j++) c[j] = 0;
     for (int g = lo; g < hi; g++)
-        for (int j = 0; j < NC; j++) c[j] += gm(P.blkcnt)[g * 8 + j];
+        for (int j = 0; j < NC; j++) c[j] += gm(P.blkcnt)[g * BIN_STRIDE + j];
     for (int j = 0; j < NC; j++) cnt[j][tid] = c[j];
     __syncthreads();
-    // inclusive scan over threads, per class (Hillis-Steele on 1024 entries)
-    for (int off = 1; off < 1024; off <<= 1) {
+    // inclusive scan over threads, per bin (Hillis-Steele)
+    for (int off = 1; off < NT; off <<= 1) {
         int v[NC];
         for (int j = 0; j < NC; j++) v[j] = tid >= off ? cnt[j][tid - off] : 0;
         __syncthreads();
@@ -1247,7 +1252,7 @@ __global__ __launch_bounds__(1024) void k_compact(Params P) {
     }
     if (tid == 0) {
         int acc = 0;
-        for (int j = 0; j < NC; j++) { base[j] = acc; acc += cnt[j][1023]; }
+        for (int j = 0; j < NC; j++) { base[j] = acc; acc += cnt[j][NT - 1]; }
         base[NC] = acc;
         gm(P.nipm)[0] = acc;
     }
@@ -1257,16 +1262,18 @@ __global__ __launch_bounds__(1024) void k_compact(Params P) {
     for (int j = 0; j < NC; j++) pos[j] = base[j] + cnt[j][tid] - c[j];
     for (int g = lo; g < hi; g++)
         for (int j = 0; j < NC; j++) {
-            const int n = gm(P.blkcnt)[g * 8 + j];
-            gm(P.blkcnt)[g * 8 + j] = pos[j];
+            const int n = gm(P.blkcnt)[g * BIN_STRIDE + j];
+            gm(P.blkcnt)[g * BIN_STRIDE + j] = pos[j];
             pos[j] += n;
         }
 }
 __global__ __launch_bounds__(256) void k_scatter(Params P) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.B) return;
-    const int h = gm(P.head)[i];
-    if (h > 0) gm(P.ilist)[gm(P.blkcnt)[(i >> 6) * 8 + head_cls(P, h)] + gm(P.rank)[i]] = i;
+    if (gm(P.head)[i] > 0) {
+        const int r = gm(P.rank)[i];
+        gm(P.ilist)[gm(P.blkcnt)[(i >> 6) * BIN_STRIDE + (r >> 8)] + (r & 255)] = i;
+    }
 }
 
 // =============================================================================================
@@ -1906,7 +1913,7 @@ void launch_linearise_list(const Params& P, int chunks, hipStream_t st) {
 void launch_qp_start(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, st, P);
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_scatter, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
 }
 void launch_qp_ipm(const Params& P, hipStream_t st) {

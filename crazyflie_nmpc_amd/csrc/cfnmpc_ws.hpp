@@ -84,8 +84,8 @@ struct Params {
     double *res, *viol;          // per instance
     int *ilist;                  // compacted list of the instances that need the interior-point method
     int *nipm;                   // its length
-    int *blkcnt;                 // per 64-instance group of k_forward: instances per head class [group][8]
-    int *rank;                   // per instance: rank among the same-class instances of its group
+    int *blkcnt;                 // per 64-instance group of k_forward: instances per compaction bin [group][32]
+    int *rank;                   // per instance: (bin << 8) | rank among the same-bin instances of its group
 };
 
 // linearisation of all instances / of the instances in P.ilist; `chunks` = number of workgroups the
