@@ -476,6 +476,42 @@ def riccati_ipm(qp: StageQP, **opts):
     return dict(dx=xs, du=v, lam_l=ll, lam_u=lu, **info)
 
 
+def pdas_dense(qp: StageQP, max_solves=12):
+    """Primal-dual active-set solve of the condensed QP (dense algebra) -- the CPU statement of the
+    engine's `active_set` path (include/cfnmpc.h): classify every input from
+    the unconstrained minimiser (below / above its bound = active, else free), solve the QP with
+    the active inputs fixed, re-classify (a free input that leaves the box becomes active; a lower-
+    active one stays while its multiplier H v + h > 0, an upper-active one while it is < 0), stop
+    when the classification is stationary -- which is the KKT system of the strictly convex QP.
+    Returns dict(dx, du, solves, converged); solves = 0 if the unconstrained minimiser is feasible."""
+    H, h, Gam, g = condense(qp)
+    n = H.shape[0]
+    lb = qp.lb.reshape(-1)
+    ub = qp.ub.reshape(-1)
+    v0 = np.linalg.solve(H, -h)
+    v = v0
+    lo, up = v0 < lb, v0 > ub
+    solves, converged = 0, True
+    if lo.any() or up.any():
+        converged = False
+        while solves < max_solves:
+            solves += 1
+            act = lo | up
+            free = ~act
+            v = np.where(lo, lb, np.where(up, ub, 0.0))
+            if free.any():
+                v[free] = np.linalg.solve(H[np.ix_(free, free)], -h[free] - H[np.ix_(free, act)] @ v[act])
+            grad = H @ v + h
+            lo2 = (free & (v < lb)) | (lo & (grad > 0))
+            up2 = (free & (v > ub)) | (up & (grad < 0))
+            if np.array_equal(lo2, lo) and np.array_equal(up2, up):
+                converged = True
+                break
+            lo, up = lo2, up2
+    dx = (Gam @ v + g).reshape(qp.N + 1, NX)
+    return dict(dx=dx, du=v.reshape(qp.N, NU), solves=solves, converged=converged)
+
+
 def _steplen(tl, tu, ll, lu, dtl, dtu, dll, dlu):
     a = 1.0
     for z, dz in ((tl, dtl), (tu, dtu), (ll, dll), (lu, dlu)):

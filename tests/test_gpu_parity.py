@@ -164,3 +164,31 @@ def test_ragged_batch_and_status(oracle, cref):
     # different central paths (active-horizon vs full-horizon sweeps) at the default tol 1e-8:
     # agreement is bounded by ~sqrt(tol) for nearly degenerate bounds
     assert np.abs(ug - ur).max() < 5e-4 and np.abs(xg - xr).max() < 5e-4
+
+
+def test_active_set_solves_match_oracle_exactly(oracle):
+    """The engine's default QP method (primal-dual active-set solves on the Riccati
+    factorisation) against its CPU twin oracle.pdas_dense on QPs built by the numpy oracle (sympy
+    Jacobians): the same number of solves for every instance -- the classifications coincide pass
+    by pass -- and the same solution to 1e-9 (both are exact; nothing of an interior point's
+    central-path error is left).  Full-horizon sweeps so that both solve the same problem."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 48, 50
+    x0, yref, yref_e = _problem(oracle, B, seed=321, scale=2.0)
+    s = BatchSolver(B, default_opts(active_horizon=0, active_set=1))
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    s.solve(1)
+    st, it, _ = s.stats()
+    xg, ug = s.get_iterate()
+    assert (st == 0).all()
+    n_act = 0
+    for i in range(B):
+        xbar = np.repeat(x0[i][None], N + 1, 0); ubar = np.full((N, 4), HOV)
+        qp = oracle.build_qp(xbar, ubar, x0[i], yref[i], yref_e[i])
+        sol = oracle.pdas_dense(qp)
+        assert sol["converged"]
+        assert it[i] == sol["solves"], (i, it[i], sol["solves"])
+        assert np.abs(ug[i] - (ubar + sol["du"])).max() < 1e-9 and np.abs(xg[i] - (xbar + sol["dx"])).max() < 1e-9, i
+        n_act += sol["solves"] > 0
+    assert n_act >= 10
