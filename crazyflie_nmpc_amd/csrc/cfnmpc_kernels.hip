@@ -1325,18 +1325,26 @@ __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave
 #else
 #define PROF_T(i)
 #endif
-__global__ __launch_bounds__(64) void k_ipm(Params P) {
+// One wave = four compacted constrained instances.  MODE 0: everything (active-set solves if
+// P.active_set, then the interior point for the rows that did not settle); MODE 1: active-set
+// solves only -- rows that settle and pass the tail check are finished and flagged in P.done, the
+// others are left untouched for a MODE 2 launch; MODE 2: interior point for the rows without flag.
+template <int MODE>
+__device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64]) {
 #ifdef CFN_PROF
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
     const unsigned long long pstart = plast;
 #endif
-    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
-    __shared__ double btile[4][64];
     const int nipm = gm(P.nipm)[0];
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 4);
     if (blockIdx.x * 4 >= nipm) return;  // wave-uniform: no work for this wave
-    const bool has = slot < nipm;
-    const Lane t = lane_indirect(P, has ? gm(P.ilist)[imin(slot, nipm - 1)] : 0, has);
+    bool has = slot < nipm;
+    const int inst0 = has ? gm(P.ilist)[imin(slot, nipm - 1)] : 0;
+    if (MODE == 2) {
+        has = has && gm(P.done)[inst0] == 0;
+        if (!__any(has)) return;
+    }
+    const Lane t = lane_indirect(P, inst0, has);
     double* wt = wtile[t.row];
     double* sb = btile[t.row];
     const int N = P.N;
@@ -1391,6 +1399,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         }
     };
     RowIPM R;
+    bool accepted = MODE != 1;   // MODE 1: only rows finished by the active-set solve publish / commit
 
     for (int attempt = 0; attempt < 3; attempt++) {
         R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
@@ -1399,7 +1408,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         // ---- primal-dual active-set solves (exact when the classification becomes stationary)
         bool as_done = false;
         int as_iters = 0;
-        if (P.active_set) {
+        if (MODE != 2 && P.active_set) {
             // initial classification from the unconstrained minimiser
             for (int e0 = t.L; e0 < head * 4; e0 += 64) {
                 double uk[4], vv[4];
@@ -1440,6 +1449,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             }
         }
         if (as_done) { R.status = 0; R.iters = as_iters; }
+        if constexpr (MODE != 1) {
         if (infeasible && !as_done) {
             // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
             const double mu0 = fmax(P.mu0_scale * viol, P.lam0_min);
@@ -1603,6 +1613,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
                 }
             }
         }
+        }   // MODE != 1
 
         PROF_T(4)
         // ---- expand: dynamics-exact roll-out; head stages use the QP inputs, tail stages the
@@ -1639,6 +1650,11 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             kviol = (int)row_max((double)kviol);
         }
         PROF_T(6)
+        if (MODE == 1) {   // no second attempt here: a row is finished iff it settled and its tail stays in the box
+            as_done = as_done && kviol < 0;
+            accepted = as_done;
+            break;
+        }
         const bool redo = t.valid && R.status != 4 && kviol >= 0 && head < N;
         if (!__any(redo)) break;
         // rare: a tail input left the box -> solve again (whole wave) over the smallest head class
@@ -1651,8 +1667,9 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         chk = -1;
         SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
     }
+    if (MODE == 1 && t.L == 0 && t.valid) gm(P.done)[t.inst] = accepted ? 1 : 0;
     // accepted: publish the inputs of the whole horizon
-    if (t.valid) {
+    if (t.valid && accepted) {
         const size_t pb = (size_t)t.inst * N * 4;
         for (int e0 = t.L; e0 < N * 4; e0 += 64) {
             double vv[4];
@@ -1660,13 +1677,13 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
             SFOR(j, 0, 4, { if (e0 + 16 * j < N * 4) gm(P.v)[pb + e0 + 16 * j] = vv[j]; });
         }
     }
-    if (t.L == 0 && infeasible) {
+    if (t.L == 0 && infeasible && accepted) {
         gm(P.status)[t.inst] = R.status;
         gm(P.iters)[t.inst] = R.iters;
         gm(P.res)[t.inst] = R.res;
         gm(P.head)[t.inst] = head;
     }
-    commit_row(P, t, infeasible && R.status != 4);
+    commit_row(P, t, infeasible && accepted && R.status != 4);
 #ifdef CFN_PROF
     PROF_T(7)
     if (threadIdx.x == 0) {
@@ -1678,6 +1695,21 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {
         for (int i = 0; i < 8; i++) atomicAdd(&g_prof[16 + i], pacc[i]);
     }
 #endif
+}
+__global__ __launch_bounds__(64) void k_ipm(Params P) {       // MODE 0: used when active_set = 0
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<0>(P, wtile, btile);
+}
+__global__ __launch_bounds__(64) void k_as(Params P) {        // active-set solves
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<1>(P, wtile, btile);
+}
+__global__ __launch_bounds__(64) void k_ipm_rest(Params P) {  // interior point for what k_as left
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<2>(P, wtile, btile);
 }
 #ifdef CFN_PROF
 // isolated sweeps on one wave per SIMD (development aid): every wave repeats the sweep `reps` times
@@ -1917,7 +1949,12 @@ void launch_qp_start(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_scatter, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
 }
 void launch_qp_ipm(const Params& P, hipStream_t st) {
-    hipLaunchKernelGGL(k_ipm, dim3(P.NW), dim3(64), 0, st, P);
+    if (P.active_set) {
+        hipLaunchKernelGGL(k_as, dim3(P.NW), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_ipm_rest, dim3(P.NW), dim3(64), 0, st, P);
+    } else {
+        hipLaunchKernelGGL(k_ipm, dim3(P.NW), dim3(64), 0, st, P);
+    }
 }
 void launch_qp(const Params& P, hipStream_t st) {
     launch_qp_start(P, st);
