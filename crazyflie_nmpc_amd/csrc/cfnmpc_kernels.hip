@@ -8,7 +8,7 @@
 //     through LDS tiles -- for the kernels that carry at most a 13-vector (k_linearise, k_forward).
 // One wavefront per workgroup; instances never communicate.
 //
-// Kernels, one RTI step = five launches on one stream:
+// Kernels, one RTI step = seven launches on one stream:
 //   k_linearise : RK4 + forward sensitivities per shooting interval (the role of acados sim_erk +
 //                 CasADi forw_vde, acados_mpc.cpp:84), written in the row-distributed A / B form.
 //   k_factor    : start solve, backward: augmented Riccati factorisation of the unconstrained QP
@@ -18,10 +18,16 @@
 //                 A and B; unconstrained inputs, feasibility / active-horizon decision, full RTI
 //                 step of the instances whose unconstrained minimiser respects the input box.
 //   k_compact   : list of the instances that need the interior-point method, by head class.
-//   k_ipm       : those instances only: Mehrotra predictor-corrector over stage-wise Riccati
-//                 sweeps in delta form (HPIPM's role, generate_c_code.py:140) on a compact copy of
-//                 the head stages, expansion, tail verification, full RTI step
+//   k_scatter   : places every constrained instance in the list.
+//   k_as        : those instances only, on a compact copy of their head stages: primal-dual
+//                 active-set solves (one Riccati factorisation with the active inputs fixed,
+//                 forward sweep, costate sweep with re-classification) until the active set is
+//                 stationary = exact QP solution; expansion, tail verification, full RTI step
 //                 (acados_solve() epilogue, acados_mpc.cpp:611-616).
+//   k_ipm_rest  : rows k_as left (no stationary set within 12 solves, tail check failed):
+//                 Mehrotra predictor-corrector over stage-wise Riccati sweeps in delta form
+//                 (HPIPM's role, generate_c_code.py:140).  k_ipm = the same without k_as
+//                 (cfnmpc_opts.active_set = 0).
 //   k_linearise_list : cfnmpc_opts.overlap_linearise only -- re-linearises the interior-point
 //                 instances after the early pass that ran beside k_ipm.
 //   k_sim / k_estimate : RK4 plant step / predictor (acados_estimator.cpp:573-593).
