@@ -1656,12 +1656,12 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             kviol = (int)row_max((double)kviol);
         }
         PROF_T(6)
-        if (MODE == 1) {   // no second attempt here: a row is finished iff it settled and its tail stays in the box
-            as_done = as_done && kviol < 0;
-            accepted = as_done;
-            break;
-        }
-        const bool redo = t.valid && R.status != 4 && kviol >= 0 && head < N;
+        // MODE 1: a row is finished iff its active set settled and its tail stays in the box; a
+        // settled row whose tail leaves the box gets a longer head (below), one that did not
+        // settle is left to the interior-point kernel
+        if (MODE == 1) accepted = as_done && kviol < 0;
+        const bool redo = MODE == 1 ? (t.valid && as_done && kviol >= 0 && head < N)
+                                    : (t.valid && R.status != 4 && kviol >= 0 && head < N);
         if (!__any(redo)) break;
         // rare: a tail input left the box -> solve again (whole wave) over the smallest head class
         // that covers the offending stage (+4), the full horizon as the last resort.  Nothing of
