@@ -300,7 +300,7 @@ def main():
                        "qp": ("primal-dual active-set solves on the Riccati factorisation (exact, KKT-verified; "
                               "Mehrotra interior point, tol 1e-8, as fall-back), ") +
                              ("active-horizon sweeps" if args.active_horizon else "full-horizon sweeps")},
-            "roofline": {"bound": "hbm", "kernel": "QP phase = k_factor + k_forward + k_compact + k_ipm "
+            "roofline": {"bound": "hbm", "kernel": "QP phase = k_factor + k_forward + k_compact + k_scatter + k_as + k_ipm_rest "
                                                      "(HIP events on the launch stream, summed over the sub-batch launches)",
                          "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,

@@ -30,7 +30,8 @@ def main():
             continue
         r, w = 2.0 * rd.get(k, 0.0) * 1024.0, wr.get(k, 0.0) * 1024.0
         kernels[k] = {"read_bytes": r, "write_bytes": w, "total_bytes": r + w}
-    qp = sum(kernels[k]["total_bytes"] for k in ("cfn::k_factor", "cfn::k_forward", "cfn::k_compact", "cfn::k_ipm") if k in kernels)
+    qp = sum(kernels[k]["total_bytes"] for k in ("cfn::k_factor", "cfn::k_forward", "cfn::k_compact", "cfn::k_scatter", "cfn::k_as",
+                       "cfn::k_ipm_rest", "cfn::k_ipm") if k in kernels)
     json.dump({"batch": batch,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB); reads = 2 x FETCH_SIZE "
                        "(gfx950 correction, see tools/pmc_traffic.py); average of the last third of the dispatches of "
@@ -40,7 +41,7 @@ def main():
         f.write("kernel,read_GB,write_GB,total_GB\n")
         for k, v in kernels.items():
             f.write(f"{k},{v['read_bytes'] / 1e9:.4f},{v['write_bytes'] / 1e9:.4f},{v['total_bytes'] / 1e9:.4f}\n")
-        f.write(f"QP phase (factor+forward+compact+ipm),,,{qp / 1e9:.4f}\n")
+        f.write(f"QP phase (factor+forward+compact+scatter+as+ipm_rest | ipm),,,{qp / 1e9:.4f}\n")
     print(open(out_csv).read())
 
 
