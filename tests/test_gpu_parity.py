@@ -192,3 +192,38 @@ def test_active_set_solves_match_oracle_exactly(oracle):
         assert np.abs(ug[i] - (ubar + sol["du"])).max() < 1e-9 and np.abs(xg[i] - (xbar + sol["dx"])).max() < 1e-9, i
         n_act += sol["solves"] > 0
     assert n_act >= 10
+
+
+@pytest.mark.parametrize("scale,init", [(3.0, "hover"), (1.0, "acados")])
+def test_active_set_under_heavy_saturation(oracle, cref, scale, init):
+    """Stress of the default QP method: large perturbations (many inputs at both bounds over long
+    heads) and the cold acados start (iterate far from the measurement: the active-set iteration
+    does not always settle and hands over to the interior point).  Whatever route an instance
+    takes, it must end at the restatement's solution, inside the box, with status 0."""
+    from crazyflie_nmpc_amd import BatchSolver, sim, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_ACADOS, INIT_HOVER
+    B, N, tol = 256, 50, 1e-10
+    x0, yref, yref_e = _problem(oracle, B, seed=4242, scale=scale)
+    opts = cref.default_opts(tol=tol)
+    if init == "hover":
+        xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    else:
+        xr = np.tile(np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0]), (B, N + 1, 1)); ur = np.zeros((B, N, 4))
+    s = BatchSolver(B, default_opts(tol=tol))
+    s.set_x0(x0); s.set_yref(yref, yref_e)
+    s.init_iterate(INIT_HOVER if init == "hover" else INIT_ACADOS)
+    x = x0.copy()
+    n_con = 0
+    for t in range(4):
+        s.set_x0(x); s.solve(1)
+        st, it, _ = s.stats()
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        xg, ug = s.get_iterate()
+        assert (st == 0).all() and (st_r == 0).all(), (t, np.bincount(st), np.bincount(st_r))
+        assert ((it > 0) == (it_r > 0)).all()
+        assert ug.min() > -1e-9 and ug.max() < 22.0 + 1e-9
+        assert np.abs(ug - ur).max() < 2e-5 and np.abs(xg - xr).max() < 2e-5, (t, np.abs(ug - ur).max())
+        n_con += int((it > 0).sum())
+        x = sim(x, s.get_u(0), T=0.015, steps=1)
+        ur[:] = ug; xr[:] = xg
+    assert n_con > B // 2
