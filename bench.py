@@ -63,7 +63,7 @@ def cpu_baseline(seed, n_inst=2048, n_steps=4, reps=3):
     yr, ye = o.regulation_yref(N_HORIZON, (0.0, 0.0, 0.4))
     yref = np.repeat(yr[None], n_inst, 0).copy()
     yref_e = np.repeat(ye[None], n_inst, 0).copy()
-    opts = cref.default_opts()
+    opts = cref.default_opts(active_set=1)   # same QP method as the engine's default
     cores = os.cpu_count() or 1
     best_all, best_one, used, iters = 0.0, 0.0, 1, []
     for _ in range(reps):
@@ -91,9 +91,8 @@ def cpu_baseline(seed, n_inst=2048, n_steps=4, reps=3):
         "host_cores": int(cores), "kind": "port",
         "single_thread_steps_per_s": best_one,
         "sample": f"best of {reps} x ({n_inst} instances x {n_steps} closed-loop RTI steps of the same hover workload), "
-                  f"oracle/cfnmpc_ref.c (CPU restatement, not acados; Riccati interior point, the reference's QP method "
-                  f"class -- the GPU path reaches the same solutions by active-set solves), OpenMP over {used} threads; "
-                  f"mean interior-point iterations {np.mean(iters):.2f}",
+                  f"oracle/cfnmpc_ref.c (CPU restatement, not acados; same QP method as the engine: active-set solves, "
+                  f"interior point as fall-back), OpenMP over {used} threads; mean QP solves {np.mean(iters):.2f}",
     }
 
 

@@ -44,6 +44,9 @@ typedef struct {
     double thr0;      /* IPM: slack floor of the starting point                */
     double lam0_min;  /* IPM: floor of the starting complementarity            */
     double mu0_scale; /* IPM: starting complementarity = max(lam0_min, mu0_scale * max. violation) */
+    int active_set;   /* 1: primal-dual active-set solves first (the engine's cfnmpc_opts.active_set;
+                         numpy twin pdas_dense), interior point only if the set does not settle in
+                         12 solves; 0 (default): interior point only                              */
 } cfo_opts;
 
 void cfo_default_opts(cfo_opts *o) {
@@ -61,6 +64,7 @@ void cfo_default_opts(cfo_opts *o) {
     o->thr0 = 1.0;
     o->lam0_min = 1e-2;
     o->mu0_scale = 0.1;
+    o->active_set = 0;
 }
 
 /* ---------------------------------------------------------------- dynamics */
@@ -271,13 +275,18 @@ static int spd4_inv(const double *S, double *Si) {
 
 /* backward sweep: Riccati factorisation with input Hessian diag Rhat[k] and gradient g[k];
  * absolute != 0 -> affine terms q, b of the QP are included (start solve). */
+static int riccati_factor_aff(qp_t *qp, const double *Rhat, const double *g, const double *bb, const double *qq);
 static int riccati_factor(qp_t *qp, const double *Rhat, const double *g, int absolute) {
+    return riccati_factor_aff(qp, Rhat, g, absolute ? qp->b : NULL, absolute ? qp->q : NULL);
+}
+/* bb [N][13] / qq [N+1][13]: affine terms of the dynamics / of the state cost (NULL = zero) */
+static int riccati_factor_aff(qp_t *qp, const double *Rhat, const double *g, const double *bb, const double *qq) {
     const int N = qp->N;
     double P[169], p[NX], PA[169], PB[52], S[16], G[52], hb[NX], rho[4], Pn[169], pn[NX];
     memset(P, 0, sizeof P);
-    for (int i = 0; i < NX; i++) { P[i * NX + i] = qp->QNd[i]; p[i] = absolute ? qp->q[N * NX + i] : 0.0; }
+    for (int i = 0; i < NX; i++) { P[i * NX + i] = qp->QNd[i]; p[i] = qq ? qq[N * NX + i] : 0.0; }
     for (int k = N - 1; k >= 0; k--) {
-        const double *A = qp->A + (size_t)k * 169, *B = qp->B + (size_t)k * 52, *b = qp->b + (size_t)k * NX;
+        const double *A = qp->A + (size_t)k * 169, *B = qp->B + (size_t)k * 52, *b = bb ? bb + (size_t)k * NX : NULL;
         double *K = qp->K + (size_t)k * 52, *Si = qp->Sinv + (size_t)k * 16, *d = qp->d + (size_t)k * 4;
         for (int i = 0; i < NX; i++) {
             for (int j = 0; j < NX; j++) { double s = 0; for (int l = 0; l < NX; l++) s += P[i * NX + l] * A[l * NX + j]; PA[i * NX + j] = s; }
@@ -289,7 +298,7 @@ static int riccati_factor(qp_t *qp, const double *Rhat, const double *g, int abs
         }
         for (int i = 0; i < NX; i++) {
             double s = p[i];
-            if (absolute) for (int l = 0; l < NX; l++) s += P[i * NX + l] * b[l];
+            if (b) for (int l = 0; l < NX; l++) s += P[i * NX + l] * b[l];
             hb[i] = s;
         }
         for (int i = 0; i < NU; i++) { double s = g[k * 4 + i]; for (int l = 0; l < NX; l++) s += B[l * NU + i] * hb[l]; rho[i] = s; }
@@ -306,7 +315,7 @@ static int riccati_factor(qp_t *qp, const double *Rhat, const double *g, int abs
                 Pn[i * NX + j] = s;
             }
         for (int i = 0; i < NX; i++) {
-            double s = absolute ? qp->q[k * NX + i] : 0.0;
+            double s = qq ? qq[k * NX + i] : 0.0;
             for (int l = 0; l < NX; l++) s += A[l * NX + i] * hb[l];
             for (int l = 0; l < NU; l++) s -= K[l * NX + i] * rho[l];
             pn[i] = s;
@@ -382,6 +391,92 @@ static double steplen(int n, const double *z, const double *dz, double a) {
     return a;
 }
 
+/* Primal-dual active-set solves in delta form around the unconstrained minimiser qp->v
+ * (numpy twin pdas_dense; the engine's k_as): classify every input, solve
+ * the homogeneous LQ problem with the active inputs fixed at c = bound - v0 (1e30 on their diagonal
+ * of R^, b_eff = B c in the affine recursion), forward sweep, costate sweep with multipliers
+ * R c + B'pi and re-classification; a stationary classification is the KKT system.
+ * Returns the number of solves (> 0) with qp->v = solution, or 0 if the set did not settle. */
+static int as_solve(qp_t *qp) {
+    const int N = qp->N, n = N * NU;
+    double *v0 = qp->v, *du = qp->dva;
+    double *Rhat = (double *)malloc(sizeof(double) * ((size_t)n * 3 + (size_t)N * NX + (size_t)(N + 1) * NX));
+    double *g = Rhat + n, *c = g + n, *beff = c + n, *dx = beff + (size_t)N * NX;
+    int *cls = (int *)malloc(sizeof(int) * n);
+    int solves = 0, done = 0;
+    for (int i = 0; i < n; i++) {
+        cls[i] = v0[i] < qp->lb[i] ? 1 : (v0[i] > qp->ub[i] ? 2 : 0);
+        c[i] = cls[i] == 1 ? qp->lb[i] - v0[i] : (cls[i] == 2 ? qp->ub[i] - v0[i] : 0.0);
+        g[i] = 0.0;
+    }
+    while (solves < 12 && !done) {
+        solves++;
+        for (int k = 0; k < N; k++) {
+            const double *B = qp->B + (size_t)k * 52;
+            for (int a = 0; a < NU; a++) Rhat[k * 4 + a] = cls[k * 4 + a] ? 1e30 : qp->Rd[a];
+            for (int i = 0; i < NX; i++) {
+                double s = 0.0;
+                for (int a = 0; a < NU; a++) s += B[i * NU + a] * c[k * 4 + a];
+                beff[k * NX + i] = s;
+            }
+        }
+        if (riccati_factor_aff(qp, Rhat, g, beff, NULL)) { solves = 0; break; }
+        {   /* forward: free inputs from the feedback law, fixed ones = c */
+            double x[NX] = {0}, xn[NX];
+            memcpy(dx, x, sizeof x);
+            for (int k = 0; k < N; k++) {
+                const double *A = qp->A + (size_t)k * 169, *B = qp->B + (size_t)k * 52;
+                const double *K = qp->K + (size_t)k * 52, *d = qp->d + (size_t)k * 4;
+                for (int a = 0; a < NU; a++) {
+                    double s = -d[a];
+                    for (int l = 0; l < NX; l++) s -= K[a * NX + l] * x[l];
+                    du[k * 4 + a] = cls[k * 4 + a] ? c[k * 4 + a] : s;
+                }
+                for (int i = 0; i < NX; i++) {
+                    double s = 0.0;
+                    for (int l = 0; l < NX; l++) s += A[i * NX + l] * x[l];
+                    for (int a = 0; a < NU; a++) s += B[i * NU + a] * du[k * 4 + a];
+                    xn[i] = s;
+                }
+                memcpy(x, xn, sizeof x);
+                memcpy(dx + (size_t)(k + 1) * NX, x, sizeof x);
+            }
+        }
+        {   /* costate: pi_N = QN dx_N ; multipliers and new classification ; pi_k = Q dx_k + A'pi */
+            double pi[NX], pn[NX];
+            int changed = 0;
+            for (int i = 0; i < NX; i++) pi[i] = qp->QNd[i] * dx[(size_t)N * NX + i];
+            for (int k = N - 1; k >= 0; k--) {
+                const double *A = qp->A + (size_t)k * 169, *B = qp->B + (size_t)k * 52;
+                for (int a = 0; a < NU; a++) {
+                    const int i = k * 4 + a;
+                    double grad = qp->Rd[a] * c[i];
+                    for (int l = 0; l < NX; l++) grad += B[l * NU + a] * pi[l];
+                    const double vn = v0[i] + du[i];
+                    int nc;
+                    if (cls[i] == 0) nc = vn < qp->lb[i] ? 1 : (vn > qp->ub[i] ? 2 : 0);
+                    else if (cls[i] == 1) nc = grad > 0.0 ? 1 : 0;
+                    else nc = grad < 0.0 ? 2 : 0;
+                    if (nc != cls[i]) changed = 1;
+                    cls[i] = nc;
+                    c[i] = nc == 1 ? qp->lb[i] - v0[i] : (nc == 2 ? qp->ub[i] - v0[i] : 0.0);
+                }
+                for (int i = 0; i < NX; i++) {
+                    double s = qp->Qd[i] * dx[(size_t)k * NX + i];
+                    for (int l = 0; l < NX; l++) s += A[l * NX + i] * pi[l];
+                    pn[i] = s;
+                }
+                memcpy(pi, pn, sizeof pi);
+            }
+            done = !changed;
+        }
+    }
+    if (done) for (int i = 0; i < n; i++) v0[i] += du[i];
+    free(cls);
+    free(Rhat);
+    return done ? solves : 0;
+}
+
 /* Mehrotra predictor-corrector, delta form (mirrors riccati_ipm in
  * cfnmpc_oracle.py).  On return qp->v holds du and qp->x holds dx.
  * status: 0 converged, 2 iteration cap, 4 factorisation failure / non-finite */
@@ -408,6 +503,16 @@ static int ipm_solve(qp_t *qp, const cfo_opts *o, int *iters_out, double *res_ou
     }
     if (feas) { free(Rhat); *res_out = 0.0; return 0; }
     if (!(viol == viol)) { free(Rhat); *res_out = NAN; return 4; }
+    if (o->active_set) {
+        const int solves = as_solve(qp);
+        if (solves > 0) {
+            rollout(qp, v, qp->x);
+            free(Rhat);
+            *iters_out = solves;
+            *res_out = 0.0;
+            return 0;
+        }
+    }
     {
         const double mu0 = fmax(o->mu0_scale * viol, o->lam0_min);
         for (int i = 0; i < n; i++) {

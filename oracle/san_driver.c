@@ -8,16 +8,18 @@
 typedef struct {
     int N; double dt; double W[17]; double WN[13]; double u_min, u_max; double tol; int max_iter;
     double tau, thr0, lam0_min, mu0_scale;
+    int active_set;
 } cfo_opts;
 void cfo_default_opts(cfo_opts *o);
 int cfo_rti_step(const cfo_opts *o, int B, double *x_it, double *u_it, const double *x0, const double *yref,
                  const double *yref_e, int *status, int *iters, double *res, int nthreads);
 void cfo_sim(int B, const double *x, const double *u, double T, int steps, double *xn);
 
-int main(void) {
+static int run(int active_set) {
     enum { B = 6, NX = 13, NU = 4, NY = 17 };
     cfo_opts o;
     cfo_default_opts(&o);
+    o.active_set = active_set;
     const int N = o.N;
     double *xit = malloc(sizeof(double) * B * (N + 1) * NX), *uit = malloc(sizeof(double) * B * N * NU);
     double *yref = malloc(sizeof(double) * B * N * NY), yref_e[B * NX], x0[B * NX], xn[B * NX], u0[B * NU], res[B];
@@ -52,7 +54,12 @@ int main(void) {
         cfo_sim(B, x0, u0, 0.015, 1, xn);
         memcpy(x0, xn, sizeof xn);
     }
-    printf("sanitizer run ok, %d constrained solves\n", constrained);
+    printf("sanitizer run ok (active_set = %d), %d constrained solves\n", active_set, constrained);
     free(xit); free(uit); free(yref);
     return constrained > 0 ? 0 : 3;
+}
+
+int main(void) {
+    const int a = run(0), b = run(1);   /* interior point, active-set solves */
+    return a ? a : b;
 }

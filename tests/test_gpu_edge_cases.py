@@ -19,9 +19,8 @@ def _inputs(oracle, B, N, seed, scale=1.0):
 @pytest.mark.parametrize("active_set", [0, 1])
 def test_other_horizons_match_oracle(oracle, cref, N, active_horizon, active_set):
     """Mixed-horizon config C5 runs one solver object per horizon bucket; each bucket must agree
-    with the CPU restatement (dt stays 15 ms, Tf = 0.015 N).  With the interior point on both
-    sides (active_set = 0) the agreement is FP64-level; the active-set solve is exact, so there the
-    bound is the restatement's interior-point accuracy at tol 1e-11 (measured 5e-8)."""
+    with the CPU restatement (dt stays 15 ms, Tf = 0.015 N), with the interior point on both
+    sides (active_set = 0) and with the active-set solves on both sides (1): FP64-level."""
     from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
     from crazyflie_nmpc_amd.solver import INIT_HOVER
     B = 37
@@ -29,8 +28,8 @@ def test_other_horizons_match_oracle(oracle, cref, N, active_horizon, active_set
     tol = 1e-11
     s = BatchSolver(B, default_opts(N=N, tol=tol, active_horizon=active_horizon, active_set=active_set))
     s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
-    opts = cref.default_opts(N=N, tol=tol)
-    bound = 5e-6 if active_set else 1e-8
+    opts = cref.default_opts(N=N, tol=tol, active_set=active_set)
+    bound = 1e-8
     xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
     x = x0.copy()
     nipm = 0
@@ -58,13 +57,13 @@ def test_tiny_and_ragged_batches(oracle, cref, B, active_set):
     s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
     s.solve(1)
     xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
-    st_r, it_r, _, _ = cref.rti_step(cref.default_opts(), xr, ur, x0.copy(), yref, yref_e, nthreads=0)
+    st_r, it_r, _, _ = cref.rti_step(cref.default_opts(active_set=active_set), xr, ur, x0.copy(), yref, yref_e, nthreads=0)
     st, it, _ = s.stats()
     xg, ug = s.get_iterate()
     assert (st == 0).all() and ((it > 0) == (it_r > 0)).all()
     if active_set:
-        assert (it <= it_r).all()           # never more solves than interior-point iterations here
-        assert np.abs(ug - ur).max() < 5e-4 and np.abs(xg - xr).max() < 5e-4   # restatement stops at tol 1e-8
+        assert np.array_equal(it, it_r)     # same active-set solves, pass by pass
+        assert np.abs(ug - ur).max() < 1e-8 and np.abs(xg - xr).max() < 1e-8   # both exact
     else:
         assert (np.abs(it - it_r) <= 1).all()
         assert np.abs(ug - ur).max() < 1e-6 and np.abs(xg - xr).max() < 1e-6
