@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libcfnmpc.so")
 SYMBOLS = [
     "cfnmpc_default_opts", "cfnmpc_create", "cfnmpc_free", "cfnmpc_batch", "cfnmpc_horizon",
     "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_set_weights", "cfnmpc_set_yref_windows", "cfnmpc_init_iterate",
-    "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_get_u", "cfnmpc_get_x",
+    "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_step_host", "cfnmpc_get_u", "cfnmpc_get_x",
     "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_estimate", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise",
     "cfnmpc_debug_get_head", "cfnmpc_set_profiling", "cfnmpc_get_profile", "cfnmpc_version",
 ]
@@ -65,6 +65,7 @@ def lib():
     L.cfnmpc_set_iterate.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_get_iterate.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_solve.argtypes = [vp, i32, vp]
+    L.cfnmpc_step_host.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.cfnmpc_get_u.argtypes = [vp, i32, vp, i32, vp]
     L.cfnmpc_get_x.argtypes = [vp, i32, vp, i32, vp]
     L.cfnmpc_get_stats.argtypes = [vp, vp, vp, vp, i32, vp]

@@ -170,13 +170,10 @@ int acados_solve(void) {
         if (cfnmpc_set_weights(g->s, g->W, g->WN) != CFNMPC_OK) return 1;
         g->weights_dirty = false;
     }
-    if (cfnmpc_set_x0(g->s, g->lbx, 0, nullptr) != CFNMPC_OK) return 1;
-    if (cfnmpc_set_yref(g->s, g->yref, g->yref_e, 0, nullptr) != CFNMPC_OK) return 1;
-    if (cfnmpc_solve(g->s, 1, nullptr) != CFNMPC_OK) return 1;
     int status = 1, iters = 0;
     double res = 0.0;
-    if (cfnmpc_get_stats(g->s, &status, &iters, &res, 0, nullptr) != CFNMPC_OK) return 1;
-    if (cfnmpc_get_iterate(g->s, g->x, g->u, 0, nullptr) != CFNMPC_OK) return 1;
+    // inputs in, one RTI step, iterate and statistics out: one transfer each way, one synchronisation
+    if (cfnmpc_step_host(g->s, g->lbx, g->yref, g->yref_e, g->u, g->x, &status, &iters, &res, nullptr) != CFNMPC_OK) return 1;
     g->out.inf_norm_res = res;
     g->out.qp_iter = iters;
     g->out.total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

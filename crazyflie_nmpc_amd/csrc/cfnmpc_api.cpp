@@ -20,6 +20,9 @@ struct cfnmpc_solver {
     std::vector<void*> allocs;
     double* stage_buf;  // device staging buffer for AoS transfers (largest AoS array)
     size_t stage_doubles;
+    // cfnmpc_step_host: pinned host mirror + device buffers of one step's inputs / outputs (lazy)
+    double *h_io, *d_io;
+    size_t io_doubles;
     unsigned long long bytes;
     // optional per-kernel timing with HIP events on the launch stream (cfnmpc_set_profiling)
     int profiling;
@@ -138,6 +141,8 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     cfnmpc_solver* s = new (std::nothrow) cfnmpc_solver();
     if (!s) return CFNMPC_ENOMEM;
     s->bytes = 0;
+    s->h_io = s->d_io = nullptr;
+    s->io_doubles = 0;
     s->profiling = 0;
     s->ev_used = 0;
     s->overlap = o.overlap_linearise ? 1 : 0;
@@ -220,6 +225,7 @@ int cfnmpc_free(cfnmpc_solver* s) {
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_aux) (void)hipEventDestroy(s->ev_aux);
     for (void* p : s->allocs) (void)hipFree(p);
+    if (s->h_io) (void)hipHostFree(s->h_io);
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     delete s;
     return CFNMPC_OK;
@@ -330,6 +336,53 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
         s->lin_valid = true;
     }
     HIP_TRY(hipGetLastError());
+    return CFNMPC_OK;
+}
+
+int cfnmpc_step_host(cfnmpc_solver* s, const double* x0, const double* yref, const double* yref_e, double* u,
+                     double* x, int* status, int* qp_iter, double* res, void* stream) {
+    if (!s || !x0 || !yref || !yref_e) return CFNMPC_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const cfn::Params& P = s->P;
+    const size_t B = P.B, N = P.N;
+    // layout of the I/O block (doubles): x0 | yref | yref_e || u | x | res | status, iters (as ints)
+    const size_t n_x0 = B * 13, n_yr = B * N * 17, n_ye = B * 13, n_in = n_x0 + n_yr + n_ye;
+    const size_t n_u = B * N * 4, n_x = B * (N + 1) * 13, n_res = B, n_int = B;   // 2 ints per double slot
+    const size_t n_out = n_u + n_x + n_res + n_int, n_all = n_in + n_out;
+    if (s->io_doubles < n_all) {
+        if (s->h_io) (void)hipHostFree(s->h_io);
+        s->h_io = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&s->h_io, n_all * sizeof(double), hipHostMallocDefault));
+        int rc = dev_alloc(s, &s->d_io, n_all);
+        if (rc != CFNMPC_OK) return rc;
+        s->io_doubles = n_all;
+    }
+    double *h = s->h_io, *d = s->d_io;
+    std::memcpy(h, x0, n_x0 * sizeof(double));
+    std::memcpy(h + n_x0, yref, n_yr * sizeof(double));
+    std::memcpy(h + n_x0 + n_yr, yref_e, n_ye * sizeof(double));
+    HIP_TRY(hipMemcpyAsync(d, h, n_in * sizeof(double), hipMemcpyHostToDevice, st));
+    cfn::launch_put(P.B, 1, 13, 1, d, P.x0, st);
+    cfn::launch_put(P.B, P.N, 17, 1, d + n_x0, P.yref, st);
+    cfn::launch_put(P.B, 1, 13, 1, d + n_x0 + n_yr, P.yref_e, st);
+    int rc = cfnmpc_solve(s, 1, stream);
+    if (rc != CFNMPC_OK) return rc;
+    double* o = d + n_in;
+    cfn::launch_get(P.B, P.N, 4, 0, 0, P.N, s->P.uit, o, st);
+    cfn::launch_get(P.B, P.N + 1, 13, 1, 0, P.N + 1, s->P.xit, o + n_u, st);
+    HIP_TRY(hipMemcpyAsync(o + n_u + n_x, s->P.res, B * sizeof(double), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(o + n_u + n_x + n_res, s->P.status, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync((int*)(o + n_u + n_x + n_res) + B, s->P.iters, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h + n_in, o, n_out * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const double* ho = h + n_in;
+    if (u) std::memcpy(u, ho, n_u * sizeof(double));
+    if (x) std::memcpy(x, ho + n_u, n_x * sizeof(double));
+    if (res) std::memcpy(res, ho + n_u + n_x, B * sizeof(double));
+    const int* hi = (const int*)(ho + n_u + n_x + n_res);
+    if (status) std::memcpy(status, hi, B * sizeof(int));
+    if (qp_iter) std::memcpy(qp_iter, hi + B, B * sizeof(int));
     return CFNMPC_OK;
 }
 

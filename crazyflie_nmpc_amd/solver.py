@@ -137,6 +137,19 @@ class BatchSolver:
         """acados_solve() for the batch; `stream` is a raw hipStream_t (int) or None = default."""
         _check(self._L.cfnmpc_solve(self._h, int(n_rti), C.c_void_p(stream or 0)), "cfnmpc_solve")
 
+    def step_host(self, x0, yref, yref_e, stream=None):
+        """cfnmpc_step_host: host arrays in (x0 [B,13], yref [B,N,17], yref_e [B,13]), one RTI step,
+        host arrays out -> (u [B,N,4], x [B,N+1,13], status, qp_iter, res); one synchronisation."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64); yref = np.ascontiguousarray(yref, dtype=np.float64)
+        yref_e = np.ascontiguousarray(yref_e, dtype=np.float64)
+        assert x0.shape == (self.B, NX) and yref.shape == (self.B, self.N, NY) and yref_e.shape == (self.B, NX)
+        u = np.empty((self.B, self.N, NU)); x = np.empty((self.B, self.N + 1, NX))
+        st = np.empty(self.B, dtype=np.int32); it = np.empty(self.B, dtype=np.int32); rs = np.empty(self.B)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        _check(self._L.cfnmpc_step_host(self._h, vp(x0), vp(yref), vp(yref_e), vp(u), vp(x), vp(st), vp(it), vp(rs),
+                                        C.c_void_p(stream or 0)), "cfnmpc_step_host")
+        return u, x, st, it, rs
+
     def set_profiling(self, enable=True):
         _check(self._L.cfnmpc_set_profiling(self._h, int(bool(enable))), "cfnmpc_set_profiling")
 

@@ -125,6 +125,15 @@ int cfnmpc_get_iterate(cfnmpc_solver *s, double *x, double *u, int on_device, vo
  * `stream`.  The reference calls it with one step. */
 int cfnmpc_solve(cfnmpc_solver *s, int n_rti, void *stream);
 
+/* One complete control step from HOST buffers with a single synchronisation -- what the node
+ * does per sample (acados_mpc.cpp:581-625: set lbx/ubx, N+1 yref rows, acados_solve(), read u/x):
+ * x0 [B][13], yref [B][N][17], yref_e [B][13] in; one RTI step; the whole iterate out
+ * (u [B][N][4], x [B][N+1][13]) with status, QP solve count and residual per instance.  The
+ * transfers go through pinned staging memory owned by the solver, asynchronously on `stream`,
+ * which is synchronised once before returning.  Any output pointer may be NULL. */
+int cfnmpc_step_host(cfnmpc_solver *s, const double *x0, const double *yref, const double *yref_e,
+                     double *u, double *x, int *status, int *qp_iter, double *res, void *stream);
+
 /* ocp_nlp_out_get(.., stage, "u"/"x", ..) equivalents (acados_mpc.cpp:619-625) */
 int cfnmpc_get_u(cfnmpc_solver *s, int stage, double *u /*[B][4]*/, int on_device, void *stream);
 int cfnmpc_get_x(cfnmpc_solver *s, int stage, double *x /*[B][13]*/, int on_device, void *stream);

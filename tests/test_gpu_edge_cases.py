@@ -239,3 +239,23 @@ def test_overlapped_preparation_is_bit_identical(oracle, B):
         s0.linearise_only()
         A0, B0, b0 = s0.get_linearisation()
         assert np.array_equal(A0, runs[1][1]) and np.array_equal(B0, runs[1][2]) and np.array_equal(b0, runs[1][3])
+
+
+def test_step_host_equals_separate_calls(oracle):
+    """cfnmpc_step_host (what the acados-named shim uses per sample: one transfer each way, one
+    synchronisation) returns exactly what set_x0 + set_yref + solve + get_* return."""
+    from crazyflie_nmpc_amd import BatchSolver
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 7, 50
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=31, scale=2.0)
+    a, b = BatchSolver(B), BatchSolver(B)
+    for s in (a, b):
+        s.set_x0(x0); s.init_iterate(INIT_HOVER)
+    x = x0.copy()
+    for t in range(3):
+        a.set_x0(x); a.set_yref(yref, yref_e); a.solve(1)
+        xa, ua = a.get_iterate(); sa, ia, ra = a.stats()
+        ub, xb, sb, ib, rb = b.step_host(x, yref, yref_e)
+        assert np.array_equal(ua, ub) and np.array_equal(xa, xb)
+        assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(ra, rb)
+        x = xa[:, 1].copy()
