@@ -1032,8 +1032,9 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
 // The forward sweep only needs the PRODUCT  dx+ = A dx + B du + b, never A and B themselves, and
 // that product is the directional derivative of the RK4 map at (x_k, u_k) along (dx, du): one
 // forward-mode pass through the four RK stages (~10^3 flops) instead of reading the 149 stored
-// entries of (A, B) per stage.  Per instance and stage the sweep then reads K (52), d (4), b (13),
-// x_k (13), u_k (4) and writes the input step and the candidate new state -- less than half the
+// entries of (A, B) per stage.  Per instance and stage the sweep then reads K (52), d (4),
+// x_k (13), u_k (4) (b_k = Phi - x_{k+1} falls out of the same RK4 pass) and writes the input step
+// and the candidate new state -- less than half the
 // bytes of the row-distributed sweep -- and with one instance per lane there are no cross-lane
 // reductions at all.  (The interior-point kernel keeps the stored A, B: its sweeps run many times
 // per QP on a compact copy.)
@@ -1043,7 +1044,7 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
 __global__ __launch_bounds__(64) void k_forward(Params P) {
     // 13-vectors travel through LDS tiles [instance][13] so that every global access of the wave
     // is a contiguous run (as in k_linearise); K, d, u, v are 32-byte runs per lane already.
-    __shared__ double xs[64 * 13], bs[64 * 13], cs[64 * 13];
+    __shared__ double xs[64 * 13], cs[64 * 13];
     __shared__ int sflag[64];
     const int N = P.N;
     const int tid = threadIdx.x;
@@ -1081,13 +1082,10 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         double r0[13], r1[13];
         issue13(P.x0, 1, 0, tid, r0);
         issue13(P.xit, N + 1, 0, tid, r1);
-        land13(bs, r0);
+        land13(cs, r0);
         land13(xs, r1);
         __syncthreads();
-        SFOR(i, 0, 13, { dx[i] = bs[tid * 13 + i] - xs[tid * 13 + i]; });
-        __syncthreads();
-        issue13(P.b, N, 0, tid, r0);
-        land13(bs, r0);
+        SFOR(i, 0, 13, { dx[i] = cs[tid * 13 + i] - xs[tid * 13 + i]; });
         __syncthreads();
     }
     double viol = 0.0;
@@ -1098,8 +1096,8 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
     for (int k = 0; k < N; k++) {
         int tl = tid;   // opaque per-stage copy (keeps the transfer offsets out of loop-invariant registers)
         asm volatile("" : "+v"(tl));
-        double xi[13], bi[13];
-        SFOR(i, 0, 13, { xi[i] = xs[tid * 13 + i]; bi[i] = bs[tid * 13 + i]; });
+        double xi[13];
+        SFOR(i, 0, 13, { xi[i] = xs[tid * 13 + i]; });
         // candidate state of stage k
         SFOR(i, 0, 13, { cs[tid * 13 + i] = xi[i] + dx[i]; });
         // du = -K dx - d, bounds
@@ -1118,11 +1116,10 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         // next stage's inputs (issued here: the gain of stage k is dead, its registers are free)
         const double uc[4] = {cur.u[0], cur.u[1], cur.u[2], cur.u[3]};
         load(imin(k + 1, N - 1), nxt);
-        double xr[13], br[13];
+        double xr[13];
         issue13(P.xit, N + 1, k + 1, tl, xr);
-        issue13(P.b, N, imin(k + 1, N - 1), tl, br);
         // directional derivative of the RK4 step along (dx, du); model vectors in EXTERNAL order
-        double x[13], s[13], xt[13], st[13], kk[13], dk[13], acc[13];
+        double x[13], s[13], xt[13], st[13], kk[13], dk[13], acc[13], ks[13];   // ks = k1 + 2 k2 + 2 k3 + k4 (nominal)
         SFOR(e, 0, 13, { x[e] = xi[int_of(e)]; s[e] = dx[int_of(e)]; });
         double jud[4];
         {
@@ -1138,26 +1135,30 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         jac_point(x, J);
         jvp<true, true>(J, s, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
-        SFOR(e, 0, 13, { acc[e] = dk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
+        SFOR(e, 0, 13, { acc[e] = dk[e]; ks[e] = kk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
         // stage 2
         f_expl(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
-        SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
+        SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; ks[e] = ks[e] + 2 * kk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
         // stage 3
         f_expl(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
-        SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; xt[e] = x[e] + h * kk[e]; st[e] = s[e] + h * dk[e]; });
-        // stage 4
+        SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; ks[e] = ks[e] + 2 * kk[e]; xt[e] = x[e] + h * kk[e]; st[e] = s[e] + h * dk[e]; });
+        // stage 4 (the nominal slope too: b_k = Phi(x_k, u_k) - x_{k+1} is formed here, as k_linearise
+        // forms it, instead of being read back)
+        f_expl(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
+        double dxp[13];   // dx_{k+1} + x_{k+1}
         SFOR(i, 0, 13, {
             constexpr int e = ext_of(i);
-            dx[i] = s[e] + (h / 6.0) * (acc[e] + dk[e]) + bi[i];
+            const double phi = x[e] + (h / 6.0) * (ks[e] + kk[e]);
+            dxp[i] = s[e] + (h / 6.0) * (acc[e] + dk[e]) + phi;
         });
         // candidate tile out, next stage's tiles in
         __syncthreads();
@@ -1167,8 +1168,8 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
             SFOR(j, 0, 13, { *el13(P.dx, tl + 64 * j, N + 1, k) = cv[j]; });
         }
         land13(xs, xr);
-        land13(bs, br);
         __syncthreads();
+        SFOR(i, 0, 13, { dx[i] = dxp[i] - xs[tid * 13 + i]; });
         cur = nxt;
     }
     // candidate of the terminal stage (xs holds x_N)
