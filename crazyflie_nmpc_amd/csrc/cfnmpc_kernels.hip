@@ -813,7 +813,8 @@ __device__ __forceinline__ void load_stage_as(const Params& P, const Lane& t, co
     const int a = t.L & 3;
     const double c = gm(P.tl)[i4(P, t, k, a)];
     const double cls = gm(P.tu)[i4(P, t, k, a)];
-    in.Rh = cls != 0.0 ? AS_BIG : w_u(P, a);   // read in lanes a < 4 only
+    const double ra = w_u(P, a);
+    in.Rh = cls != 0.0 ? AS_BIG * fmax(1.0, ra) : ra;   // read in lanes a < 4 only (the 1e30 is relative to R)
     in.g = 0.0;
     in.qv = 0.0;
     const double cm = t.L < 4 ? c : 0.0;

@@ -413,7 +413,7 @@ static int as_solve(qp_t *qp) {
         solves++;
         for (int k = 0; k < N; k++) {
             const double *B = qp->B + (size_t)k * 52;
-            for (int a = 0; a < NU; a++) Rhat[k * 4 + a] = cls[k * 4 + a] ? 1e30 : qp->Rd[a];
+            for (int a = 0; a < NU; a++) Rhat[k * 4 + a] = cls[k * 4 + a] ? 1e30 * fmax(1.0, qp->Rd[a]) : qp->Rd[a];
             for (int i = 0; i < NX; i++) {
                 double s = 0.0;
                 for (int a = 0; a < NU; a++) s += B[i * NU + a] * c[k * 4 + a];
