@@ -16,6 +16,10 @@ SYMBOLS = [
     "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_step_host", "cfnmpc_get_u", "cfnmpc_get_x",
     "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_estimate", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise",
     "cfnmpc_debug_get_head", "cfnmpc_set_profiling", "cfnmpc_get_profile", "cfnmpc_version",
+    "cfnmpc_fleet_create", "cfnmpc_fleet_free", "cfnmpc_fleet_batch", "cfnmpc_fleet_min_horizon", "cfnmpc_fleet_max_horizon",
+    "cfnmpc_fleet_num_buckets", "cfnmpc_fleet_bucket", "cfnmpc_fleet_workspace_bytes", "cfnmpc_fleet_set_x0",
+    "cfnmpc_fleet_set_yref", "cfnmpc_fleet_set_weights", "cfnmpc_fleet_init_iterate", "cfnmpc_fleet_solve",
+    "cfnmpc_fleet_get_u", "cfnmpc_fleet_get_x", "cfnmpc_fleet_get_stats",
 ]
 
 
@@ -77,6 +81,19 @@ def lib():
     L.cfnmpc_get_profile.argtypes = [vp, vp, vp, vp]
     L.cfnmpc_debug_linearise.argtypes = [vp, vp]
     L.cfnmpc_version.restype = C.c_char_p
+    L.cfnmpc_fleet_create.argtypes = [C.POINTER(vp), i32, vp, C.POINTER(Opts)]
+    for n in ("free", "batch", "min_horizon", "max_horizon", "num_buckets", "workspace_bytes"):
+        getattr(L, "cfnmpc_fleet_" + n).argtypes = [vp]
+    L.cfnmpc_fleet_workspace_bytes.restype = C.c_ulonglong
+    L.cfnmpc_fleet_bucket.argtypes = [vp, i32, vp, vp, C.POINTER(vp), vp]
+    L.cfnmpc_fleet_set_x0.argtypes = [vp, vp, i32, vp]
+    L.cfnmpc_fleet_set_yref.argtypes = [vp, vp, vp, i32, vp]
+    L.cfnmpc_fleet_set_weights.argtypes = [vp, vp, vp]
+    L.cfnmpc_fleet_init_iterate.argtypes = [vp, i32, vp]
+    L.cfnmpc_fleet_solve.argtypes = [vp, i32, vp]
+    L.cfnmpc_fleet_get_u.argtypes = [vp, i32, vp, i32, vp]
+    L.cfnmpc_fleet_get_x.argtypes = [vp, i32, vp, i32, vp]
+    L.cfnmpc_fleet_get_stats.argtypes = [vp, vp, vp, vp, i32, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int or fn.restype is None or name in ("cfnmpc_version", "cfnmpc_workspace_bytes"):

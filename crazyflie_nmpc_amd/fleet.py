@@ -1,58 +1,115 @@
 """Mixed-horizon fleets (BASELINE.json config C5: N in {30, 50, 100}, dt fixed at 15 ms).
 
-A solver object has one horizon (its workspace is wave-blocked by stage), so a mixed fleet is
-bucketed by N: one BatchSolver per horizon, instances addressed through index lists.  This is
-also the unit of multi-GPU balancing (parallel.shard_by_horizon deals buckets out by sum N)."""
+Thin wrapper over the C-ABI's cfnmpc_fleet_* (include/cfnmpc.h): the library buckets the vehicles
+by horizon (one solver per distinct N -- a solver's workspace is blocked by stage for one
+horizon), keeps the caller's vehicle order at the boundary and solves the buckets concurrently.
+A bucket is also the unit of multi-GPU balancing (parallel.shard_by_horizon deals buckets out by
+sum N).  Arrays may be numpy (host) or torch device tensors, as for BatchSolver."""
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 
-from .solver import BatchSolver, default_opts
+from . import _lib
+from ._lib import NU, NX, NY
+from .solver import _arg, _check, default_opts
 from .synthetic import regulation_row
 
 
 class MixedHorizonFleet:
     def __init__(self, horizons, **opt_kw):
-        self.horizons = np.asarray(horizons, dtype=np.int64)
+        self._L = _lib.lib()
+        self.horizons = np.ascontiguousarray(horizons, dtype=np.int32)
         self.B = len(self.horizons)
-        self.buckets = {}
-        for N in sorted(set(self.horizons.tolist())):
-            idx = np.where(self.horizons == N)[0]
-            self.buckets[N] = (idx, BatchSolver(len(idx), default_opts(N=int(N), **opt_kw)))
+        self.opts = default_opts(**opt_kw)
+        h = C.c_void_p()
+        _check(self._L.cfnmpc_fleet_create(C.byref(h), self.B, self.horizons.ctypes.data_as(C.c_void_p), C.byref(self.opts)),
+               "cfnmpc_fleet_create")
+        self._h = h
+        self.Nmin = self._L.cfnmpc_fleet_min_horizon(h)
+        self.Nmax = self._L.cfnmpc_fleet_max_horizon(h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cfnmpc_fleet_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self._L.cfnmpc_fleet_workspace_bytes(self._h))
+
+    def buckets(self):
+        """-> [(N, fleet indices of the bucket's rows)] in ascending N"""
+        out = []
+        for b in range(self._L.cfnmpc_fleet_num_buckets(self._h)):
+            n, c = C.c_int(0), C.c_int(0)
+            _check(self._L.cfnmpc_fleet_bucket(self._h, b, C.byref(n), C.byref(c), None, None), "cfnmpc_fleet_bucket")
+            idx = np.empty(c.value, dtype=np.int32)
+            _check(self._L.cfnmpc_fleet_bucket(self._h, b, None, None, None, idx.ctypes.data_as(C.c_void_p)), "cfnmpc_fleet_bucket")
+            out.append((n.value, idx))
+        return out
 
     def set_regulation(self, xyz, uss):
         """xyz [B][3]: Regulation reference of every vehicle (acados_mpc.cpp:435-454)."""
-        for N, (idx, s) in self.buckets.items():
-            rows = np.stack([regulation_row(xyz[i], uss) for i in idx])
-            s.set_yref(np.repeat(rows[:, None, :], N, 1).copy(), rows[:, :13].copy())
+        rows = np.stack([regulation_row(xyz[i], uss) for i in range(self.B)])
+        self.set_yref(np.repeat(rows[:, None, :], self.Nmax, 1).copy(), rows[:, :13].copy())
+
+    def set_yref(self, yref, yref_e):
+        """yref [B][Nmax][17] (vehicle i uses rows 0..N_i-1), yref_e [B][13]"""
+        p, dev, st, _k = _arg(yref, (self.B, self.Nmax, NY))
+        pe, deve, _st, _k2 = _arg(yref_e, (self.B, NX))
+        if dev != deve:
+            raise ValueError("yref and yref_e must live on the same side")
+        _check(self._L.cfnmpc_fleet_set_yref(self._h, p, pe, dev, st), "cfnmpc_fleet_set_yref")
 
     def set_x0(self, x0):
-        for _N, (idx, s) in self.buckets.items():
-            s.set_x0(np.ascontiguousarray(x0[idx]))
+        p, dev, st, _k = _arg(x0, (self.B, NX))
+        _check(self._L.cfnmpc_fleet_set_x0(self._h, p, dev, st), "cfnmpc_fleet_set_x0")
 
-    def init_iterate(self, mode):
-        for _N, (_idx, s) in self.buckets.items():
-            s.init_iterate(mode)
+    def set_weights(self, W=None, WN=None):
+        w = None if W is None else np.ascontiguousarray(W, dtype=np.float64)
+        wn = None if WN is None else np.ascontiguousarray(WN, dtype=np.float64)
+        _check(self._L.cfnmpc_fleet_set_weights(self._h, None if w is None else w.ctypes.data_as(C.c_void_p),
+                                                None if wn is None else wn.ctypes.data_as(C.c_void_p)), "cfnmpc_fleet_set_weights")
 
-    def solve(self, n_rti=1):
-        for _N, (_idx, s) in self.buckets.items():
-            s.solve(n_rti)
+    def init_iterate(self, mode, stream=None):
+        _check(self._L.cfnmpc_fleet_init_iterate(self._h, int(mode), C.c_void_p(stream or 0)), "cfnmpc_fleet_init_iterate")
 
-    def _gather(self, fn, width):
-        out = np.empty((self.B, width))
-        for _N, (idx, s) in self.buckets.items():
-            out[idx] = fn(s)
+    def solve(self, n_rti=1, stream=None):
+        _check(self._L.cfnmpc_fleet_solve(self._h, int(n_rti), C.c_void_p(stream or 0)), "cfnmpc_fleet_solve")
+
+    def get_u(self, stage, out=None):
+        if out is None:
+            out = np.empty((self.B, NU))
+        p, dev, st, _k = _arg(out, (self.B, NU))
+        _check(self._L.cfnmpc_fleet_get_u(self._h, int(stage), p, dev, st), "cfnmpc_fleet_get_u")
         return out
 
-    def get_u(self, stage):
-        return self._gather(lambda s: s.get_u(stage), 4)
+    def get_x(self, stage, out=None):
+        if out is None:
+            out = np.empty((self.B, NX))
+        p, dev, st, _k = _arg(out, (self.B, NX))
+        _check(self._L.cfnmpc_fleet_get_x(self._h, int(stage), p, dev, st), "cfnmpc_fleet_get_x")
+        return out
 
-    def get_x(self, stage):
-        return self._gather(lambda s: s.get_x(stage), 13)
-
-    def stats(self):
+    def stats(self, out=None):
+        """-> (status, qp_iter, res) [B]; `out` = three torch device tensors (int32, int32, float64)
+        to keep them on the device"""
+        if out is not None:
+            st, it, rs = out
+            ps, dev, strm, _a = _arg(st, (self.B,), np.int32)
+            pi, _d, _s, _b = _arg(it, (self.B,), np.int32)
+            pr, _d2, _s2, _c = _arg(rs, (self.B,))
+            _check(self._L.cfnmpc_fleet_get_stats(self._h, ps, pi, pr, dev, strm), "cfnmpc_fleet_get_stats")
+            return out
         st = np.empty(self.B, dtype=np.int32); it = np.empty(self.B, dtype=np.int32); rs = np.empty(self.B)
-        for _N, (idx, s) in self.buckets.items():
-            a, b, c = s.stats()
-            st[idx], it[idx], rs[idx] = a, b, c
+        _check(self._L.cfnmpc_fleet_get_stats(self._h, st.ctypes.data_as(C.c_void_p), it.ctypes.data_as(C.c_void_p),
+                                              rs.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_fleet_get_stats")
         return st, it, rs

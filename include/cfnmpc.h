@@ -173,6 +173,35 @@ int cfnmpc_debug_linearise(cfnmpc_solver *s, void *stream);
 /* number of leading stages the last QP's interior-point sweeps covered, per instance [B] (host) */
 int cfnmpc_debug_get_head(cfnmpc_solver *s, int *head);
 
+/* ---- mixed-horizon fleets (BASELINE.json config C5: N in {30, 50, 100} side by side) ----------
+ * The reference fixes N when the solver is generated (generate_c_code.py:41-42; one process per
+ * vehicle, acados_mpc.cpp:76-82).  A fleet takes one horizon PER VEHICLE, buckets the vehicles by
+ * horizon (one cfnmpc_solver per distinct N) and keeps the caller's vehicle order at the
+ * boundary: rows move between that order and the buckets on the device (device pointers) or on
+ * the host (host pointers).  Buckets are solved concurrently, each on an internal stream forked
+ * from and joined to `stream`.  opts->N is ignored.  Layouts:
+ *     x0 [B][13];  yref [B][Nmax][17] (vehicle i uses rows 0..N_i-1), yref_e [B][13];
+ *     get_u: stage < min N;  get_x: stage <= min N;  stats [B]. */
+typedef struct cfnmpc_fleet cfnmpc_fleet;
+int cfnmpc_fleet_create(cfnmpc_fleet **out, int batch, const int *N_per_instance /*[B]*/, const cfnmpc_opts *opts);
+int cfnmpc_fleet_free(cfnmpc_fleet *f);
+int cfnmpc_fleet_batch(const cfnmpc_fleet *f);
+int cfnmpc_fleet_min_horizon(const cfnmpc_fleet *f);
+int cfnmpc_fleet_max_horizon(const cfnmpc_fleet *f);
+int cfnmpc_fleet_num_buckets(const cfnmpc_fleet *f);
+/* bucket b (ascending N): its horizon, size, solver (owned by the fleet; for per-bucket calls such
+ * as cfnmpc_get_iterate) and the fleet index of each of its rows [count].  Any pointer may be NULL. */
+int cfnmpc_fleet_bucket(const cfnmpc_fleet *f, int bucket, int *N, int *count, cfnmpc_solver **solver, int *index);
+unsigned long long cfnmpc_fleet_workspace_bytes(const cfnmpc_fleet *f);
+int cfnmpc_fleet_set_x0(cfnmpc_fleet *f, const double *x0, int on_device, void *stream);
+int cfnmpc_fleet_set_yref(cfnmpc_fleet *f, const double *yref, const double *yref_e, int on_device, void *stream);
+int cfnmpc_fleet_set_weights(cfnmpc_fleet *f, const double *W /*[17]*/, const double *WN /*[13]*/);
+int cfnmpc_fleet_init_iterate(cfnmpc_fleet *f, int mode, void *stream);
+int cfnmpc_fleet_solve(cfnmpc_fleet *f, int n_rti, void *stream);
+int cfnmpc_fleet_get_u(cfnmpc_fleet *f, int stage, double *u /*[B][4]*/, int on_device, void *stream);
+int cfnmpc_fleet_get_x(cfnmpc_fleet *f, int stage, double *x /*[B][13]*/, int on_device, void *stream);
+int cfnmpc_fleet_get_stats(cfnmpc_fleet *f, int *status, int *qp_iter, double *res, int on_device, void *stream);
+
 const char *cfnmpc_version(void);
 
 #ifdef __cplusplus

@@ -191,6 +191,61 @@ def test_mixed_horizon_fleet_config5(oracle, cref):
         assert np.abs(x4[idx] - xr[:, 4]).max() < 1e-7
 
 
+def test_fleet_device_pointers_and_buckets_match_single_horizon_solvers(oracle):
+    """cfnmpc_fleet_* with device pointers (row gather / scatter kernels, buckets on forked
+    streams) == the host-pointer path == one BatchSolver per horizon fed the bucket's rows, bit
+    for bit, through a few closed-loop steps; plus the argument checks of the fleet getters."""
+    import torch
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
+    from crazyflie_nmpc_amd.solver import INIT_HOVER, CfnmpcError
+    rng = np.random.default_rng(99)
+    B = 333
+    horizons = rng.choice([12, 30, 50], size=B)
+    Nmax = 50
+    x0, yref, yref_e = _inputs(oracle, B, Nmax, seed=3, scale=2.0)
+    host = MixedHorizonFleet(horizons); dev = MixedHorizonFleet(horizons)
+    assert [n for n, _ in host.buckets()] == [12, 30, 50]
+    assert sorted(np.concatenate([i for _, i in host.buckets()]).tolist()) == list(range(B))
+    singles = {n: (idx, BatchSolver(len(idx), default_opts(N=n))) for n, idx in host.buckets()}
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    host.set_yref(yref, yref_e); dev.set_yref(d(yref), d(yref_e))
+    for n, (idx, s) in singles.items():
+        s.set_yref(yref[idx, :n].copy(), yref_e[idx].copy())
+    x = x0.copy()
+    u_dev = torch.empty(B, 4, dtype=torch.float64, device="cuda"); x_dev = torch.empty(B, 13, dtype=torch.float64, device="cuda")
+    stats_dev = (torch.empty(B, dtype=torch.int32, device="cuda"), torch.empty(B, dtype=torch.int32, device="cuda"),
+                 torch.empty(B, dtype=torch.float64, device="cuda"))
+    for t in range(3):
+        host.set_x0(x); dev.set_x0(d(x))
+        if t == 0:
+            host.init_iterate(INIT_HOVER); dev.init_iterate(INIT_HOVER)
+        host.solve(1); dev.solve(1)
+        dev.get_u(0, u_dev); dev.get_x(1, x_dev); dev.stats(stats_dev)
+        torch.cuda.synchronize()
+        uh, xh = host.get_u(0), host.get_x(1)
+        sh = host.stats()
+        assert np.array_equal(uh, u_dev.cpu().numpy()) and np.array_equal(xh, x_dev.cpu().numpy())
+        for a, b in zip(sh, stats_dev):
+            assert np.array_equal(a, b.cpu().numpy())
+        assert (sh[0] == 0).all()
+        for n, (idx, s) in singles.items():
+            s.set_x0(x[idx].copy())
+            if t == 0:
+                s.init_iterate(INIT_HOVER)
+            s.solve(1)
+            assert np.array_equal(s.get_u(0), uh[idx]) and np.array_equal(s.get_x(1), xh[idx])
+            assert np.array_equal(s.stats()[1], sh[1][idx])
+        x = xh.copy()
+    with pytest.raises(CfnmpcError):
+        host.get_u(12)                       # beyond the shortest horizon
+    host.get_x(12)
+    with pytest.raises(CfnmpcError):
+        host.get_x(13)
+    with pytest.raises(CfnmpcError):
+        MixedHorizonFleet([30, 0, 50])
+
+
 @pytest.mark.parametrize("B", [3, 257, 4099])
 def test_overlapped_preparation_is_bit_identical(oracle, B):
     """cfnmpc_opts.overlap_linearise: linearising for the next step beside the interior-point
