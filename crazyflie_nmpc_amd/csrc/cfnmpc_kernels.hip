@@ -61,6 +61,12 @@ __device__ __forceinline__ double bc(double v) {
     const long long r = __builtin_amdgcn_update_dpp((long long)0, x, 0x150 + L, 0xf, 0xf, true);
     return __builtin_bit_cast(double, r);
 }
+// lane i of every row <- lane i + 4 (row_shl:4; lanes 12..15 get 0)
+__device__ __forceinline__ double shift4(const double v) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const long long r = __builtin_amdgcn_update_dpp((long long)0, x, 0x104, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, r);
+}
 __device__ __forceinline__ double row_sum(double x) {
     double s = 0.0;
     SFOR(l, 0, 16, { s += bc<l>(x); });
@@ -493,7 +499,7 @@ static_assert(WT_TILE >= 13 * WT_ROW && WT_TILE % 2 == 0, "W transpose tile");
 //           stage k.  ABSOLUTE: start solve with the QP's own affine terms (q_k, b_k, r_k);
 //   otherwise R^ and g come from the interior-point state (homogeneous Newton system).
 //   wt: LDS [13*17] (transpose of W), sb: LDS [4*16] (columns of B for lanes 0..3).
-template <bool ABSOLUTE>
+template <bool ABSOLUTE, bool AS = false>
 __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, const int k, double (&Pa)[13],
                                              const StageIn<ABSOLUTE>& in, const double wq, const double is13,
                                              double* wt, double* sb) {
@@ -541,6 +547,10 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     dot2bc<13, 0>(Srow[0], Srow[1], bcl, V[0], V[1]);
     dot2bc<13, 0>(Srow[2], Srow[3], bcl, V[2], V[3]);
     SFOR(c, 0, 4, { settle(Srow[c]); });
+    if (AS && t.L < 4) {
+        gdouble* sr = blk(P.cS, t, P.N, k, SZ_S4) + t.q * 4 + t.L;
+        SFOR(c, 0, 4, { sr[c * 16] = Srow[c]; });
+    }
     double S[10], Si[10];
     SFOR(a, 0, 4, { SFOR(c, a, 4, { S[s4(a, c)] = bc<a>(Srow[c]); }); });
     SFOR(l, 0, 13, { pin(Wt[l]); });
@@ -567,6 +577,14 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     dot2bc<13, 0>(Gp[0], Gp[1], Wt, br[0], br[1]);
     dot2bc<13, 0>(Gp[2], Gp[3], Wt, br[2], br[3]);
     SFOR(a, 0, 4, { dotbc<1, a>(Gp[a], &is13, in.g); });   // lane 13: += g[a]
+    if (AS) {
+        // active-set solve: the forward sweep evaluates the multipliers of the fixed inputs from the
+        // stage's own blocks, B'pi_{k+1} = G dx_k + (B'PB) du_free + rho -- keep G (gain layout),
+        // rho (lane 13) and the rows of S (off-diagonal entries = B'PB, untouched by the fixing weight)
+        gdouble* gr = blk(P.cGR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
+        gdouble* dst = t.L == 13 ? gm(P.crho) + i4(P, t, k, 0) : gr;
+        if (t.L < 14) SFOR(a, 0, 4, { dst[a] = Gp[a]; });
+    }
     chol4_finish(ch, Si);
     const bool ok = ch.ok;
     // (7) K' = G' Sinv  (lane 13: feed-forward d)
@@ -797,9 +815,11 @@ __device__ __forceinline__ void sweep_resolve(const Params& P, const Lane& t, co
 //     augmented Riccati recursion, lane 13), and
 //   * is taken out of the minimisation by a 1e30 on its diagonal entry of R^ (gain row, feed-
 //     forward and its share of P <- M - G'K vanish to 1e-30 relative: no separate code path).
-// One solve = this factorisation, a forward sweep (free inputs from the feedback law, fixed ones
-// = c; state deltas stored), and a backward costate sweep that evaluates the multiplier of every
-// fixed input (grad = R c + B'pi) and re-classifies every input:
+// One solve = this factorisation (which also keeps G = B'PA, rho = B'(p + P b_eff) and the rows of
+// S of every stage) and ONE forward sweep: free inputs from the feedback law, fixed ones = c, and
+// on the way the multiplier of every fixed input, grad = R c + B'pi_{k+1}, from the stage's own
+// blocks -- the costate of the equality-constrained solve is pi = P dx + p, hence
+// B'pi_{k+1} = G dx_k + (B'PB) du_free + rho: no backward costate sweep -- and the new class:
 //   free   : lower / upper if v0 + du leaves the box,
 //   lower  : stays while grad > 0,    upper : stays while grad < 0.
 // A stationary classification satisfies the KKT conditions of the strictly convex QP exactly.
@@ -843,31 +863,70 @@ __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, 
     int k = head - 1;
     while (k >= 0) {
         load_stage_as(P, t, imax(k - 1, 0), bufB);
-        ok = factor_stage<true>(P, t, k, Pa, bufA, wq, is13, wt, sb) && ok;
+        ok = factor_stage<true, true>(P, t, k, Pa, bufA, wq, is13, wt, sb) && ok;
         if (--k < 0) break;
         load_stage_as(P, t, imax(k - 1, 0), bufA);
-        ok = factor_stage<true>(P, t, k, Pa, bufB, wq, is13, wt, sb) && ok;
+        ok = factor_stage<true, true>(P, t, k, Pa, bufB, wq, is13, wt, sb) && ok;
         --k;
     }
     return ok;
 }
-// forward sweep: du -> P.dva, state deltas dx_0 .. dx_head -> P.cdx
-__device__ __forceinline__ void sweep_forward_as(const Params& P, const Lane& t, const int head) {
-    struct In { FwdIn<false> f; double c, cls; };
+// forward sweep: du -> P.dva; multipliers of the fixed inputs and re-classification of every input
+// on the way (stage-local: grad = R c + B'pi_{k+1} with B'pi_{k+1} = G dx_k + (B'PB) du_free + rho,
+// pi = P dx + p being the costate of the equality-constrained solve).  True if any input of the
+// row changed its class.
+__device__ __forceinline__ bool sweep_forward_as(const Params& P, const Lane& t, const int head) {
+    // kg: lanes 0..3 hold K[a][0..12], lanes 4..7 hold G[a][0..12] -- ONE chain of 13 broadcast FMAs
+    // forms the feedback (lanes 0..3) and G dx (lanes 4..7) together
+    struct In { double kg[13], ar[10], br[4], d, sr[4], rho, c, cls, v0, uk; };
+    const int a = t.L & 3;
+    const bool lo4 = t.L < 4;
     auto load = [&](int k, In& in) {
-        load_fwd<false>(P, t, k, in.f);
-        in.c = gm(P.tl)[i4(P, t, k, t.L & 3)];
-        in.cls = gm(P.tu)[i4(P, t, k, t.L & 3)];
+        const gdouble* kb = blk(P.KR, t, P.N, k, SZ_K);
+        const gdouble* gb = blk(P.cGR, t, P.N, k, SZ_K);
+        const gdouble* src = (lo4 ? kb : gb) + t.q * 4 + a;
+        SFOR(l, 0, 13, { in.kg[l] = src[l * 16]; });
+        ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
+        ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+        const gdouble* sr = blk(P.cS, t, P.N, k, SZ_S4) + t.q * 4 + a;
+        SFOR(c, 0, 4, { in.sr[c] = sr[c * 16]; });
+        const size_t idx = i4(P, t, k, a);
+        in.d = gm(P.d)[idx];
+        in.rho = gm(P.crho)[idx];
+        in.c = gm(P.tl)[idx]; in.cls = gm(P.tu)[idx]; in.v0 = gm(P.v)[idx]; in.uk = gm(P.uit)[idx];
     };
     double x = 0.0;
+    bool changed = false;
     auto body = [&](const In& cur, int k) {
-        st13(blk(P.cdx, t, P.N + 1, k, SZ_V13), t, x);
-        double dv = feedback<false>(t, cur.f, x);
-        dv = cur.cls != 0.0 ? cur.c : dv;
-        if (t.L < 4) gm(P.dva)[i4(P, t, k, t.L)] = dv;
-        double vr[4];
-        SFOR(a, 0, 4, { vr[a] = bc<a>(dv); });
-        x = propagate<false>(t, cur.f, x, vr);
+        double acc = 0.0;
+        dotbc<13, 0>(acc, cur.kg, x);        // lanes 0..3: K[a] dx, lanes 4..7: G[a] dx
+        settle(acc);
+        double dv = lo4 ? -cur.d - acc : 0.0;
+        dv = (lo4 && cur.cls != 0.0) ? cur.c : dv;
+        if (lo4) gm(P.dva)[i4(P, t, k, t.L)] = dv;
+        double gd = shift4(acc);             // lane a <- lane a + 4
+        double vr[4], fr[4];
+        SFOR(c, 0, 4, { vr[c] = bc<c>(dv); });
+        const double dfree = cur.cls == 0.0 ? dv : 0.0;
+        SFOR(c, 0, 4, { fr[c] = bc<c>(dfree); });
+        SFOR(c, 0, 4, { gd += cur.sr[c] * fr[c]; });     // + (B'PB)[a][free] du_free
+        if (lo4) {
+            const double grad = w_u(P, a) * cur.c + gd + cur.rho;   // multiplier of a fixed input
+            const double lb = P.u_min - cur.uk, ub = P.u_max - cur.uk;
+            const double vn = cur.v0 + dv;
+            double nc;
+            if (cur.cls == 0.0) nc = vn < lb ? 1.0 : (vn > ub ? 2.0 : 0.0);
+            else if (cur.cls == 1.0) nc = grad > 0.0 ? 1.0 : 0.0;
+            else nc = grad < 0.0 ? 2.0 : 0.0;
+            changed = changed || (nc != cur.cls);
+            const size_t idx = i4(P, t, k, a);
+            gm(P.tu)[idx] = nc;
+            gm(P.tl)[idx] = nc == 1.0 ? lb - cur.v0 : (nc == 2.0 ? ub - cur.v0 : 0.0);
+        }
+        double xn = t.L < 3 ? x : 0.0;
+        dotbc<10, 3>(xn, cur.ar, x);
+        SFOR(c, 0, 4, { xn += cur.br[c] * vr[c]; });
+        x = xn;
     };
     In b0, b1, b2;
     load(0, b0);
@@ -883,87 +942,6 @@ __device__ __forceinline__ void sweep_forward_as(const Params& P, const Lane& t,
         load(imin(k + 2, head - 1), b1);
         body(b2, k);
         ++k;
-    }
-    st13(blk(P.cdx, t, P.N + 1, head, SZ_V13), t, x);
-}
-// backward costate sweep + re-classification; true if any input of the row changed its class
-__device__ __forceinline__ bool sweep_costate_as(const Params& P, const Lane& t, const int head, const int chk) {
-    const int N = P.N;
-    const int a = t.L & 3;
-    // pi_head = P_head dx_head (cost-to-go of the unconstrained tail; terminal weight if head = N)
-    double p[13];
-    {
-        double Prow[13];
-        if (chk < 0) {
-            SFOR(j, 0, 13, { Prow[j] = (t.L == j) ? P.WN[ext_of(j)] : 0.0; });
-        } else {
-            const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + chk) * SZ_P;
-            SFOR(j, 0, 13, {
-                const double v = pc[(j * 4 + t.q) * 13 + imin(t.L, 12)];
-                Prow[j] = t.L < 13 ? v : 0.0;
-            });
-        }
-        const double dxh = ld13(blk(P.cdx, t, N + 1, head, SZ_V13), t);
-        double pid = 0.0;
-        dotbc<13, 0>(pid, Prow, dxh);
-        settle(pid);
-        SFOR(j, 0, 13, { p[j] = bc<j>(pid); });
-    }
-    struct In { double ar[10], br[4], dxk, c, cls, v0, uk, du; };
-    auto load = [&](int k, In& in) {
-        ld_ar_raw(blk(P.AR, t, N, k, SZ_A), t, in.ar);
-        ld_rows4_raw(blk(P.BR, t, N, k, SZ_B), t, in.br);
-        in.dxk = ld13(blk(P.cdx, t, N + 1, k, SZ_V13), t);
-        const size_t idx = i4(P, t, k, a);
-        in.c = gm(P.tl)[idx]; in.cls = gm(P.tu)[idx]; in.v0 = gm(P.v)[idx]; in.uk = gm(P.uit)[idx]; in.du = gm(P.dva)[idx];
-    };
-    bool changed = false;
-    auto body = [&](const In& cur, int k) {
-        // rr[c] = sum_l pi_{k+1}[l] B[l][c]   (replicated)
-        double rr[4] = {0.0, 0.0, 0.0, 0.0};
-        dot2bc<13, 0>(rr[0], rr[1], p, cur.br[0], cur.br[1]);
-        dot2bc<13, 0>(rr[2], rr[3], p, cur.br[2], cur.br[3]);
-        if (t.L < 4) {
-            const double grad = w_u(P, a) * cur.c + pick(rr, a);   // multiplier of a fixed input
-            const double lb = P.u_min - cur.uk, ub = P.u_max - cur.uk;
-            const double vn = cur.v0 + cur.du;
-            double nc;
-            if (cur.cls == 0.0) nc = vn < lb ? 1.0 : (vn > ub ? 2.0 : 0.0);
-            else if (cur.cls == 1.0) nc = grad > 0.0 ? 1.0 : 0.0;
-            else nc = grad < 0.0 ? 2.0 : 0.0;
-            changed = changed || (nc != cur.cls);
-            const size_t idx = i4(P, t, k, a);
-            gm(P.tu)[idx] = nc;
-            gm(P.tl)[idx] = nc == 1.0 ? lb - cur.v0 : (nc == 2.0 ? ub - cur.v0 : 0.0);
-        }
-        // pi_k' = (Q dx_k)' + pi_{k+1}' A
-        double pn[13];
-        SFOR(j, 0, 3, { pn[j] = p[j]; });
-        SFOR(j, 3, 13, { pn[j] = 0.0; });
-        dot2bc<6, 0>(pn[3], pn[4], p, cur.ar[0], cur.ar[1]);
-        dotbc<6, 0>(pn[5], p, cur.ar[2]);
-        dot2bc<10, 0>(pn[6], pn[7], p, cur.ar[3], cur.ar[4]);
-        dot2bc<10, 0>(pn[8], pn[9], p, cur.ar[5], cur.ar[6]);
-        dot2bc<13, 0>(pn[10], pn[11], p, cur.ar[7], cur.ar[8]);
-        dotbc<13, 0>(pn[12], p, cur.ar[9]);
-        SFOR(j, 0, 13, { settle(pn[j]); });
-        const double dxk = cur.dxk;
-        SFOR(j, 0, 13, { p[j] = pn[j] + P.W[ext_of(j)] * bc<j>(dxk); });
-    };
-    In b0, b1, b2;
-    load(head - 1, b0);
-    load(imax(head - 2, 0), b1);
-    int k = head - 1;
-    while (k >= 0) {
-        load(imax(k - 2, 0), b2);
-        body(b0, k);
-        if (--k < 0) break;
-        load(imax(k - 2, 0), b0);
-        body(b1, k);
-        if (--k < 0) break;
-        load(imax(k - 2, 0), b1);
-        body(b2, k);
-        --k;
     }
     return row_max(changed ? 1.0 : 0.0) > 0.0;
 }
@@ -1437,9 +1415,11 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             }
             bool as_ok = true;
             for (int it = 1; it <= AS_MAX_SOLVES; it++) {
+                PROF_T(1)
                 as_ok = sweep_factor_as(Q, tc, head, chk, wt, sb) && as_ok;
-                sweep_forward_as(Q, tc, head);
-                const bool changed = sweep_costate_as(Q, tc, head, chk);
+                PROF_T(2)
+                const bool changed = sweep_forward_as(Q, tc, head);
+                PROF_T(3)
                 const bool fine = row_min(as_ok ? 1.0 : 0.0) > 0.0;
                 if (infeasible && !as_done && !changed && fine) { as_done = true; as_iters = it; }
                 if (!__any(infeasible && !as_done && fine)) break;

@@ -43,6 +43,7 @@ constexpr int SZ_K = 4 * 52;   // KR (lane a holds K[a][0..12]): [l][inst][4]
 constexpr int SZ_V13 = 4 * 13; // 13-vectors: [inst][13]
 constexpr int SZ_V4 = 4 * 4;   // 4-vectors:  [inst][4]
 constexpr int SZ_S = 4 * 10;   // packed symmetric 4x4: [inst][10]
+constexpr int SZ_S4 = 4 * 16;  // full 4x4, row a in lane a: [c][inst][a]
 constexpr int SZ_Y = 4 * 17;   // yref row: [inst][17] (first 13 in internal order)
 constexpr int SZ_P = 4 * 13 * 13;  // a row-distributed 13x13: [col j][inst][13]
 
@@ -78,7 +79,9 @@ struct Params {
     double *dx;  // (N+1) x SZ_V13: step in x of the accepted QP solution (commit buffer)
     // compact scratch of the interior-point kernel (same block shapes, indexed by compacted slot)
     double *cAR, *cBR, *cKR, *cSinv, *cd, *cPchk, *cv, *cuit;
-    double *cdx;     // (N+1) x SZ_V13 per compact block: state deltas of the active-set solve
+    // active-set solve, per compact block and stage: G = B'PA in the gain layout (SZ_K), the rows of
+    // S = R^ + B'PB (SZ_S4: [c][inst][a]) and rho = B'(p + P b_eff) (SZ_V4)
+    double *cGR, *cS, *crho;
     int active_set;  // 1: try the primal-dual active-set solve before the interior-point iteration
     int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
     double *res, *viol;          // per instance
