@@ -83,6 +83,11 @@ __device__ __forceinline__ double row_max(double x) {
     return s;
 }
 
+__device__ __forceinline__ double lane_wu(const Params& P, int a) {
+    double w = a == 0 ? P.W[13] : (a == 1 ? P.W[14] : (a == 2 ? P.W[15] : P.W[16]));
+    asm volatile("" : "+v"(w));
+    return w;
+}
 struct Lane {
     int L;      // lane in row: 0..12 state rows, 13 affine row, 14/15 idle
     int row;    // DPP row of this lane inside the wavefront, 0..3 (LDS tile index)
@@ -90,6 +95,9 @@ struct Lane {
     int wave;   // workspace block (= "home" wave) of the instance
     int inst;   // global instance
     bool valid;
+    double wu;  // input weight R_a of this lane's input slot a = L & 3 (kept in a register: a select
+                // chain at the point of use gets turned into a lookup table in scratch, whose load
+                // then sits in the middle of the prefetch queue of every stage)
 };
 __device__ __forceinline__ Lane lane_id(const Params& P) {
     Lane t;
@@ -99,6 +107,7 @@ __device__ __forceinline__ Lane lane_id(const Params& P) {
     t.wave = blockIdx.x;
     t.inst = t.wave * 4 + t.q;
     t.valid = t.inst < P.B;
+    t.wu = lane_wu(P, t.L & 3);
     return t;
 }
 // Row r of this wavefront works on an arbitrary instance (compacted interior-point waves);
@@ -111,6 +120,7 @@ __device__ __forceinline__ Lane lane_indirect(const Params& P, int inst, bool va
     t.wave = t.inst >> 2;
     t.q = t.inst & 3;
     t.valid = valid;
+    t.wu = lane_wu(P, t.L & 3);
     return t;
 }
 // Workspace pointers live inside the by-value Params struct, where clang cannot infer the
@@ -178,11 +188,6 @@ __device__ __forceinline__ void ld_cols4(const gdouble* b, const Lane& t, double
     });
 }
 
-// input weight R_a for a runtime a in 0..3 (a select chain: dynamic indexing of the kernel
-// argument struct would force a scratch copy of it)
-__device__ __forceinline__ double w_u(const Params& P, int a) {
-    return a == 0 ? P.W[13] : (a == 1 ? P.W[14] : (a == 2 ? P.W[15] : P.W[16]));
-}
 // select element `idx` (runtime) of a register array
 template <int N>
 __device__ __forceinline__ double pick(const double (&a)[N], int idx) {
@@ -472,7 +477,7 @@ __device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const
         const double uk = gm(P.uit)[i4(P, t, k, a)];
         const gdouble* yb = blk(P.yref, t, P.N, k, SZ_Y);
         const double yr = yb[t.q * 17 + 13 + a];
-        const double wa = w_u(P, a);
+        const double wa = t.wu;
         in.Rh = wa;                 // read in lanes a < 4 only
         in.g = wa * (uk - yr);
         in.bv = blk(P.b, t, P.N, k, SZ_V13)[t.q * 13 + imin(t.L, 12)];
@@ -833,7 +838,7 @@ __device__ __forceinline__ void load_stage_as(const Params& P, const Lane& t, co
     const int a = t.L & 3;
     const double c = gm(P.tl)[i4(P, t, k, a)];
     const double cls = gm(P.tu)[i4(P, t, k, a)];
-    const double ra = w_u(P, a);
+    const double ra = t.wu;
     in.Rh = cls != 0.0 ? AS_BIG * fmax(1.0, ra) : ra;   // read in lanes a < 4 only (the 1e30 is relative to R)
     in.g = 0.0;
     in.qv = 0.0;
@@ -911,7 +916,7 @@ __device__ __forceinline__ bool sweep_forward_as(const Params& P, const Lane& t,
         SFOR(c, 0, 4, { fr[c] = bc<c>(dfree); });
         SFOR(c, 0, 4, { gd += cur.sr[c] * fr[c]; });     // + (B'PB)[a][free] du_free
         if (lo4) {
-            const double grad = w_u(P, a) * cur.c + gd + cur.rho;   // multiplier of a fixed input
+            const double grad = t.wu * cur.c + gd + cur.rho;   // multiplier of a fixed input
             const double lb = P.u_min - cur.uk, ub = P.u_max - cur.uk;
             const double vn = cur.v0 + dv;
             double nc;
@@ -1461,7 +1466,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                         gm(Q.tl)[idx] = tl; gm(Q.tu)[idx] = tu; gm(Q.ll)[idx] = ll; gm(Q.lu)[idx] = lu; gm(Q.rg)[idx] = rg;
                         const double rl = v - lb - tl, ru = ub - v - tu;
                         const double Dl = ll * itl, Du = lu * itu;
-                        gm(Q.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
+                        gm(Q.Rh)[idx] = t.wu + Dl + Du;
                         gm(Q.g)[idx] = rg + ll + Dl * rl - lu - Du * ru;
                         mu += ll * tl + lu * tu;
                         res = fmax(res, fmax(fmax(ll * tl, lu * tu), fmax(fabs(rg), fmax(fabs(rl), fabs(ru)))));
@@ -1574,7 +1579,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                     const double Dl = ll * rcp_nr(tl), Du = lu * rcp_nr(tu);
                     if (R.act) {
                         gm(Q.v)[idx] = v; gm(Q.tl)[idx] = tl; gm(Q.tu)[idx] = tu; gm(Q.ll)[idx] = ll; gm(Q.lu)[idx] = lu; gm(Q.rg)[idx] = rg;
-                        gm(Q.Rh)[idx] = w_u(P, e & 3) + Dl + Du;
+                        gm(Q.Rh)[idx] = t.wu + Dl + Du;
                         gm(Q.g)[idx] = rg + ll + Dl * rln - lu - Du * run;
                     }
                     mu += ll * tl + lu * tu;
