@@ -1313,8 +1313,10 @@ __device__ __forceinline__ void elem_pass(const Params& P, size_t base, int n, i
 #ifdef CFN_PROF
 __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave, [8] its total, [9] sum of totals, [10] waves, [16..23] phase sums
 #define PROF_T(i) { const unsigned long long now_ = wall_clock64(); pacc[i] += now_ - plast; plast = now_; }
+#define PROF_SOLVE(h) { psolves++; pstages += (h); }
 #else
 #define PROF_T(i)
+#define PROF_SOLVE(h)
 #endif
 // One wave = four compacted constrained instances.  MODE 0: everything (active-set solves if
 // P.active_set, then the interior point for the rows that did not settle); MODE 1: active-set
@@ -1325,6 +1327,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
 #ifdef CFN_PROF
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
     const unsigned long long pstart = plast;
+    unsigned long long psolves = 0, pstages = 0;
 #endif
     const int nipm = gm(P.nipm)[0];
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 4);
@@ -1423,6 +1426,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 PROF_T(1)
                 as_ok = sweep_factor_as(Q, tc, head, chk, wt, sb) && as_ok;
                 PROF_T(2)
+                PROF_SOLVE(head)
                 const bool changed = sweep_forward_as(Q, tc, head);
                 PROF_T(3)
                 const bool fine = row_min(as_ok ? 1.0 : 0.0) > 0.0;
@@ -1682,7 +1686,11 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     if (threadIdx.x == 0) {
         const unsigned long long tot = plast - pstart;
         const unsigned long long old = atomicMax(&g_prof[8], tot);
-        if (tot > old) for (int i = 0; i < 8; i++) g_prof[i] = pacc[i];   // (racy, development aid) phases of the longest wave
+        if (tot > old) {   // (racy, development aid) phases of the longest wave
+            for (int i = 0; i < 8; i++) g_prof[i] = pacc[i];
+            g_prof[11] = psolves; g_prof[12] = pstages;
+        }
+        atomicAdd(&g_prof[13], psolves); atomicAdd(&g_prof[14], pstages);
         atomicAdd(&g_prof[9], tot);
         atomicAdd(&g_prof[10], 1ull);
         for (int i = 0; i < 8; i++) atomicAdd(&g_prof[16 + i], pacc[i]);
@@ -1715,6 +1723,8 @@ __global__ __launch_bounds__(64) void k_bench_sweep(Params P, int head, int reps
         if (which == 0) ok = sweep_factor<false>(P, t, head, -1, wtile[t.row], btile[t.row]) && ok;
         if (which == 1) sweep_forward_delta(P, t, head, gm(P.dva));
         if (which == 2) sweep_resolve(P, t, head);
+        if (which == 3) ok = sweep_factor_as(P, t, head, -1, wtile[t.row], btile[t.row]) && ok;
+        if (which == 4) ok = sweep_forward_as(P, t, head) && ok;
     }
     if (!ok && t.L == 77) gm(P.res)[0] = 1.0;
 }

@@ -28,7 +28,7 @@ s.solve(1)   # fills A, B, K, Rh, g ... with sane numbers
 torch.cuda.synchronize()
 out = [os.path.basename(sys.argv[1])]
 for waves in (1024, 2048):
-    for which, name in ((0, "factor"), (1, "forward"), (2, "resolve")):
+    for which, name in ((0, "factor"), (1, "forward"), (2, "resolve"), (3, "factor_as"), (4, "forward_as")):
         for head in (16, 50):
             reps = 20
             ms = L.cfnmpc_debug_bench_sweep(s._h, waves, head, reps, which)
