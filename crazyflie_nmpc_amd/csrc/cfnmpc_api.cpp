@@ -195,6 +195,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(cSinv, NW * N * cfn::SZ_S); ALLOC(cd, NW * 4 * N * 4); ALLOC(cPchk, NW * cfn::N_CHK * cfn::SZ_P);
     ALLOC(cv, NW * 4 * N * 4); ALLOC(cuit, NW * 4 * N * 4); ALLOC(cGR, NW * N * cfn::SZ_K);
     ALLOC(cS, NW * N * cfn::SZ_S4); ALLOC(crho, NW * 4 * N * 4);
+    ALLOC(cPs, NW * 32 * cfn::SZ_PA);
     ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4); ALLOC(viol, NW * 4);
     ALLOC(ilist, NW * 4); ALLOC(nipm, 4);
     ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * 32); ALLOC(rank, NW * 4); ALLOC(done, NW * 4);

@@ -847,10 +847,18 @@ __device__ __forceinline__ void load_stage_as(const Params& P, const Lane& t, co
     SFOR(aa, 0, 4, { bv += in.br[aa] * bc<aa>(cm); });   // b_eff[i] = sum_a B[i][a] c_a in lane i
     in.bv = bv;
 }
+// Backward sweep over stages kstart .. 0.  kstart = head - 1: from the terminal cost / the checkpoint
+// of the unconstrained tail; kstart < head - 1 (later solves: no input of a stage > kstart changed
+// its class, so P_{kstart+1} and everything stored for the stages behind it are still valid): from
+// the cost-to-go this sweep saved at stage kstart + 1 during an earlier solve.
+constexpr int AS_PSAVE = 32;   // stages 1 .. AS_PSAVE-1 keep their cost-to-go (P.cPs)
 __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, const int head, const int chk,
-                                                double* wt, double* sb) {
+                                                const int kstart, double* wt, double* sb) {
     double Pa[13];
-    if (chk < 0) {
+    if (kstart + 1 < head) {
+        const gdouble* ps = blk(P.cPs, t, AS_PSAVE, kstart + 1, SZ_PA) + t.q * 14 + imin(t.L, 13);
+        SFOR(j, 0, 13, { Pa[j] = ps[j * 56]; });
+    } else if (chk < 0) {
         SFOR(j, 0, 13, { Pa[j] = (t.L == j) ? P.WN[ext_of(j)] : 0.0; });
     } else {
         const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + chk) * SZ_P;
@@ -863,24 +871,32 @@ __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, 
     double wq = 0.0;
     SFOR(j, 0, 13, { if (t.L == j) wq = P.W[ext_of(j)]; });
     const double is13 = t.L == 13 ? 1.0 : 0.0;
+    auto keep = [&](int k) {
+        if (k > 0 && k < AS_PSAVE && t.L < 14) {
+            gdouble* ps = blk(P.cPs, t, AS_PSAVE, k, SZ_PA) + t.q * 14 + t.L;
+            SFOR(j, 0, 13, { ps[j * 56] = Pa[j]; });
+        }
+    };
     StageIn<true> bufA, bufB;
-    load_stage_as(P, t, head - 1, bufA);
-    int k = head - 1;
+    load_stage_as(P, t, kstart, bufA);
+    int k = kstart;
     while (k >= 0) {
         load_stage_as(P, t, imax(k - 1, 0), bufB);
         ok = factor_stage<true, true>(P, t, k, Pa, bufA, wq, is13, wt, sb) && ok;
+        keep(k);
         if (--k < 0) break;
         load_stage_as(P, t, imax(k - 1, 0), bufA);
         ok = factor_stage<true, true>(P, t, k, Pa, bufB, wq, is13, wt, sb) && ok;
+        keep(k);
         --k;
     }
     return ok;
 }
 // forward sweep: du -> P.dva; multipliers of the fixed inputs and re-classification of every input
 // on the way (stage-local: grad = R c + B'pi_{k+1} with B'pi_{k+1} = G dx_k + (B'PB) du_free + rho,
-// pi = P dx + p being the costate of the equality-constrained solve).  True if any input of the
-// row changed its class.
-__device__ __forceinline__ bool sweep_forward_as(const Params& P, const Lane& t, const int head) {
+// pi = P dx + p being the costate of the equality-constrained solve).  Returns the last stage of
+// the row in which an input changed its class (-1: none).
+__device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, const int head) {
     // kg: lanes 0..3 hold K[a][0..12], lanes 4..7 hold G[a][0..12] -- ONE chain of 13 broadcast FMAs
     // forms the feedback (lanes 0..3) and G dx (lanes 4..7) together
     struct In { double kg[13], ar[10], br[4], d, sr[4], rho, c, cls, v0, uk; };
@@ -901,7 +917,7 @@ __device__ __forceinline__ bool sweep_forward_as(const Params& P, const Lane& t,
         in.c = gm(P.tl)[idx]; in.cls = gm(P.tu)[idx]; in.v0 = gm(P.v)[idx]; in.uk = gm(P.uit)[idx];
     };
     double x = 0.0;
-    bool changed = false;
+    int jm = -1;
     auto body = [&](const In& cur, int k) {
         double acc = 0.0;
         dotbc<13, 0>(acc, cur.kg, x);        // lanes 0..3: K[a] dx, lanes 4..7: G[a] dx
@@ -923,7 +939,7 @@ __device__ __forceinline__ bool sweep_forward_as(const Params& P, const Lane& t,
             if (cur.cls == 0.0) nc = vn < lb ? 1.0 : (vn > ub ? 2.0 : 0.0);
             else if (cur.cls == 1.0) nc = grad > 0.0 ? 1.0 : 0.0;
             else nc = grad < 0.0 ? 2.0 : 0.0;
-            changed = changed || (nc != cur.cls);
+            jm = nc != cur.cls ? k : jm;
             const size_t idx = i4(P, t, k, a);
             gm(P.tu)[idx] = nc;
             gm(P.tl)[idx] = nc == 1.0 ? lb - cur.v0 : (nc == 2.0 ? ub - cur.v0 : 0.0);
@@ -948,7 +964,7 @@ __device__ __forceinline__ bool sweep_forward_as(const Params& P, const Lane& t,
         body(b2, k);
         ++k;
     }
-    return row_max(changed ? 1.0 : 0.0) > 0.0;
+    return (int)row_max((double)jm);
 }
 
 // =============================================================================================
@@ -1422,12 +1438,17 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 });
             }
             bool as_ok = true;
+            int kstart = head - 1;
             for (int it = 1; it <= AS_MAX_SOLVES; it++) {
                 PROF_T(1)
-                as_ok = sweep_factor_as(Q, tc, head, chk, wt, sb) && as_ok;
+                as_ok = sweep_factor_as(Q, tc, head, chk, kstart, wt, sb) && as_ok;
                 PROF_T(2)
-                PROF_SOLVE(head)
-                const bool changed = sweep_forward_as(Q, tc, head);
+                PROF_SOLVE(kstart + 1)
+                int jw = sweep_forward_as(Q, tc, head);
+                const bool changed = jw >= 0;
+                jw = max(jw, __shfl_xor(jw, 16));
+                jw = max(jw, __shfl_xor(jw, 32));
+                kstart = (jw >= 0 && jw + 1 < AS_PSAVE) ? jw : head - 1;   // restart point of the next factorisation (wave-uniform)
                 PROF_T(3)
                 const bool fine = row_min(as_ok ? 1.0 : 0.0) > 0.0;
                 if (infeasible && !as_done && !changed && fine) { as_done = true; as_iters = it; }
@@ -1723,8 +1744,8 @@ __global__ __launch_bounds__(64) void k_bench_sweep(Params P, int head, int reps
         if (which == 0) ok = sweep_factor<false>(P, t, head, -1, wtile[t.row], btile[t.row]) && ok;
         if (which == 1) sweep_forward_delta(P, t, head, gm(P.dva));
         if (which == 2) sweep_resolve(P, t, head);
-        if (which == 3) ok = sweep_factor_as(P, t, head, -1, wtile[t.row], btile[t.row]) && ok;
-        if (which == 4) ok = sweep_forward_as(P, t, head) && ok;
+        if (which == 3) ok = sweep_factor_as(P, t, head, -1, head - 1, wtile[t.row], btile[t.row]) && ok;
+        if (which == 4) ok = sweep_forward_as(P, t, head) < 0 && ok;
     }
     if (!ok && t.L == 77) gm(P.res)[0] = 1.0;
 }

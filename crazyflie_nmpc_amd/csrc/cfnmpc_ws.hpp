@@ -46,6 +46,7 @@ constexpr int SZ_S = 4 * 10;   // packed symmetric 4x4: [inst][10]
 constexpr int SZ_S4 = 4 * 16;  // full 4x4, row a in lane a: [c][inst][a]
 constexpr int SZ_Y = 4 * 17;   // yref row: [inst][17] (first 13 in internal order)
 constexpr int SZ_P = 4 * 13 * 13;  // a row-distributed 13x13: [col j][inst][13]
+constexpr int SZ_PA = 4 * 13 * 14; // ... with the affine row (lane 13): [col j][inst][14]
 
 constexpr int N_CHK = 6;  // Riccati checkpoints for the active-horizon QP (stage indices below)
 __host__ __device__ constexpr int chk_stage(int c) { return c == 0 ? 4 : (c == 1 ? 8 : (c == 2 ? 12 : (c == 3 ? 16 : (c == 4 ? 24 : 32)))); }
@@ -82,6 +83,7 @@ struct Params {
     // active-set solve, per compact block and stage: G = B'PA in the gain layout (SZ_K), the rows of
     // S = R^ + B'PB (SZ_S4: [c][inst][a]) and rho = B'(p + P b_eff) (SZ_V4)
     double *cGR, *cS, *crho;
+    double *cPs;     // AS_PSAVE x SZ_PA per compact block: cost-to-go (with affine row) of the stages 1..31
     int active_set;  // 1: try the primal-dual active-set solve before the interior-point iteration
     int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
     double *res, *viol;          // per instance
