@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/cfnmpc.h"
@@ -183,7 +184,8 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     const size_t NW = P.NW + 1, N = P.N;
     int rc = CFNMPC_OK;
 #define ALLOC(field, cnt) if (rc == CFNMPC_OK) rc = dev_alloc(s, &P.field, (size_t)(cnt))
-    ALLOC(xit, NW * (N + 1) * cfn::SZ_V13); ALLOC(uit, NW * 4 * N * 4); ALLOC(x0, NW * cfn::SZ_V13);
+    ALLOC(xit, NW * (N + 1) * cfn::SZ_V13); ALLOC(uit, NW * 4 * N * 4);
+    ALLOC(xitn, NW * (N + 1) * cfn::SZ_V13); ALLOC(uitn, NW * 4 * N * 4); ALLOC(x0, NW * cfn::SZ_V13);
     ALLOC(yref, NW * N * cfn::SZ_Y); ALLOC(yref_e, NW * cfn::SZ_V13);
     ALLOC(AR, NW * N * cfn::SZ_A); ALLOC(BR, NW * N * cfn::SZ_B); ALLOC(b, NW * N * cfn::SZ_V13);
     ALLOC(KR, NW * N * cfn::SZ_K); ALLOC(Sinv, NW * N * cfn::SZ_S);
@@ -312,6 +314,8 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
             if (e) HIP_TRY(hipEventRecord(e[1], st));
             cfn::launch_qp(s->P, st);
             if (e) HIP_TRY(hipEventRecord(e[2], st));
+            std::swap(s->P.xit, s->P.xitn);   // the step's kernels wrote every instance's new iterate there
+            std::swap(s->P.uit, s->P.uitn);
             s->lin_valid = false;   // the iterate moved
             continue;
         }
@@ -325,6 +329,8 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
         // ... and preparation of the next step into the alternate set: an early pass over ALL
         // instances runs beside the interior-point kernel (the instances still inside it are
         // linearised around a stale iterate there and redone by the list pass afterwards)
+        std::swap(s->P.xit, s->P.xitn);   // (host-side: kernel arguments are by value)
+        std::swap(s->P.uit, s->P.uitn);
         cfn::Params Q = s->P;
         Q.AR = s->AR2; Q.BR = s->BR2; Q.b = s->b2;
         HIP_TRY(hipStreamWaitEvent(s->aux, s->ev_start, 0));

@@ -979,10 +979,12 @@ __global__ __launch_bounds__(64, 2) void k_factor(Params P) {
     if (t.L == 0 && t.valid) gm(P.status)[t.inst] = ok ? 0 : 4;
 }
 
-// full RTI step of one row (acados_solve() epilogue): iterate += accepted step.  `doit` is
-// row-uniform; the step (P.dx, P.v) was written by this very wave, so the reads hit in L2.
-__device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const bool doit) {
-    if (!doit) return;
+// full RTI step of one row (acados_solve() epilogue): new iterate = old iterate + accepted step
+// (`doit`), or = old iterate for a row whose QP failed (`keep`); both row-uniform.  The new
+// iterate lives in the buffers the host swaps in after the step.  The step (P.dx, P.v) was written
+// by this very wave, so the reads hit in L2.
+__device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const bool doit, const bool keep) {
+    if (!doit && !keep) return;
     const int N = P.N;
     // batches of four (loads first): one memory round trip per batch instead of one per stage
     const int lx = t.q * 13 + imin(t.L, 12);
@@ -993,7 +995,7 @@ __device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const
             xo[j] = blk(P.xit, t, N + 1, k, SZ_V13)[lx];
             dxk[j] = blk(P.dx, t, N + 1, k, SZ_V13)[lx];
         });
-        SFOR(j, 0, 4, { if (t.L < 13 && k0 + j <= N) blk(P.xit, t, N + 1, k0 + j, SZ_V13)[lx] = xo[j] + dxk[j]; });
+        SFOR(j, 0, 4, { if (t.L < 13 && k0 + j <= N) blk(P.xitn, t, N + 1, k0 + j, SZ_V13)[lx] = doit ? xo[j] + dxk[j] : xo[j]; });
     }
     const size_t ibase = (size_t)t.inst * N * 4;
     for (int e0 = t.L; e0 < N * 4; e0 += 64) {
@@ -1003,7 +1005,7 @@ __device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const
             uo[j] = gm(P.uit)[idx];
             vv[j] = gm(P.v)[idx];
         });
-        SFOR(j, 0, 4, { if (e0 + 16 * j < N * 4) gm(P.uit)[ibase + e0 + 16 * j] = uo[j] + vv[j]; });
+        SFOR(j, 0, 4, { if (e0 + 16 * j < N * 4) gm(P.uitn)[ibase + e0 + 16 * j] = doit ? uo[j] + vv[j] : uo[j]; });
     }
 }
 
@@ -1038,8 +1040,9 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
 // bytes of the row-distributed sweep -- and with one instance per lane there are no cross-lane
 // reductions at all.  (The interior-point kernel keeps the stored A, B: its sweeps run many times
 // per QP on a compact copy.)
-// P.dx receives the CANDIDATE ITERATE x_k + dx_k (not the step): feasible instances copy it into
-// the iterate in the second loop; the interior-point kernel writes its own steps.
+// The CANDIDATE ITERATE x_k + dx_k, u_k + du_k goes straight into the new iterate buffers (P.xitn,
+// P.uitn): for the ~92 % of the instances whose unconstrained minimiser is feasible that IS the RTI
+// step (the host swaps old and new after the step); the QP kernels overwrite the others.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void k_forward(Params P) {
     // 13-vectors travel through LDS tiles [instance][13] so that every global access of the wave
@@ -1112,6 +1115,7 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
             if (du[a] < lb + margin || du[a] > ub - margin) last_tight = k;
             sawnan = sawnan || !(du[a] == du[a]);
             gm(P.v)[i4b + (size_t)k * 4 + a] = du[a];
+            gm(P.uitn)[i4b + (size_t)k * 4 + a] = cur.u[a] + du[a];
         });
         // next stage's inputs (issued here: the gain of stage k is dead, its registers are free)
         const double uc[4] = {cur.u[0], cur.u[1], cur.u[2], cur.u[3]};
@@ -1165,7 +1169,7 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         {
             double cv[13];
             SFOR(j, 0, 13, { cv[j] = cs[tl + 64 * j]; });
-            SFOR(j, 0, 13, { *el13(P.dx, tl + 64 * j, N + 1, k) = cv[j]; });
+            SFOR(j, 0, 13, { *el13(P.xitn, tl + 64 * j, N + 1, k) = cv[j]; });
         }
         land13(xs, xr);
         __syncthreads();
@@ -1178,13 +1182,12 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
     const bool okf = valid && gm(P.status)[imin(raw, P.B - 1)] == 0;
     const bool bad = valid && (!okf || !(viol == viol));
     const bool infeasible = valid && !bad && (viol > 0.0);
-    const bool commit = valid && !bad && !infeasible;
-    sflag[tid] = commit ? 1 : 0;
+    sflag[tid] = bad ? 1 : 0;
     __syncthreads();
     {
         double cv[13];
         SFOR(j, 0, 13, { cv[j] = cs[tid + 64 * j]; });
-        SFOR(j, 0, 13, { *el13(P.dx, tid + 64 * j, N + 1, N) = cv[j]; });
+        SFOR(j, 0, 13, { *el13(P.xitn, tid + 64 * j, N + 1, N) = cv[j]; });
     }
     if (valid) {
         gm(P.viol)[inst] = infeasible ? viol : 0.0;
@@ -1205,29 +1208,24 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
             if (tid == c) gm(P.blkcnt)[blockIdx.x * BIN_STRIDE + c] = __popcll(m);
         });
     }
-    // instances whose unconstrained minimiser is feasible are done: full RTI step (the others
-    // are committed by k_ipm once their QP is accepted; failed ones keep their iterate).  The
-    // wave copies candidate -> iterate cooperatively, element e belonging to instance e / 13.
-    if (__any(commit)) {
+    // The candidate went straight into the NEW iterate buffers (P.xitn, P.uitn; the host swaps the
+    // buffers after the step), so instances whose unconstrained minimiser is feasible are done.
+    // Constrained ones are overwritten there by the QP kernels (or restored if their QP fails);
+    // the rare failed instance (NaN / failed factorisation) keeps its iterate: copy old -> new.
+    // The wave copies cooperatively, element e belonging to instance e / 13.
+    if (__any(bad)) {
         bool mine[13];
         SFOR(j, 0, 13, { mine[j] = sflag[(tid + 64 * j) / 13] != 0; });
         for (int k0 = 0; k0 <= N; k0 += 2) {
             double c[2][13];
-            SFOR(jj, 0, 2, { SFOR(j, 0, 13, { c[jj][j] = *el13(P.dx, tid + 64 * j, N + 1, imin(k0 + jj, N)); }); });
+            SFOR(jj, 0, 2, { SFOR(j, 0, 13, { c[jj][j] = *el13(P.xit, tid + 64 * j, N + 1, imin(k0 + jj, N)); }); });
             SFOR(jj, 0, 2, {
-                if (k0 + jj <= N) SFOR(j, 0, 13, { if (mine[j]) *el13(P.xit, tid + 64 * j, N + 1, k0 + jj) = c[jj][j]; });
+                if (k0 + jj <= N) SFOR(j, 0, 13, { if (mine[j]) *el13(P.xitn, tid + 64 * j, N + 1, k0 + jj) = c[jj][j]; });
             });
         }
     }
-    if (commit) {
-        for (int k0 = 0; k0 < N; k0 += 4) {
-            double uo[4][4], vv[4][4];
-            SFOR(j, 0, 4, {
-                const size_t idx = i4b + (size_t)imin(k0 + j, N - 1) * 4;
-                SFOR(a, 0, 4, { uo[j][a] = gm(P.uit)[idx + a]; vv[j][a] = gm(P.v)[idx + a]; });
-            });
-            SFOR(j, 0, 4, { if (k0 + j < N) SFOR(a, 0, 4, { gm(P.uit)[i4b + (size_t)(k0 + j) * 4 + a] = uo[j][a] + vv[j][a]; }); });
-        }
+    if (bad) {
+        for (int k = 0; k < N; k++) SFOR(a, 0, 4, { gm(P.uitn)[i4b + (size_t)k * 4 + a] = gm(P.uit)[i4b + (size_t)k * 4 + a]; });
     }
 }
 
@@ -1701,7 +1699,10 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         gm(P.res)[t.inst] = R.res;
         gm(P.head)[t.inst] = head;
     }
-    commit_row(P, t, infeasible && accepted && R.status != 4);
+    {   // MODE 1 leaves the rows it did not finish to the MODE 2 launch (which commits or keeps them)
+        const bool doit = infeasible && accepted && R.status != 4;
+        commit_row(P, t, doit, MODE != 1 && infeasible && !doit);
+    }
 #ifdef CFN_PROF
     PROF_T(7)
     if (threadIdx.x == 0) {

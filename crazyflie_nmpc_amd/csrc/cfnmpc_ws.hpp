@@ -63,6 +63,8 @@ struct Params {
     // persistent iterate (acados nlp_out, acados_mpc.cpp:77) and per-step inputs
     double *xit;     // (N+1) stages x SZ_V13
     double *uit;     // N x SZ_V4
+    double *xitn, *uitn;  // the NEW iterate of the running step (same shapes): every instance's step lands
+                          // here (or its old iterate, if its QP failed); the host swaps old and new afterwards
     double *x0;      // 1 x SZ_V13
     double *yref;    // N x SZ_Y
     double *yref_e;  // 1 x SZ_V13
