@@ -192,7 +192,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(d, NW * 4 * N * 4); ALLOC(Pchk, NW * cfn::N_CHK * cfn::SZ_P);
     ALLOC(v, NW * 4 * N * 4); ALLOC(tl, NW * 4 * N * 4); ALLOC(tu, NW * 4 * N * 4); ALLOC(ll, NW * 4 * N * 4);
     ALLOC(lu, NW * 4 * N * 4); ALLOC(rg, NW * 4 * N * 4); ALLOC(dva, NW * 4 * N * 4); ALLOC(dvc, NW * 4 * N * 4);
-    ALLOC(Rh, NW * 4 * N * 4); ALLOC(g, NW * 4 * N * 4); ALLOC(dx, NW * (N + 1) * cfn::SZ_V13);
+    ALLOC(Rh, NW * 4 * N * 4); ALLOC(g, NW * 4 * N * 4);
     ALLOC(cAR, NW * N * cfn::SZ_A); ALLOC(cBR, NW * N * cfn::SZ_B); ALLOC(cKR, NW * N * cfn::SZ_K);
     ALLOC(cSinv, NW * N * cfn::SZ_S); ALLOC(cd, NW * 4 * N * 4); ALLOC(cPchk, NW * cfn::N_CHK * cfn::SZ_P);
     ALLOC(cv, NW * 4 * N * 4); ALLOC(cuit, NW * 4 * N * 4); ALLOC(cGR, NW * N * cfn::SZ_K);

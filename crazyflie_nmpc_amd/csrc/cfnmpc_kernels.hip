@@ -979,33 +979,21 @@ __global__ __launch_bounds__(64, 2) void k_factor(Params P) {
     if (t.L == 0 && t.valid) gm(P.status)[t.inst] = ok ? 0 : 4;
 }
 
-// full RTI step of one row (acados_solve() epilogue): new iterate = old iterate + accepted step
-// (`doit`), or = old iterate for a row whose QP failed (`keep`); both row-uniform.  The new
-// iterate lives in the buffers the host swaps in after the step.  The step (P.dx, P.v) was written
-// by this very wave, so the reads hit in L2.
-__device__ __forceinline__ void commit_row(const Params& P, const Lane& t, const bool doit, const bool keep) {
-    if (!doit && !keep) return;
+// a row whose QP failed keeps its iterate: old -> new buffers (`keep` is row-uniform; rare)
+__device__ __forceinline__ void keep_row(const Params& P, const Lane& t, const bool keep) {
+    if (!keep) return;
     const int N = P.N;
-    // batches of four (loads first): one memory round trip per batch instead of one per stage
     const int lx = t.q * 13 + imin(t.L, 12);
     for (int k0 = 0; k0 <= N; k0 += 4) {
-        double xo[4], dxk[4];
-        SFOR(j, 0, 4, {
-            const int k = imin(k0 + j, N);
-            xo[j] = blk(P.xit, t, N + 1, k, SZ_V13)[lx];
-            dxk[j] = blk(P.dx, t, N + 1, k, SZ_V13)[lx];
-        });
-        SFOR(j, 0, 4, { if (t.L < 13 && k0 + j <= N) blk(P.xitn, t, N + 1, k0 + j, SZ_V13)[lx] = doit ? xo[j] + dxk[j] : xo[j]; });
+        double xo[4];
+        SFOR(j, 0, 4, { xo[j] = blk(P.xit, t, N + 1, imin(k0 + j, N), SZ_V13)[lx]; });
+        SFOR(j, 0, 4, { if (t.L < 13 && k0 + j <= N) blk(P.xitn, t, N + 1, k0 + j, SZ_V13)[lx] = xo[j]; });
     }
     const size_t ibase = (size_t)t.inst * N * 4;
     for (int e0 = t.L; e0 < N * 4; e0 += 64) {
-        double uo[4], vv[4];
-        SFOR(j, 0, 4, {
-            const size_t idx = ibase + imin(e0 + 16 * j, N * 4 - 1);
-            uo[j] = gm(P.uit)[idx];
-            vv[j] = gm(P.v)[idx];
-        });
-        SFOR(j, 0, 4, { if (e0 + 16 * j < N * 4) gm(P.uitn)[ibase + e0 + 16 * j] = doit ? uo[j] + vv[j] : uo[j]; });
+        double uo[4];
+        SFOR(j, 0, 4, { uo[j] = gm(P.uit)[ibase + imin(e0 + 16 * j, N * 4 - 1)]; });
+        SFOR(j, 0, 4, { if (e0 + 16 * j < N * 4) gm(P.uitn)[ibase + e0 + 16 * j] = uo[j]; });
     }
 }
 
@@ -1636,7 +1624,10 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         //      unconstrained feedback law of the start solve, whose inputs must stay inside the box
         int kviol = -1;  // last tail stage whose feedback input leaves the box
         {
-            double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
+            // the candidate iterate (old + step) goes straight into the new iterate buffers: a row that
+            // is not accepted is overwritten again (retry / interior-point launch) or restored (commit_row)
+            double xbcur = ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t), xbnxt;
+            double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - xbcur;
             FwdIn<true> cur, nxt;
             load_fwd<true>(P, t, 0, cur);
             double vcur = gm(Q.v)[i4(Q, tc, 0, t.L & 3)], ucur = gm(P.uit)[i4(P, t, 0, t.L & 3)], vnxt, unxt;
@@ -1645,7 +1636,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 load_fwd<true>(P, t, kn, nxt);  // prefetch
                 vnxt = gm(Q.v)[i4(Q, tc, imin(kn, head - 1), t.L & 3)];
                 unxt = gm(P.uit)[i4(P, t, kn, t.L & 3)];
-                st13(blk(P.dx, t, N + 1, k, SZ_V13), t, x);
+                xbnxt = ld13(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);
+                st13(blk(P.xitn, t, N + 1, k, SZ_V13), t, xbcur + x);
                 double v;
                 if (k < head) {
                     v = t.L < 4 ? vcur : 0.0;
@@ -1653,16 +1645,17 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                     v = feedback<true>(t, cur, x);
                     if (t.L < 4 && !((v >= P.u_min - ucur) && (v <= P.u_max - ucur))) kviol = k;
                 }
-                // candidate inputs of the whole horizon (P.v keeps the unconstrained ones until accepted)
-                if (t.L < 4) gm(Q.dva)[i4(Q, tc, k, t.L)] = v;
+                // candidate inputs of the whole horizon (P.v keeps the unconstrained minimiser)
+                if (t.L < 4) gm(P.uitn)[i4(P, t, k, t.L)] = ucur + v;
                 double vr[4];
                 SFOR(a, 0, 4, { vr[a] = bc<a>(v); });
                 x = propagate<true>(t, cur, x, vr);
                 cur = nxt;
                 vcur = vnxt;
                 ucur = unxt;
+                xbcur = xbnxt;
             }
-            st13(blk(P.dx, t, N + 1, N, SZ_V13), t, x);
+            st13(blk(P.xitn, t, N + 1, N, SZ_V13), t, xbcur + x);
             kviol = (int)row_max((double)kviol);
         }
         PROF_T(6)
@@ -1684,25 +1677,15 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
     }
     if (MODE == 1 && t.L == 0 && t.valid) gm(P.done)[t.inst] = accepted ? 1 : 0;
-    // accepted: publish the inputs of the whole horizon
-    if (t.valid && accepted) {
-        const size_t pb = (size_t)t.inst * N * 4;
-        for (int e0 = t.L; e0 < N * 4; e0 += 64) {
-            double vv[4];
-            SFOR(j, 0, 4, { vv[j] = gm(Q.dva)[cbase + imin(e0 + 16 * j, N * 4 - 1)]; });
-            SFOR(j, 0, 4, { if (e0 + 16 * j < N * 4) gm(P.v)[pb + e0 + 16 * j] = vv[j]; });
-        }
-    }
     if (t.L == 0 && infeasible && accepted) {
         gm(P.status)[t.inst] = R.status;
         gm(P.iters)[t.inst] = R.iters;
         gm(P.res)[t.inst] = R.res;
         gm(P.head)[t.inst] = head;
     }
-    {   // MODE 1 leaves the rows it did not finish to the MODE 2 launch (which commits or keeps them)
-        const bool doit = infeasible && accepted && R.status != 4;
-        commit_row(P, t, doit, MODE != 1 && infeasible && !doit);
-    }
+    // the roll-out already left the new iterate of an accepted row in place; a row whose QP failed
+    // keeps its old iterate (MODE 1 leaves the rows it did not finish to the MODE 2 launch)
+    keep_row(P, t, MODE != 1 && infeasible && !(accepted && R.status != 4));
 #ifdef CFN_PROF
     PROF_T(7)
     if (threadIdx.x == 0) {

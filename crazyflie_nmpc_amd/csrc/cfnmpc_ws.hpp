@@ -79,7 +79,6 @@ struct Params {
     double *Pchk;     // N_CHK x SZ_P   cost-to-go of the unconstrained tail at the checkpoints
     // interior-point state, N x SZ_V4 each
     double *v, *tl, *tu, *ll, *lu, *rg, *dva, *dvc, *Rh, *g;
-    double *dx;  // (N+1) x SZ_V13: step in x of the accepted QP solution (commit buffer)
     // compact scratch of the interior-point kernel (same block shapes, indexed by compacted slot)
     double *cAR, *cBR, *cKR, *cSinv, *cd, *cPchk, *cv, *cuit;
     // active-set solve, per compact block and stage: G = B'PA in the gain layout (SZ_K), the rows of
