@@ -52,12 +52,26 @@ namespace {
         }                                                                                           \
     } while (0)
 
+// The solver lives on the device that was current at cfnmpc_create; every entry point that touches
+// it makes that device current for the duration of the call (a caller that drives several GPUs
+// from one thread may have another one selected).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const cfnmpc_solver* s) {
+        if (s && hipGetDevice(&prev) == hipSuccess && prev != s->device) switched = hipSetDevice(s->device) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 template <typename T>
 int dev_alloc(cfnmpc_solver* s, T** p, size_t count) {
     void* q = nullptr;
     if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) return CFNMPC_ENOMEM;
+    s->allocs.push_back(q);   // (before the memset: cfnmpc_free releases it on any later failure)
     if (hipMemset(q, 0, count * sizeof(T)) != hipSuccess) return CFNMPC_EHIP;
-    s->allocs.push_back(q);
     s->bytes += count * sizeof(T);
     *p = static_cast<T*>(q);
     return CFNMPC_OK;
@@ -225,6 +239,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
 
 int cfnmpc_free(cfnmpc_solver* s) {
     if (!s) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_aux) (void)hipEventDestroy(s->ev_aux);
@@ -241,11 +256,13 @@ unsigned long long cfnmpc_workspace_bytes(const cfnmpc_solver* s) { return s ? s
 
 int cfnmpc_set_x0(cfnmpc_solver* s, const double* x0, int on_device, void* stream) {
     if (!s || !x0) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     return put_field(s, x0, on_device, 1, 13, 1, s->P.x0, (hipStream_t)stream);
 }
 
 int cfnmpc_set_yref(cfnmpc_solver* s, const double* yref, const double* yref_e, int on_device, void* stream) {
     if (!s || !yref || !yref_e) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     int rc = put_field(s, yref, on_device, s->P.N, 17, 1, s->P.yref, (hipStream_t)stream);
     if (rc != CFNMPC_OK) return rc;
     return put_field(s, yref_e, on_device, 1, 13, 1, s->P.yref_e, (hipStream_t)stream);
@@ -254,6 +271,7 @@ int cfnmpc_set_yref(cfnmpc_solver* s, const double* yref, const double* yref_e, 
 int cfnmpc_set_yref_windows(cfnmpc_solver* s, const double* traj, int n_rows, int* mode, int* iter,
                             const double* des_xyz, double uss, void* stream) {
     if (!s || !mode || !iter || !des_xyz) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     if (n_rows > 0 && (!traj || n_rows < s->P.N + 1)) return CFNMPC_EINVAL;
     if (n_rows <= 0 && traj) return CFNMPC_EINVAL;
     cfn::launch_windows(s->P, traj, n_rows > 0 ? n_rows : 0, mode, iter, des_xyz, uss, (hipStream_t)stream);
@@ -272,6 +290,7 @@ int cfnmpc_set_weights(cfnmpc_solver* s, const double* W, const double* WN) {
 
 int cfnmpc_init_iterate(cfnmpc_solver* s, int mode, void* stream) {
     if (!s || (mode != CFNMPC_INIT_ACADOS && mode != CFNMPC_INIT_HOVER)) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     cfn::launch_init_iterate(s->P, mode, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     s->lin_valid = false;
@@ -280,6 +299,7 @@ int cfnmpc_init_iterate(cfnmpc_solver* s, int mode, void* stream) {
 
 int cfnmpc_set_iterate(cfnmpc_solver* s, const double* x, const double* u, int on_device, void* stream) {
     if (!s || !x || !u) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     s->lin_valid = false;
     int rc = put_field(s, x, on_device, s->P.N + 1, 13, 1, s->P.xit, (hipStream_t)stream);
     if (rc != CFNMPC_OK) return rc;
@@ -288,6 +308,7 @@ int cfnmpc_set_iterate(cfnmpc_solver* s, const double* x, const double* u, int o
 
 int cfnmpc_get_iterate(cfnmpc_solver* s, double* x, double* u, int on_device, void* stream) {
     if (!s || !x || !u) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     int rc = get_field(s, x, on_device, s->P.N + 1, 13, 1, 0, s->P.N + 1, s->P.xit, (hipStream_t)stream);
     if (rc != CFNMPC_OK) return rc;
     return get_field(s, u, on_device, s->P.N, 4, 0, 0, s->P.N, s->P.uit, (hipStream_t)stream);
@@ -295,6 +316,7 @@ int cfnmpc_get_iterate(cfnmpc_solver* s, double* x, double* u, int on_device, vo
 
 int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
     if (!s || n_rti < 1) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     hipStream_t st = (hipStream_t)stream;
     for (int it = 0; it < n_rti; it++) {
         hipEvent_t* e = nullptr;
@@ -350,6 +372,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
 int cfnmpc_step_host(cfnmpc_solver* s, const double* x0, const double* yref, const double* yref_e, double* u,
                      double* x, int* status, int* qp_iter, double* res, void* stream) {
     if (!s || !x0 || !yref || !yref_e) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     hipStream_t st = (hipStream_t)stream;
     const cfn::Params& P = s->P;
     const size_t B = P.B, N = P.N;
@@ -396,16 +419,19 @@ int cfnmpc_step_host(cfnmpc_solver* s, const double* x0, const double* yref, con
 
 int cfnmpc_get_u(cfnmpc_solver* s, int stage, double* u, int on_device, void* stream) {
     if (!s || !u || stage < 0 || stage >= s->P.N) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     return get_field(s, u, on_device, 1, 4, 0, stage, s->P.N, s->P.uit, (hipStream_t)stream);
 }
 
 int cfnmpc_get_x(cfnmpc_solver* s, int stage, double* x, int on_device, void* stream) {
     if (!s || !x || stage < 0 || stage > s->P.N) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     return get_field(s, x, on_device, 1, 13, 1, stage, s->P.N + 1, s->P.xit, (hipStream_t)stream);
 }
 
 int cfnmpc_get_stats(cfnmpc_solver* s, int* status, int* qp_iter, double* res, int on_device, void* stream) {
     if (!s) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     hipStream_t st = (hipStream_t)stream;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     const size_t B = s->P.B;
@@ -464,6 +490,7 @@ int cfnmpc_set_profiling(cfnmpc_solver* s, int enable) {
 
 int cfnmpc_get_profile(cfnmpc_solver* s, double* ms_linearise, double* ms_qp, int* n_steps) {
     if (!s || !ms_linearise || !ms_qp || !n_steps) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     double a = 0.0, b = 0.0;
     const size_t n = s->ev_used / 3;
     for (size_t i = 0; i < n; i++) {
@@ -492,6 +519,7 @@ int cfnmpc_debug_prof(unsigned long long* out, int reset) { (void)hipDeviceSynch
 
 int cfnmpc_debug_linearise(cfnmpc_solver* s, void* stream) {
     if (!s) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     cfn::launch_linearise(s->P, s->chunks_all, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     s->lin_valid = true;
@@ -502,6 +530,7 @@ int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, double* A, double* Bm, doub
     // Decodes the row-distributed stage blocks (AR, BR, b) into dense arrays in the EXTERNAL
     // state order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13].
     if (!s || !A || !Bm || !b) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     const cfn::Params& P = s->P;
     const size_t NW = P.NW, N = P.N, B = P.B;
     std::vector<double> ha(NW * N * cfn::SZ_A), hb(NW * N * cfn::SZ_B), hv(NW * N * cfn::SZ_V13);
@@ -537,6 +566,7 @@ int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, double* A, double* Bm, doub
 
 int cfnmpc_debug_get_head(cfnmpc_solver* s, int* head) {
     if (!s || !head) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(head, s->P.head, (size_t)s->P.B * sizeof(int), hipMemcpyDeviceToHost));
     return CFNMPC_OK;

@@ -66,6 +66,18 @@ struct cfnmpc_fleet {
 };
 
 #define HIP_TRY(x) do { if ((x) != hipSuccess) return CFNMPC_EHIP; } while (0)
+
+// the fleet lives on the device that was current at cfnmpc_fleet_create (as its solvers do)
+struct FleetDevice {
+    int prev = -1;
+    bool switched = false;
+    explicit FleetDevice(const cfnmpc_fleet* f) {
+        if (f && hipGetDevice(&prev) == hipSuccess && prev != f->device) switched = hipSetDevice(f->device) == hipSuccess;
+    }
+    ~FleetDevice() { if (switched) (void)hipSetDevice(prev); }
+    FleetDevice(const FleetDevice&) = delete;
+    FleetDevice& operator=(const FleetDevice&) = delete;
+};
 #define RC_TRY(x) do { int rc_ = (x); if (rc_ != CFNMPC_OK) return rc_; } while (0)
 
 namespace {
@@ -133,6 +145,7 @@ int cfnmpc_fleet_create(cfnmpc_fleet** out, int batch, const int* N_per_instance
 
 int cfnmpc_fleet_free(cfnmpc_fleet* f) {
     if (!f) return CFNMPC_EINVAL;
+    FleetDevice fd(f);
     (void)hipDeviceSynchronize();
     for (Bucket& b : f->bk) {
         if (b.s) cfnmpc_free(b.s);
@@ -175,6 +188,7 @@ static int staging(Bucket& b) {
 
 int cfnmpc_fleet_set_x0(cfnmpc_fleet* f, const double* x0, int on_device, void* stream) {
     if (!f || !x0) return CFNMPC_EINVAL;
+    FleetDevice fd(f);
     if (!on_device) {
         for (Bucket& b : f->bk) RC_TRY(cfnmpc_set_x0(b.s, host_gather(f, b, x0, 13, 13), 0, stream));
         return CFNMPC_OK;
@@ -188,6 +202,7 @@ int cfnmpc_fleet_set_x0(cfnmpc_fleet* f, const double* x0, int on_device, void* 
 
 int cfnmpc_fleet_set_yref(cfnmpc_fleet* f, const double* yref, const double* yref_e, int on_device, void* stream) {
     if (!f || !yref || !yref_e) return CFNMPC_EINVAL;
+    FleetDevice fd(f);
     const long fs = (long)f->Nmax * 17;
     if (!on_device) {
         std::vector<double> ye;
@@ -215,11 +230,13 @@ int cfnmpc_fleet_set_weights(cfnmpc_fleet* f, const double* W, const double* WN)
 
 int cfnmpc_fleet_init_iterate(cfnmpc_fleet* f, int mode, void* stream) {
     if (!f) return CFNMPC_EINVAL;
+    FleetDevice fd(f);
     return on_buckets(f, (hipStream_t)stream, [&](Bucket& b, hipStream_t st) { return cfnmpc_init_iterate(b.s, mode, st); });
 }
 
 int cfnmpc_fleet_solve(cfnmpc_fleet* f, int n_rti, void* stream) {
     if (!f || n_rti < 1) return CFNMPC_EINVAL;
+    FleetDevice fd(f);
     return on_buckets(f, (hipStream_t)stream, [&](Bucket& b, hipStream_t st) { return cfnmpc_solve(b.s, n_rti, st); });
 }
 
@@ -243,16 +260,19 @@ static int fleet_get(cfnmpc_fleet* f, int stage, double* out, int width, int on_
 
 int cfnmpc_fleet_get_u(cfnmpc_fleet* f, int stage, double* u, int on_device, void* stream) {
     if (!f || !u || stage < 0 || stage >= f->Nmin) return CFNMPC_EINVAL;
+    FleetDevice fd(f);
     return fleet_get(f, stage, u, 4, on_device, stream, cfnmpc_get_u);
 }
 
 int cfnmpc_fleet_get_x(cfnmpc_fleet* f, int stage, double* x, int on_device, void* stream) {
     if (!f || !x || stage < 0 || stage > f->Nmin) return CFNMPC_EINVAL;
+    FleetDevice fd(f);
     return fleet_get(f, stage, x, 13, on_device, stream, cfnmpc_get_x);
 }
 
 int cfnmpc_fleet_get_stats(cfnmpc_fleet* f, int* status, int* qp_iter, double* res, int on_device, void* stream) {
     if (!f) return CFNMPC_EINVAL;
+    FleetDevice fd(f);
     if (!on_device) {
         for (Bucket& b : f->bk) {
             f->h_ints.resize((size_t)2 * b.count);

@@ -17,6 +17,8 @@
  *     host); == 0: host memory, copied synchronously;
  *   - every call returns 0 on success, a negative CFNMPC_E* code otherwise; solver *status*
  *     per instance follows acados: 0 success, 2 max. iterations, 4 QP failure.
+ *   - a solver (or fleet) lives on the HIP device that is current when it is created; later calls
+ *     may be made with any device current (they select the solver's device for their duration);
  *   - there is NO CPU fallback: if no HIP device is usable, cfnmpc_create fails.
  */
 #ifndef CFNMPC_H
