@@ -275,16 +275,24 @@ def main():
 
     if rank == 0:
         value = total_inst * args.steps / elapsed
-        ach = alg_bytes_qp(N) * B / (ms_qp_avg * 1e-3)
-        traffic = None
+        # BASELINE.md section 4 / SURVEY.md section 8d: algorithmic bytes of ONE RTI STEP (B_alg per instance x the
+        # instances of one launch) over the duration of the step's kernels, measured with HIP events on
+        # the launch stream (linearisation phase + QP phase); the QP phase is reported beside it
+        ms_step = ms_lin_avg + ms_qp_avg
+        ach = alg_bytes_step(N) * B / (ms_step * 1e-3)
+        ach_qp = alg_bytes_qp(N) * B / (ms_qp_avg * 1e-3)
+        traffic = traffic_qp = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
                 if int(tj.get("batch", -1)) == B:
-                    traffic = tj.get("hbm_bytes_per_launch_k_qp")
+                    traffic_qp = tj.get("hbm_bytes_per_launch_k_qp")
+                    traffic = tj.get("hbm_bytes_per_step")
+                    if traffic is None and traffic_qp is not None:
+                        traffic = traffic_qp + tj["kernels"]["cfn::k_linearise"]["total_bytes"]
             except Exception:
-                traffic = None
+                traffic = traffic_qp = None
         out = {
             "metric": "NMPC RTI steps/sec (batch=65536, N=50, nx=13, nu=4)",
             "value": value, "unit": "RTI steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -299,12 +307,17 @@ def main():
                        "qp": ("primal-dual active-set solves on the Riccati factorisation (exact, KKT-verified; "
                               "Mehrotra interior point, tol 1e-8, as fall-back), ") +
                              ("active-horizon sweeps" if args.active_horizon else "full-horizon sweeps")},
-            "roofline": {"bound": "hbm", "kernel": "QP phase = k_factor + k_forward + k_compact + k_scatter + k_as + k_ipm_rest "
-                                                     "(HIP events on the launch stream, summed over the sub-batch launches)",
+            "roofline": {"bound": "hbm", "kernel": "one RTI step = k_linearise + k_factor + k_forward + k_compact + k_scatter + "
+                                                     "k_as + k_ipm_rest (HIP events on the launch stream around the two "
+                                                     "phases, summed over the sub-batch launches)",
                          "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes_qp(N) * B, "kernel_ms": ms_qp_avg,
-                         "linearise_ms": ms_lin_avg,
+                         "alg_bytes_per_launch": alg_bytes_step(N) * B, "kernel_ms": ms_step,
+                         "linearise_ms": ms_lin_avg, "qp_ms": ms_qp_avg,
+                         "qp_phase": {"kernels": "k_factor + k_forward + k_compact + k_scatter + k_as + k_ipm_rest",
+                                      "alg_bytes_per_launch": alg_bytes_qp(N) * B, "achieved": ach_qp / 1e9,
+                                      "frac": ach_qp / HBM_PEAK, "traffic": traffic_qp},
+                         # the same model against the wall clock of the whole closed loop (plant, I/O kernels included)
                          "step_frac_hbm": alg_bytes_step(N) * value / (world * HBM_PEAK)},
             "qp_stats": {"status_ok_frac": stats[0] / total_inst, "mean_qp_solves": stats[2] / total_inst,
                          "frac_constrained": stats[3] / total_inst, "mean_head_stages": stats[4] / total_inst},

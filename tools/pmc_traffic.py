@@ -36,12 +36,15 @@ def main():
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB); reads = 2 x FETCH_SIZE "
                        "(gfx950 correction, see tools/pmc_traffic.py); average of the last third of the dispatches of "
                        "`python bench.py --steps 6 --warmup 20 --no-cpu-baseline`",
-               "kernels": kernels, "hbm_bytes_per_launch_k_qp": qp}, open(out_json, "w"), indent=1)
+               "kernels": kernels, "hbm_bytes_per_launch_k_qp": qp,
+               "hbm_bytes_per_step": qp + kernels.get("cfn::k_linearise", {}).get("total_bytes", 0.0)},
+              open(out_json, "w"), indent=1)
     with open(out_csv, "w") as f:
         f.write("kernel,read_GB,write_GB,total_GB\n")
         for k, v in kernels.items():
             f.write(f"{k},{v['read_bytes'] / 1e9:.4f},{v['write_bytes'] / 1e9:.4f},{v['total_bytes'] / 1e9:.4f}\n")
         f.write(f"QP phase (factor+forward+compact+scatter+as+ipm_rest | ipm),,,{qp / 1e9:.4f}\n")
+        f.write(f"RTI step (linearise + QP phase),,,{(qp + kernels.get('cfn::k_linearise', {}).get('total_bytes', 0.0)) / 1e9:.4f}\n")
     print(open(out_csv).read())
 
 
