@@ -117,7 +117,7 @@ int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int pe
 
 extern "C" {
 
-const char* cfnmpc_version(void) { return "cfnmpc 0.4 (gfx950; row-group Riccati with fused DPP broadcast FMAs, lane-per-instance linearisation and matrix-free forward sweep)"; }
+const char* cfnmpc_version(void) { return "cfnmpc 0.5 (gfx950; row-group Riccati with fused DPP broadcast FMAs, lane-per-instance linearisation and matrix-free forward sweep, primal-dual active-set QP solves)"; }
 
 void cfnmpc_default_opts(cfnmpc_opts* o) {
     // generate_c_code.py:41-42,63-84,109,133-134
