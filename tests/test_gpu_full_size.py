@@ -24,7 +24,7 @@ def test_full_size_properties_and_spot_parity(oracle, cref):
     x = x0.copy()
     idx = np.random.default_rng(1).choice(B, 192, replace=False)
     xr = np.repeat(x0[idx, None, :], N + 1, 1).copy(); ur = np.full((len(idx), N, 4), HOV)
-    opts = cref.default_opts(tol=1e-8)
+    opts = cref.default_opts(tol=1e-8, active_set=1)   # the engine's default QP method on both sides
     for t in range(3):
         s.set_x0(x); s.solve(1)
         st, it, rs = s.stats()
@@ -38,10 +38,11 @@ def test_full_size_properties_and_spot_parity(oracle, cref):
         # the interior-point method was needed for a sizeable part of the fleet, not for all
         frac = (it > 0).mean()
         assert 0.02 < frac < 0.8, frac
-        # spot parity with the CPU restatement on 192 instances (different central paths at tol 1e-8)
+        # spot parity with the CPU restatement on 192 instances: exact active-set solutions on both
+        # sides (the engine's active horizon only changes how much of the horizon each solve sweeps)
         st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x[idx].copy(), yref[idx].copy(), yref_e[idx].copy(), nthreads=0)
         assert (st_r == 0).all() and ((it[idx] > 0) == (it_r > 0)).all()
-        assert np.abs(ug[idx] - ur).max() < 5e-4 and np.abs(xg[idx] - xr).max() < 5e-4
+        assert np.abs(ug[idx] - ur).max() < 1e-8 and np.abs(xg[idx] - xr).max() < 1e-8
         xr[:] = xg[idx]; ur[:] = ug[idx]
         x = sim(x, ug[:, 0, :].copy(), T=0.015, steps=1)
 
@@ -73,3 +74,36 @@ def test_instances_are_independent_under_permutation(oracle, active_horizon):
     else:
         assert np.abs(u0a[perm] - u0b).max() < 5e-4 and np.abs(x4a[perm] - x4b).max() < 5e-4
         assert ((ita[perm] > 0) == (itb > 0)).all()
+
+
+def test_full_size_mixed_horizon_fleet(oracle):
+    """Config C5 at full size through cfnmpc_fleet_*: 65 536 vehicles with N in {30, 50, 100},
+    device-resident inputs and outputs; three closed-loop steps: every status 0, x0 pinned, every
+    applied input inside the box, buckets = the horizons' index sets."""
+    import torch
+    from crazyflie_nmpc_amd import sim
+    from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(20200105)
+    horizons = rng.choice([30, 50, 100], size=B)
+    fleet = MixedHorizonFleet(horizons)
+    bk = fleet.buckets()
+    assert [n for n, _ in bk] == [30, 50, 100]
+    for n, idx in bk:
+        assert np.array_equal(np.sort(idx), np.nonzero(horizons == n)[0])
+    fleet.set_regulation(np.tile([0.0, 0.0, 0.4], (B, 1)), HOV)
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(oracle.sample_hover_x0(rng, B)).to(dev)
+    xn = torch.empty_like(x)
+    u0 = torch.empty((B, 4), dtype=torch.float64, device=dev); x1 = torch.empty((B, 13), dtype=torch.float64, device=dev)
+    fleet.set_x0(x); fleet.init_iterate(INIT_HOVER)
+    for t in range(3):
+        fleet.set_x0(x); fleet.solve(1); fleet.get_u(0, u0); fleet.get_x(0, x1)
+        torch.cuda.synchronize()
+        st, it, rs = fleet.stats()
+        assert (st == 0).all(), np.bincount(st)
+        assert float((x1 - x).abs().max()) < 1e-14
+        assert float(u0.min()) >= -1e-8 and float(u0.max()) <= 22.0 + 1e-8
+        assert 0.02 < (it > 0).mean() < 0.8
+        sim(x, u0, T=0.015, steps=1, out=xn)
+        x, xn = xn, x
