@@ -33,14 +33,16 @@ def test_sim_and_linearisation_match_golden_model_vectors():
             assert np.abs(b[:, k] - (m["phi"] - m["x"])).max() < 1e-13
 
 
-@pytest.mark.parametrize("tol,bound", [(1e-12, 5e-6), (1e-8, 5e-4)])
-def test_qp_steps_match_golden_exact_solutions(tol, bound):
+@pytest.mark.parametrize("active_set,tol,bound", [(0, 1e-12, 5e-6), (0, 1e-8, 5e-4), (1, 1e-8, 5e-9)])
+def test_qp_steps_match_golden_exact_solutions(active_set, tol, bound):
+    """Interior point: central-path error ~ sqrt(tol); active-set solves (the default): exact, the
+    bound is the accuracy of the committed solutions themselves."""
     from crazyflie_nmpc_amd import BatchSolver, default_opts
     from crazyflie_nmpc_amd.solver import INIT_HOVER
     q = np.load(os.path.join(G, "qp.npz"))
     n, N = q["x0"].shape[0], 50
     for ah in (0, 1):
-        s = BatchSolver(n, default_opts(tol=tol, active_horizon=ah))
+        s = BatchSolver(n, default_opts(tol=tol, active_horizon=ah, active_set=active_set))
         s.set_x0(q["x0"]); s.set_yref(np.tile(q["yref"], (n, 1, 1)), np.tile(q["yref_e"], (n, 1))); s.init_iterate(INIT_HOVER)
         s.solve(1)
         st, it, _ = s.stats()

@@ -122,17 +122,18 @@ def test_closed_loop_rti_matches_oracle(oracle, cref, init, active_horizon, tol,
         assert np.abs(x[:, :3] - np.array([0, 0, 0.4])).max() < 0.25  # and the loop regulates
 
 
-@pytest.mark.parametrize("tol,bound", [(1e-12, 5e-6), (1e-8, 5e-4)])
-def test_qp_solution_matches_dense_oracle(oracle, tol, bound):
+@pytest.mark.parametrize("active_set,tol,bound", [(0, 1e-12, 5e-6), (0, 1e-8, 5e-4), (1, 1e-8, 5e-9)])
+def test_qp_solution_matches_dense_oracle(oracle, active_set, tol, bound):
     """Independent check: the HIP step equals the step of the dense-QP oracle on the QP built by
     the numpy oracle (sympy Jacobians).  An interior-point solution sits on the central path:
     for a (nearly) degenerate bound slack ~ multiplier ~ sqrt(mu), so the primal error is bounded
-    by ~sqrt(tol) -- 1e-6 at tol 1e-12 and 1e-4 at the default 1e-8 (same property as HPIPM)."""
+    by ~sqrt(tol) -- 1e-6 at tol 1e-12 and 1e-4 at the default 1e-8 (same property as HPIPM).  The
+    active-set solves (the engine's default) are exact: they meet the dense oracle at its own accuracy."""
     from crazyflie_nmpc_amd import BatchSolver, default_opts
     from crazyflie_nmpc_amd.solver import INIT_HOVER
     B, N = 64, 50
     x0, yref, yref_e = _problem(oracle, B, seed=99, scale=1.5)
-    s = BatchSolver(B, default_opts(tol=tol))
+    s = BatchSolver(B, default_opts(tol=tol, active_set=active_set))
     s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
     s.solve(1)
     xg, ug = s.get_iterate()
@@ -162,13 +163,13 @@ def test_ragged_batch_and_status(oracle, cref):
     s.solve(1)
     st, it, rs = s.stats()
     assert (st == 0).all() and it.max() <= 30 and np.nanmax(rs) <= 1e-8
-    opts = cref.default_opts()
+    opts = cref.default_opts(active_set=1)
     xr = np.repeat(x0[:, None, :], 51, 1).copy(); ur = np.full((B, 50, 4), HOV)
     cref.rti_step(opts, xr, ur, x0.copy(), yref, yref_e, nthreads=0)
     xg, ug = s.get_iterate()
-    # different central paths (active-horizon vs full-horizon sweeps) at the default tol 1e-8:
-    # agreement is bounded by ~sqrt(tol) for nearly degenerate bounds
-    assert np.abs(ug - ur).max() < 5e-4 and np.abs(xg - xr).max() < 5e-4
+    # exact active-set solutions on both sides (the engine sweeps active horizons, the restatement
+    # the full one: same unique solution)
+    assert np.abs(ug - ur).max() < 1e-8 and np.abs(xg - xr).max() < 1e-8
 
 
 def test_active_set_solves_match_oracle_exactly(oracle):
