@@ -1362,17 +1362,17 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
     const size_t cbase = (size_t)tc.inst * N * 4;  // compact 4-vectors of this row
     auto gather = [&](int hd, int ck) {
-        // two stages per batch, loads first (the source lines are cold: one HBM round trip each)
-        for (int k0 = 0; k0 < hd; k0 += 2) {
-            double ar[2][10], br[2][4], vv[2], uu[2];
-            SFOR(j, 0, 2, {
+        // four stages per batch, loads first (the source lines are cold: one HBM round trip each)
+        for (int k0 = 0; k0 < hd; k0 += 4) {
+            double ar[4][10], br[4][4], vv[4], uu[4];
+            SFOR(j, 0, 4, {
                 const int k = imin(k0 + j, hd - 1);
                 ld_ar(blk(P.AR, t, N, k, SZ_A), t, ar[j]);
                 ld_rows4(blk(P.BR, t, N, k, SZ_B), t, br[j]);
                 vv[j] = gm(P.v)[i4(P, t, k, t.L & 3)];
                 uu[j] = gm(P.uit)[i4(P, t, k, t.L & 3)];
             });
-            SFOR(j, 0, 2, {
+            SFOR(j, 0, 4, {
                 const int k = k0 + j;
                 if (k < hd) {
                     gdouble* ca = blk(Q.AR, tc, N, k, SZ_A);
