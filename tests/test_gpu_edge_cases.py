@@ -191,6 +191,43 @@ def test_mixed_horizon_fleet_config5(oracle, cref):
         assert np.abs(x4[idx] - xr[:, 4]).max() < 1e-7
 
 
+@pytest.mark.parametrize("N", [5, 9, 33])
+@pytest.mark.parametrize("bounds", [(0.0, 22.0), (4.0, 19.0)])
+@pytest.mark.parametrize("active_horizon", [0, 1])
+def test_short_horizons_and_other_boxes_match_restatement(oracle, cref, N, bounds, active_horizon):
+    """Horizons around and below the head classes (the shortest admissible one included) and an
+    input box other than the reference's [0, 22] kRPM, three closed-loop steps with 2x kicks:
+    exact active-set solutions on both sides (1e-7 leaves room for an instance that needs the
+    interior-point fall-back at tol 1e-8)."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER, CfnmpcError
+    B = 41
+    rng = np.random.default_rng(N)
+    x0 = oracle.sample_hover_x0(rng, B, scale=2.0)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    s = BatchSolver(B, default_opts(N=N, u_min=bounds[0], u_max=bounds[1], active_horizon=active_horizon))
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    opts = cref.default_opts(N=N, u_min=bounds[0], u_max=bounds[1], active_set=1)
+    x = x0.copy()
+    constrained = 0
+    for t in range(3):
+        s.set_x0(x); s.solve(1)
+        st, it, _ = s.stats()
+        xg, ug = s.get_iterate()
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        assert (st == 0).all() and (st_r == 0).all()
+        assert ((it > 0) == (it_r > 0)).all()
+        assert ug.min() >= bounds[0] - 1e-8 and ug.max() <= bounds[1] + 1e-8
+        assert np.abs(ug - ur).max() < 1e-7 and np.abs(xg - xr).max() < 1e-7
+        constrained += int((it > 0).sum())
+        x = xg[:, 1, :].copy()
+    assert constrained > 20
+    with pytest.raises(CfnmpcError):
+        BatchSolver(4, default_opts(N=4))       # below the shortest admissible horizon
+
+
 def test_fleet_device_pointers_and_buckets_match_single_horizon_solvers(oracle):
     """cfnmpc_fleet_* with device pointers (row gather / scatter kernels, buckets on forked
     streams) == the host-pointer path == one BatchSolver per horizon fed the bucket's rows, bit
