@@ -47,7 +47,12 @@ def default_opts(N=50, **kw):
     lib().cfo_default_opts(C.byref(o))
     o.N = N
     for k, v in kw.items():
-        setattr(o, k, v)
+        if k in ("W", "WN"):          # array members: element-wise
+            arr = getattr(o, k)
+            for i, x in enumerate(v):
+                arr[i] = float(x)
+        else:
+            setattr(o, k, v)
     return o
 
 

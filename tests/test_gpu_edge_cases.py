@@ -228,6 +228,36 @@ def test_short_horizons_and_other_boxes_match_restatement(oracle, cref, N, bound
         BatchSolver(4, default_opts(N=4))       # below the shortest admissible horizon
 
 
+@pytest.mark.parametrize("N,dt,r_scale", [(25, 0.03, 1.0), (50, 0.0075, 1.0), (50, 0.015, 10.0), (30, 0.025, 0.5)])
+def test_other_intervals_and_weights_match_restatement(oracle, cref, N, dt, r_scale):
+    """Shooting intervals other than the reference's 15 ms and other input weights (both are
+    cfnmpc_opts, i.e. what generate_c_code.py:41-42,63-84 bakes into the reference's solver), a
+    target away from the start, three closed-loop steps with 2x kicks."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B = 37
+    rng = np.random.default_rng(int(1000 * dt) + N)
+    x0 = oracle.sample_hover_x0(rng, B, scale=2.0)
+    yr, ye = oracle.regulation_yref(N, (0.1, -0.2, 0.6))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    d = default_opts()
+    W = np.array(list(d.W)); WN = np.array(list(d.WN))
+    W[13:] *= r_scale
+    s = BatchSolver(B, default_opts(N=N, dt=dt, W=W, WN=WN))
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    opts = cref.default_opts(N=N, dt=dt, W=W, WN=WN, active_set=1)
+    x = x0.copy()
+    for t in range(3):
+        s.set_x0(x); s.solve(1)
+        st, it, _ = s.stats()
+        xg, ug = s.get_iterate()
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        assert (st == 0).all() and (st_r == 0).all() and ((it > 0) == (it_r > 0)).all()   # (active horizon: a tail retry adds solves)
+        assert np.abs(ug - ur).max() < 5e-8 and np.abs(xg - xr).max() < 5e-8
+        x = xg[:, 1, :].copy()
+
+
 def test_fleet_device_pointers_and_buckets_match_single_horizon_solvers(oracle):
     """cfnmpc_fleet_* with device pointers (row gather / scatter kernels, buckets on forked
     streams) == the host-pointer path == one BatchSolver per horizon fed the bucket's rows, bit
