@@ -3,7 +3,7 @@
 // Two mappings, chosen per kernel by what the kernel carries from stage to stage:
 //   * row groups (cfnmpc_ws.hpp): one NMPC instance per 16-lane DPP row, four instances per
 //     wavefront, lane i = row i of every 13-row object -- for the Riccati recursions, which carry
-//     the 13 x 13 cost-to-go (k_factor, k_ipm);
+//     the 13 x 13 cost-to-go (k_factor, k_as, k_ipm_rest);
 //   * lane per instance: 64 instances per wavefront, all model arithmetic in registers, 13-vectors
 //     through LDS tiles -- for the kernels that carry at most a 13-vector (k_linearise, k_forward).
 // One wavefront per workgroup; instances never communicate.
@@ -15,15 +15,17 @@
 //                 over all N stages, next stage software-prefetched (2 waves/SIMD).
 //   k_forward   : start solve, forward, MATRIX-FREE: dx+ = A dx + B du + b is evaluated as the
 //                 directional derivative of the RK4 map (one forward-mode pass) instead of reading
-//                 A and B; unconstrained inputs, feasibility / active-horizon decision, full RTI
-//                 step of the instances whose unconstrained minimiser respects the input box.
+//                 A and B; unconstrained inputs, feasibility / active-horizon decision; the candidate
+//                 is written straight into the second iterate buffer, which IS the full RTI step of
+//                 the instances whose unconstrained minimiser respects the input box (the host
+//                 swaps the two iterate buffers after the step).
 //   k_compact   : list of the instances that need the interior-point method, by head class.
 //   k_scatter   : places every constrained instance in the list.
 //   k_as        : those instances only, on a compact copy of their head stages: primal-dual
-//                 active-set solves (one Riccati factorisation with the active inputs fixed,
-//                 forward sweep, costate sweep with re-classification) until the active set is
-//                 stationary = exact QP solution; expansion, tail verification, full RTI step
-//                 (acados_solve() epilogue, acados_mpc.cpp:611-616).
+//                 active-set solves (one Riccati factorisation with the active inputs fixed and one
+//                 forward sweep that also evaluates the multipliers and re-classifies) until the
+//                 active set is stationary = exact QP solution; roll-out into the second iterate
+//                 buffer with tail verification (acados_solve() epilogue, acados_mpc.cpp:611-616).
 //   k_ipm_rest  : rows k_as left (no stationary set within 12 solves, tail check failed):
 //                 Mehrotra predictor-corrector over stage-wise Riccati sweeps in delta form
 //                 (HPIPM's role, generate_c_code.py:140).  k_ipm = the same without k_as
@@ -1395,7 +1397,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         }
     };
     RowIPM R;
-    bool accepted = MODE != 1;   // MODE 1: only rows finished by the active-set solve publish / commit
+    bool accepted = MODE != 1;   // MODE 1: only rows finished by the active-set solve are final
 
     for (int attempt = 0; attempt < 3; attempt++) {
         R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
@@ -1625,7 +1627,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         int kviol = -1;  // last tail stage whose feedback input leaves the box
         {
             // the candidate iterate (old + step) goes straight into the new iterate buffers: a row that
-            // is not accepted is overwritten again (retry / interior-point launch) or restored (commit_row)
+            // is not accepted is overwritten again (retry / interior-point launch) or restored (keep_row)
             double xbcur = ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t), xbnxt;
             double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - xbcur;
             FwdIn<true> cur, nxt;
