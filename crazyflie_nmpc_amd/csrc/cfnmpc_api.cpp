@@ -213,7 +213,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(cS, NW * N * cfn::SZ_S4); ALLOC(crho, NW * 4 * N * 4);
     ALLOC(cPs, NW * 32 * cfn::SZ_PA);
     ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4); ALLOC(viol, NW * 4);
-    ALLOC(ilist, NW * 4); ALLOC(nipm, 4);
+    ALLOC(ilist, NW * 4); ALLOC(nipm, 64);
     ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * 32); ALLOC(rank, NW * 4); ALLOC(done, NW * 4);
     if (s->overlap) {
         if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->AR2, NW * N * cfn::SZ_A);

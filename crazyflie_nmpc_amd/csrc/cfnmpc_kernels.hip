@@ -1223,51 +1223,48 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
 // class (largest first) so that the four rows of a wave work on similar horizons.  k_forward
 // left per-group class counts and per-instance ranks; k_compact (one block) turns the counts
 // into per-group bases, k_scatter places every instance.
+// k_compact: one workgroup per bin; thread t owns a run of consecutive groups, the workgroup scans
+// its bin's counts over the groups (exclusive prefix, in place) and leaves the bin's total in
+// P.nipm[1 + bin].  k_scatter adds the totals of the preceding bins.
 __global__ __launch_bounds__(256) void k_compact(Params P) {
-    constexpr int NC = N_BIN, NT = 256;
-    __shared__ int cnt[NC][NT];
-    __shared__ int base[NC + 1];
-    const int tid = threadIdx.x;
+    constexpr int NT = 256;
+    __shared__ int cnt[NT];
+    const int tid = threadIdx.x, j = blockIdx.x;
     const int ng = (P.B + 63) / 64;                 // groups of k_forward
     const int chunk = (ng + NT - 1) / NT;
     const int lo = tid * chunk, hi = min(lo + chunk, ng);
-    int c[NC];
-    for (int j = 0; j < NC; j++) c[j] = 0;
-    for (int g = lo; g < hi; g++)
-        for (int j = 0; j < NC; j++) c[j] += gm(P.blkcnt)[g * BIN_STRIDE + j];
-    for (int j = 0; j < NC; j++) cnt[j][tid] = c[j];
+    int c = 0;
+    for (int g = lo; g < hi; g++) c += gm(P.blkcnt)[g * BIN_STRIDE + j];
+    cnt[tid] = c;
     __syncthreads();
-    // inclusive scan over threads, per bin (Hillis-Steele)
-    for (int off = 1; off < NT; off <<= 1) {
-        int v[NC];
-        for (int j = 0; j < NC; j++) v[j] = tid >= off ? cnt[j][tid - off] : 0;
+    for (int off = 1; off < NT; off <<= 1) {        // inclusive scan over threads (Hillis-Steele)
+        const int v = tid >= off ? cnt[tid - off] : 0;
         __syncthreads();
-        for (int j = 0; j < NC; j++) cnt[j][tid] += v[j];
+        cnt[tid] += v;
         __syncthreads();
     }
-    if (tid == 0) {
-        int acc = 0;
-        for (int j = 0; j < NC; j++) { base[j] = acc; acc += cnt[j][NT - 1]; }
-        base[NC] = acc;
-        gm(P.nipm)[0] = acc;
+    if (tid == NT - 1) gm(P.nipm)[1 + j] = cnt[tid];
+    int pos = cnt[tid] - c;
+    for (int g = lo; g < hi; g++) {
+        const int n = gm(P.blkcnt)[g * BIN_STRIDE + j];
+        gm(P.blkcnt)[g * BIN_STRIDE + j] = pos;
+        pos += n;
     }
-    __syncthreads();
-    // counts -> bases, in place
-    int pos[NC];
-    for (int j = 0; j < NC; j++) pos[j] = base[j] + cnt[j][tid] - c[j];
-    for (int g = lo; g < hi; g++)
-        for (int j = 0; j < NC; j++) {
-            const int n = gm(P.blkcnt)[g * BIN_STRIDE + j];
-            gm(P.blkcnt)[g * BIN_STRIDE + j] = pos[j];
-            pos[j] += n;
-        }
 }
 __global__ __launch_bounds__(256) void k_scatter(Params P) {
+    __shared__ int base[N_BIN + 1];
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int j = 0; j < N_BIN; j++) { base[j] = acc; acc += gm(P.nipm)[1 + j]; }
+        base[N_BIN] = acc;
+        if (blockIdx.x == 0) gm(P.nipm)[0] = acc;
+    }
+    __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.B) return;
     if (gm(P.head)[i] > 0) {
         const int r = gm(P.rank)[i];
-        gm(P.ilist)[gm(P.blkcnt)[(i >> 6) * BIN_STRIDE + (r >> 8)] + (r & 255)] = i;
+        gm(P.ilist)[base[r >> 8] + gm(P.blkcnt)[(i >> 6) * BIN_STRIDE + (r >> 8)] + (r & 255)] = i;
     }
 }
 
@@ -1955,7 +1952,7 @@ void launch_linearise_list(const Params& P, int chunks, hipStream_t st) {
 void launch_qp_start(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_compact, dim3(N_BIN), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_scatter, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
 }
 void launch_qp_ipm(const Params& P, hipStream_t st) {

@@ -89,7 +89,7 @@ struct Params {
     int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
     double *res, *viol;          // per instance
     int *ilist;                  // compacted list of the instances that need the interior-point method
-    int *nipm;                   // its length
+    int *nipm;                   // [0] its length, [1 + bin] instances per compaction bin
     int *blkcnt;                 // per 64-instance group of k_forward: instances per compaction bin [group][32]
     int *done;                   // per instance: 1 = finished by the active-set kernel (k_as), 0 = left for k_ipm_rest
     int *rank;                   // per instance: (bin << 8) | rank among the same-bin instances of its group
