@@ -951,19 +951,15 @@ __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, 
         SFOR(c, 0, 4, { xn += cur.br[c] * vr[c]; });
         x = xn;
     };
-    In b0, b1, b2;
+    In b0, b1;
     load(0, b0);
-    load(imin(1, head - 1), b1);
     int k = 0;
     while (k < head) {
-        load(imin(k + 2, head - 1), b2);
+        load(imin(k + 1, head - 1), b1);
         body(b0, k);
         if (++k >= head) break;
-        load(imin(k + 2, head - 1), b0);
+        load(imin(k + 1, head - 1), b0);
         body(b1, k);
-        if (++k >= head) break;
-        load(imin(k + 2, head - 1), b1);
-        body(b2, k);
         ++k;
     }
     return (int)row_max((double)jm);
