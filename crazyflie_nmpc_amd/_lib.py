@@ -12,14 +12,14 @@ LIB_PATH = os.path.join(_HERE, "libcfnmpc.so")
 # every symbol include/cfnmpc.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
     "cfnmpc_default_opts", "cfnmpc_create", "cfnmpc_free", "cfnmpc_batch", "cfnmpc_horizon",
-    "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_set_weights", "cfnmpc_set_yref_windows", "cfnmpc_init_iterate",
+    "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_set_weights", "cfnmpc_set_box", "cfnmpc_get_cmd", "cfnmpc_set_yref_windows", "cfnmpc_init_iterate",
     "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_step_host", "cfnmpc_get_u", "cfnmpc_get_x",
     "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_estimate", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise",
     "cfnmpc_debug_get_head", "cfnmpc_set_profiling", "cfnmpc_get_profile", "cfnmpc_version",
     "cfnmpc_fleet_create", "cfnmpc_fleet_free", "cfnmpc_fleet_batch", "cfnmpc_fleet_min_horizon", "cfnmpc_fleet_max_horizon",
     "cfnmpc_fleet_num_buckets", "cfnmpc_fleet_bucket", "cfnmpc_fleet_workspace_bytes", "cfnmpc_fleet_set_x0",
     "cfnmpc_fleet_set_yref", "cfnmpc_fleet_set_weights", "cfnmpc_fleet_init_iterate", "cfnmpc_fleet_solve",
-    "cfnmpc_fleet_get_u", "cfnmpc_fleet_get_x", "cfnmpc_fleet_get_stats",
+    "cfnmpc_fleet_get_u", "cfnmpc_fleet_get_x", "cfnmpc_fleet_get_stats", "cfnmpc_fleet_set_box", "cfnmpc_fleet_get_cmd",
 ]
 
 
@@ -64,6 +64,8 @@ def lib():
     L.cfnmpc_set_x0.argtypes = [vp, vp, i32, vp]
     L.cfnmpc_set_yref.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_set_weights.argtypes = [vp, vp, vp]
+    L.cfnmpc_set_box.argtypes = [vp, dbl, dbl]
+    L.cfnmpc_get_cmd.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_set_yref_windows.argtypes = [vp, vp, i32, vp, vp, vp, dbl, vp]
     L.cfnmpc_init_iterate.argtypes = [vp, i32, vp]
     L.cfnmpc_set_iterate.argtypes = [vp, vp, vp, i32, vp]
@@ -89,6 +91,8 @@ def lib():
     L.cfnmpc_fleet_set_x0.argtypes = [vp, vp, i32, vp]
     L.cfnmpc_fleet_set_yref.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_fleet_set_weights.argtypes = [vp, vp, vp]
+    L.cfnmpc_fleet_set_box.argtypes = [vp, dbl, dbl]
+    L.cfnmpc_fleet_get_cmd.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_fleet_init_iterate.argtypes = [vp, i32, vp]
     L.cfnmpc_fleet_solve.argtypes = [vp, i32, vp]
     L.cfnmpc_fleet_get_u.argtypes = [vp, i32, vp, i32, vp]

@@ -28,7 +28,7 @@ struct Shim {
     double yref[N * NY], yref_e[NX];
     double W[NY], WN[NX];
     double x[(N + 1) * NX], u[N * NU];  // host copy of the iterate after the last solve
-    double lbu[NU], ubu[NU];
+    double lbu[N][NU], ubu[N][NU];      // per-stage input box as set through "lbu" / "ubu"
     bool weights_dirty = false, box_dirty = false;
     ocp_nlp_in in;
     ocp_nlp_out out;
@@ -88,7 +88,8 @@ int acados_create(void) {
     h->yref_e[2] = 0.5; h->yref_e[3] = 1.0;
     for (int i = 0; i < NY; i++) h->W[i] = h->opts.W[i];
     for (int i = 0; i < NX; i++) h->WN[i] = h->opts.WN[i];
-    for (int i = 0; i < NU; i++) { h->lbu[i] = h->opts.u_min; h->ubu[i] = h->opts.u_max; }
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < NU; i++) { h->lbu[k][i] = h->opts.u_min; h->ubu[k][i] = h->opts.u_max; }
     for (int k = 0; k <= N; k++) { std::memset(h->x + k * NX, 0, sizeof(double) * NX); h->x[k * NX + 3] = 1.0; }
     std::memset(h->u, 0, sizeof h->u);
     h->dims = ocp_nlp_dims{N, NX, NU, NY, NX};
@@ -115,7 +116,9 @@ int acados_free(void) {
 int acados_cfnmpc_init_iterate(int mode) {
     if (!g) return 1;
     if (cfnmpc_set_x0(g->s, g->lbx, 0, nullptr) != CFNMPC_OK) return 1;
-    return cfnmpc_init_iterate(g->s, mode, nullptr) == CFNMPC_OK ? 0 : 1;
+    if (cfnmpc_init_iterate(g->s, mode, nullptr) != CFNMPC_OK) return 1;
+    // ocp_nlp_out_get reads the host copy of the iterate: refresh it
+    return cfnmpc_get_iterate(g->s, g->x, g->u, 0, nullptr) == CFNMPC_OK ? 0 : 1;
 }
 
 int ocp_nlp_constraints_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in*, int stage, const char* field,
@@ -128,12 +131,15 @@ int ocp_nlp_constraints_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in*, i
         return 0;
     }
     if (!std::strcmp(field, "lbu") || !std::strcmp(field, "ubu")) {
+        // stored per stage like acados does; the engine solves with ONE box for all inputs and
+        // stages, so acados_solve() applies the stored boxes if they are uniform and fails (status 1,
+        // nothing solved) if they are not -- e.g. the reference's FIXED_U0 pin of stage 0
+        // (acados_mpc.cpp:605-608, compiled out at :111)
         if (stage < 0 || stage >= N) return 1;
-        // the engine has ONE input box for all stages: accept only a uniform scalar box
-        for (int i = 1; i < NU; i++) if (v[i] != v[0]) return 1;
-        (field[0] == 'l' ? g->lbu : g->ubu)[0] = v[0];
+        for (int i = 0; i < NU; i++) if (!(v[i] == v[i])) return 1;
+        std::memcpy(field[0] == 'l' ? g->lbu[stage] : g->ubu[stage], v, sizeof(double) * NU);
         g->box_dirty = true;
-        return 1;  // reported as unsupported: FIXED_U0 is 0 in the reference (acados_mpc.cpp:111)
+        return 0;
     }
     return 1;
 }
@@ -149,12 +155,15 @@ int ocp_nlp_cost_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in*, int stag
     if (!std::strcmp(field, "W")) {
         // the node writes only the diagonal (acados_mpc.cpp:526-556): element i + i*n is the same
         // in row- and column-major order
+        // (state weights may be 0 -- config/crazyflie_params.cfg ranges start at 0.0 --, input
+        //  weights must be positive; the whole diagonal is checked before anything is copied)
         const int n = stage < N ? NY : NX;
         double* dst = stage < N ? g->W : g->WN;
         for (int i = 0; i < n; i++) {
-            if (!(v[i + i * n] > 0.0)) return 1;
-            dst[i] = v[i + i * n];
+            const double w = v[i + i * n];
+            if (!(i < NX ? w >= 0.0 : w > 0.0)) return 1;
         }
+        for (int i = 0; i < n; i++) dst[i] = v[i + i * n];
         g->weights_dirty = true;
         return 0;
     }
@@ -169,6 +178,14 @@ int acados_solve(void) {
     if (g->weights_dirty) {
         if (cfnmpc_set_weights(g->s, g->W, g->WN) != CFNMPC_OK) return 1;
         g->weights_dirty = false;
+    }
+    if (g->box_dirty) {
+        const double lo = g->lbu[0][0], hi = g->ubu[0][0];
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < NU; i++)
+                if (g->lbu[k][i] != lo || g->ubu[k][i] != hi) return 1;   // per-stage boxes: not supported
+        if (cfnmpc_set_box(g->s, lo, hi) != CFNMPC_OK) return 1;          // (also rejects lo >= hi)
+        g->box_dirty = false;
     }
     int status = 1, iters = 0;
     double res = 0.0;
@@ -193,7 +210,8 @@ int crazyflie_acados_sim_create(void) {
     std::memset(&g_sim_out, 0, sizeof g_sim_out);
     g_sim_in.T = 0.06;  // launch/acados_predictor.launch:62
     g_sim_in.x[3] = 1.0;
-    g_sim_config.ns = 4;
+    g_sim_config.ns = 4;         // stages of the explicit RK scheme (classic RK4)
+    g_sim_config.num_steps = 4;  // integration steps over T (4 x 15 ms for T = 60 ms)
     crazyflie_sim_config = &g_sim_config;
     crazyflie_sim_dims = &g_sim_config;
     crazyflie_sim_in = &g_sim_in;
@@ -227,7 +245,8 @@ int crazyflie_acados_sim_solve(void) {
     if (!g_sim_ready) return 1;
     const auto t0 = std::chrono::steady_clock::now();
     if (!(g_sim_in.T > 0.0)) return 1;
-    const int rc = cfnmpc_sim(1, g_sim_in.x, g_sim_in.u, g_sim_in.T, g_sim_config.ns, g_sim_out.xn, 0, nullptr);
+    if (g_sim_config.ns != 4 || g_sim_config.num_steps < 1) return 1;   // only the 4-stage scheme exists
+    const int rc = cfnmpc_sim(1, g_sim_in.x, g_sim_in.u, g_sim_in.T, g_sim_config.num_steps, g_sim_out.xn, 0, nullptr);
     g_sim_out.total_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return rc == CFNMPC_OK ? 0 : 1;
 }

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <utility>
 #include <vector>
@@ -66,6 +67,8 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the count
+
 template <typename T>
 int dev_alloc(cfnmpc_solver* s, T** p, size_t count) {
     void* q = nullptr;
@@ -113,6 +116,18 @@ int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int pe
     return CFNMPC_OK;
 }
 
+// Q may be positive SEMI-definite (the reference's dynamic_reconfigure ranges start at 0.0,
+// config/crazyflie_params.cfg:19-35): state weights >= 0, input weights > 0 (R must be definite:
+// S = R + B'PB is what the Riccati recursion inverts); no NaN.
+bool weights_ok(const double* W, const double* WN) {
+    if (W) {
+        for (int i = 0; i < 13; i++) if (!(W[i] >= 0.0)) return false;
+        for (int i = 13; i < 17; i++) if (!(W[i] > 0.0)) return false;
+    }
+    if (WN) for (int i = 0; i < 13; i++) if (!(WN[i] >= 0.0)) return false;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -148,6 +163,10 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     if (opts) o = *opts; else cfnmpc_default_opts(&o);
     if (o.N < 5 || o.N > 4096 || !(o.dt > 0) || !(o.u_max > o.u_min) || o.max_iter < 0 ||
         !(o.ah_margin >= 0.0 && o.ah_margin < 0.5) || o.ah_extra < 0) return CFNMPC_EINVAL;
+    // QP parameters that would otherwise only show up as NaN / status 4 at run time
+    if (!(o.tol > 0.0) || !(o.tau > 0.0 && o.tau < 1.0) || !(o.thr0 > 0.0) || !(o.lam0_min > 0.0) ||
+        !(o.mu0_scale >= 0.0)) return CFNMPC_EINVAL;
+    if (!weights_ok(o.W, o.WN)) return CFNMPC_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         std::fprintf(stderr, "cfnmpc: no HIP device available (this library has no CPU path)\n");
@@ -281,11 +300,39 @@ int cfnmpc_set_yref_windows(cfnmpc_solver* s, const double* traj, int n_rows, in
 
 int cfnmpc_set_weights(cfnmpc_solver* s, const double* W, const double* WN) {
     if (!s || (!W && !WN)) return CFNMPC_EINVAL;
-    if (W) for (int i = 0; i < 17; i++) { if (!(W[i] > 0.0)) return CFNMPC_EINVAL; }
-    if (WN) for (int i = 0; i < 13; i++) { if (!(WN[i] > 0.0)) return CFNMPC_EINVAL; }
+    if (!weights_ok(W, WN)) return CFNMPC_EINVAL;   // validated as a whole before anything is copied
     if (W) for (int i = 0; i < 17; i++) s->P.W[i] = W[i];
     if (WN) for (int i = 0; i < 13; i++) s->P.WN[i] = WN[i];
     return CFNMPC_OK;  // kernel arguments: take effect at the next cfnmpc_solve
+}
+
+int cfnmpc_set_box(cfnmpc_solver* s, double u_min, double u_max) {
+    if (!s || !(u_max > u_min)) return CFNMPC_EINVAL;
+    s->P.u_min = u_min;   // kernel arguments: take effect at the next cfnmpc_solve
+    s->P.u_max = u_max;
+    return CFNMPC_OK;
+}
+
+int cfnmpc_get_cmd(cfnmpc_solver* s, double* cmd_vel, int* motvel, int on_device, void* stream) {
+    if (!s || !cmd_vel) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B = s->P.B;
+    if (on_device) {
+        cfn::launch_postproc(s->P, cmd_vel, motvel, st);
+        HIP_TRY(hipGetLastError());
+        return CFNMPC_OK;
+    }
+    // host pointers: through the staging buffer ([B][4] doubles, then [B][4] ints)
+    if (B * 6 > s->stage_doubles) return CFNMPC_EINVAL;
+    double* dc = s->stage_buf;
+    int* dm = (int*)(s->stage_buf + B * 4);
+    cfn::launch_postproc(s->P, dc, dm, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(cmd_vel, dc, B * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (motvel) HIP_TRY(hipMemcpyAsync(motvel, dm, B * 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CFNMPC_OK;
 }
 
 int cfnmpc_init_iterate(cfnmpc_solver* s, int mode, void* stream) {
@@ -320,7 +367,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     for (int it = 0; it < n_rti; it++) {
         hipEvent_t* e = nullptr;
-        if (s->profiling) {
+        if (s->profiling && s->ev_used < 3 * MAX_PROFILED_STEPS) {   // bounded: later steps go untimed
             while (s->ev.size() < s->ev_used + 3) {
                 hipEvent_t ne;
                 HIP_TRY(hipEventCreate(&ne));
@@ -451,25 +498,30 @@ int cfnmpc_sim(int batch, const double* x, const double* u, double T, int steps,
         HIP_TRY(hipGetLastError());
         return CFNMPC_OK;
     }
-    double *dx = nullptr, *du = nullptr, *dn = nullptr;
-    const size_t B = batch;
-    if (hipMalloc((void**)&dx, B * 13 * 8) != hipSuccess || hipMalloc((void**)&du, B * 4 * 8) != hipSuccess ||
-        hipMalloc((void**)&dn, B * 13 * 8) != hipSuccess) {
-        (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dn);
-        return CFNMPC_ENOMEM;
+    // host pointers: device scratch cached per device and grown on demand (the estimator calls this
+    // at 66 Hz with batch 1, acados_estimator.cpp:589 -- no allocation per call); one caller at a time
+    static std::mutex mtx;
+    static double* scratch[64] = {nullptr};
+    static size_t cap[64] = {0};
+    std::lock_guard<std::mutex> lock(mtx);
+    int devi = 0;
+    HIP_TRY(hipGetDevice(&devi));
+    if (devi < 0 || devi >= 64) return CFNMPC_EHIP;
+    const size_t B = batch, need = B * 30;
+    if (cap[devi] < need) {
+        if (scratch[devi]) (void)hipFree(scratch[devi]);
+        scratch[devi] = nullptr; cap[devi] = 0;
+        if (hipMalloc((void**)&scratch[devi], need * 8) != hipSuccess) return CFNMPC_ENOMEM;
+        cap[devi] = need;
     }
-    int rc = CFNMPC_OK;
-    if (hipMemcpyAsync(dx, x, B * 13 * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(du, u, B * 4 * 8, hipMemcpyHostToDevice, st) != hipSuccess)
-        rc = CFNMPC_EHIP;
-    if (rc == CFNMPC_OK) {
-        cfn::launch_sim(batch, dx, du, T, steps, dn, st);
-        if (hipMemcpyAsync(xn, dn, B * 13 * 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess)
-            rc = CFNMPC_EHIP;
-    }
-    (void)hipFree(dx); (void)hipFree(du); (void)hipFree(dn);
-    return rc;
+    double *dx = scratch[devi], *du = dx + B * 13, *dn = du + B * 4;
+    HIP_TRY(hipMemcpyAsync(dx, x, B * 13 * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(du, u, B * 4 * 8, hipMemcpyHostToDevice, st));
+    cfn::launch_sim(batch, dx, du, T, steps, dn, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(xn, dn, B * 13 * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CFNMPC_OK;
 }
 
 int cfnmpc_estimate(int batch, const double* meas, double* filt, const double* u, double dt, int use_lpf, double delay,

@@ -228,6 +228,12 @@ int cfnmpc_fleet_set_weights(cfnmpc_fleet* f, const double* W, const double* WN)
     return CFNMPC_OK;
 }
 
+int cfnmpc_fleet_set_box(cfnmpc_fleet* f, double u_min, double u_max) {
+    if (!f || !(u_max > u_min)) return CFNMPC_EINVAL;
+    for (Bucket& b : f->bk) RC_TRY(cfnmpc_set_box(b.s, u_min, u_max));
+    return CFNMPC_OK;
+}
+
 int cfnmpc_fleet_init_iterate(cfnmpc_fleet* f, int mode, void* stream) {
     if (!f) return CFNMPC_EINVAL;
     FleetDevice fd(f);
@@ -268,6 +274,31 @@ int cfnmpc_fleet_get_x(cfnmpc_fleet* f, int stage, double* x, int on_device, voi
     if (!f || !x || stage < 0 || stage > f->Nmin) return CFNMPC_EINVAL;
     FleetDevice fd(f);
     return fleet_get(f, stage, x, 13, on_device, stream, cfnmpc_get_x);
+}
+
+int cfnmpc_fleet_get_cmd(cfnmpc_fleet* f, double* cmd_vel, int* motvel, int on_device, void* stream) {
+    if (!f || !cmd_vel || f->Nmin < 4) return CFNMPC_EINVAL;   // the output stage reads u1 and x4
+    FleetDevice fd(f);
+    if (!on_device) {
+        for (Bucket& b : f->bk) {
+            f->h_rows.resize((size_t)b.count * 4);
+            f->h_ints.resize((size_t)b.count * 4);
+            RC_TRY(cfnmpc_get_cmd(b.s, f->h_rows.data(), motvel ? f->h_ints.data() : nullptr, 0, stream));
+            for (int r = 0; r < b.count; r++) {
+                std::copy_n(f->h_rows.data() + (size_t)r * 4, 4, cmd_vel + (long)b.idx[r] * 4);
+                if (motvel) std::copy_n(f->h_ints.data() + (size_t)r * 4, 4, motvel + (long)b.idx[r] * 4);
+            }
+        }
+        return CFNMPC_OK;
+    }
+    return on_buckets(f, (hipStream_t)stream, [&](Bucket& b, hipStream_t st) {
+        RC_TRY(staging(b));
+        int* mv = (int*)(b.d_rows + (size_t)b.count * 4);
+        RC_TRY(cfnmpc_get_cmd(b.s, b.d_rows, motvel ? mv : nullptr, 1, st));
+        rows<double, false>(b.d_rows, cmd_vel, b.d_idx, b.count, 4, 4, st);
+        if (motvel) rows<int, false>(mv, motvel, b.d_idx, b.count, 4, 4, st);
+        return (int)CFNMPC_OK;
+    });
 }
 
 int cfnmpc_fleet_get_stats(cfnmpc_fleet* f, int* status, int* qp_iter, double* res, int on_device, void* stream) {

@@ -1891,7 +1891,9 @@ __global__ void k_windows(Params P, const double* __restrict__ traj, int n_rows,
     const int k = (int)(idx % (P.N + 1));
     const int i = (int)(idx / (P.N + 1));
     if (i >= P.B) return;
-    const int m = mode[i];
+    // without a usable trajectory (n_rows < N + 1, traj may be NULL) Tracking / Position_Hold
+    // instances are served as Regulation around des_xyz instead of dereferencing traj
+    const int m = n_rows >= P.N + 1 ? mode[i] : 0;
     double row[17];
     bool write = true;
     if (m == 1) {
@@ -1918,8 +1920,45 @@ __global__ void k_windows(Params P, const double* __restrict__ traj, int n_rows,
 }
 __global__ void k_windows_advance(int B, int N, int n_rows, int* __restrict__ mode, int* __restrict__ iter) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B || mode[i] != 1) return;
+    if (i >= B || mode[i] != 1 || n_rows < N + 1) return;
     if (iter[i] < n_rows - N) iter[i] += 1; else mode[i] = 2;
+}
+
+// Output stage of the reference node for a fleet (NMPC::iteration, acados_mpc.cpp:619-670), one
+// vehicle per lane, straight from the iterate:
+//   motvel [B][4] (int32)  = u0 truncated toward zero -- the int32 fields of PropellerSpeedsStamped
+//                            (msg/PropellerSpeedsStamped.msg:2-5; assignment at acados_mpc.cpp:637-640)
+//   cmd_vel [B][4]         = { pitch [deg] = +deg(theta), roll [deg] = -deg(phi), thrust [PWM] =
+//                            (int)((mean(u1) * 1000 - 4070.3) / 0.2685), yaw rate [deg/s] = deg(x4.wz) }
+//                            with (phi, theta) from the NORMALISED quaternion of x4 (:645-668; Euler
+//                            formulas :384-404, PWM map :421-425, pi as defined at :106)
+// u0 / u1 = inputs of stages 0 / 1, x4 = state of stage 4 (60 ms delay compensation, :624).
+__global__ void k_postproc(Params P, double* __restrict__ cmd_vel, int* __restrict__ motvel) {
+#pragma clang fp contract(off)   // the PWM value is truncated to int: keep the reference's rounding sequence
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.B) return;
+    const double pi = 3.14159265358979323846;
+    const double* u0 = P.uit + blk_index(i, 0, 0, P.N, 4);
+    const double* u1 = P.uit + blk_index(i, 1, 0, P.N, 4);
+    const double* x4 = P.xit + blk_index(i, 4, 0, P.N + 1, 13);
+    double qw = x4[int_of(3)], qx = x4[int_of(4)], qy = x4[int_of(5)], qz = x4[int_of(6)];
+    const double nrm = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    qw /= nrm; qx /= nrm; qy /= nrm; qz /= nrm;
+    const double R31 = 2 * (qx * qz + qw * qy);
+    const double R32 = 2 * (qy * qz - qw * qx);
+    const double R33 = 2 * (qw * qw + qz * qz) - 1;
+    const double phi = atan2(R32, R33), theta = -asin(R31);
+    const double mean1 = (u1[0] + u1[1] + u1[2] + u1[3]) / 4;
+    const int pwm = (int)(((mean1 * 1000) - 4070.3) / 0.2685);
+    double* c = cmd_vel + (size_t)i * 4;
+    c[0] = theta * 180.0 / pi;
+    c[1] = -1.0 * (phi * 180.0 / pi);
+    c[2] = (double)pwm;
+    c[3] = x4[int_of(12)] * 180.0 / pi;
+    if (motvel) {
+        int* mv = motvel + (size_t)i * 4;
+        for (int a = 0; a < 4; a++) mv[a] = (int)u0[a];
+    }
 }
 
 __global__ void k_init_iterate(Params P, int mode) {
@@ -1986,6 +2025,9 @@ void launch_windows(const Params& P, const double* traj, int n_rows, int* mode, 
     const size_t n = (size_t)P.B * (P.N + 1);
     hipLaunchKernelGGL(k_windows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P, traj, n_rows, mode, iter, des, uss);
     hipLaunchKernelGGL(k_windows_advance, dim3((P.B + 255) / 256), dim3(256), 0, st, P.B, P.N, n_rows, mode, iter);
+}
+void launch_postproc(const Params& P, double* cmd_vel, int* motvel, hipStream_t st) {
+    hipLaunchKernelGGL(k_postproc, dim3((P.B + 255) / 256), dim3(256), 0, st, P, cmd_vel, motvel);
 }
 void launch_init_iterate(const Params& P, int mode, hipStream_t st) {
     hipLaunchKernelGGL(k_init_iterate, dim3((P.B + 255) / 256), dim3(256), 0, st, P, mode);

@@ -123,6 +123,9 @@ class BatchSolver:
         _check(self._L.cfnmpc_set_weights(self._h, None if w is None else w.ctypes.data_as(C.c_void_p),
                                           None if wn is None else wn.ctypes.data_as(C.c_void_p)), "cfnmpc_set_weights")
 
+    def set_box(self, u_min, u_max):
+        _check(self._L.cfnmpc_set_box(self._h, float(u_min), float(u_max)), "cfnmpc_set_box")
+
     def init_iterate(self, mode=INIT_ACADOS, stream=None):
         _check(self._L.cfnmpc_init_iterate(self._h, mode, C.c_void_p(stream or 0)), "cfnmpc_init_iterate")
 
@@ -181,6 +184,24 @@ class BatchSolver:
         p, dev, st, _k = _arg(out, (self.B, NX))
         _check(self._L.cfnmpc_get_x(self._h, int(stage), p, dev, st), "cfnmpc_get_x")
         return out
+
+    def get_cmd(self, cmd_vel=None, motvel=None):
+        """Output stage of the reference node for the fleet on the device (cfnmpc_get_cmd):
+        -> (cmd_vel [B][4] float64 = pitch deg, -roll deg, thrust PWM, yaw rate deg/s; motvel [B][4] int32).
+        numpy arrays (host) or torch device tensors."""
+        if cmd_vel is None:
+            cmd_vel = np.empty((self.B, 4))
+        if motvel is None:
+            if _is_torch(cmd_vel):
+                import torch
+                motvel = torch.empty((self.B, 4), dtype=torch.int32, device=cmd_vel.device)
+            else:
+                motvel = np.empty((self.B, 4), dtype=np.int32)
+        p, dev, st, _k = _arg(cmd_vel, (self.B, 4))
+        pm, devm, _s, _k2 = _arg(motvel, (self.B, 4), dtype=np.int32)
+        assert dev == devm
+        _check(self._L.cfnmpc_get_cmd(self._h, p, pm, dev, st), "cfnmpc_get_cmd")
+        return cmd_vel, motvel
 
     def stats(self):
         st = np.empty(self.B, dtype=np.int32); it = np.empty(self.B, dtype=np.int32); rs = np.empty(self.B)

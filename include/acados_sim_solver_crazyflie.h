@@ -14,7 +14,9 @@
 extern "C" {
 #endif
 
-typedef struct sim_config { int ns; } sim_config;
+/* ns = stages of the explicit Runge-Kutta scheme (4: classic RK4, the only one offered);
+ * num_steps = integration steps over T (default 4, i.e. 15 ms steps for T = 60 ms) */
+typedef struct sim_config { int ns; int num_steps; } sim_config;
 typedef struct sim_in { double T; double x[13]; double u[4]; } sim_in;
 typedef struct sim_out { double xn[13]; double total_time; } sim_out;
 

@@ -55,10 +55,14 @@ int acados_free(void);
 
 /* ---- setters (copy-in), acados_mpc.cpp:581-582, 590-594, 599-601, 606-607
  *   constraints: stage 0 "lbx"/"ubx" (13 doubles; the solver pins x0 = lbx and requires
- *                ubx == lbx at solve time), "lbu"/"ubu" (4 doubles, any stage: sets the global
- *                input box when all stages agree -- per-stage boxes are not supported: returns 1)
+ *                ubx == lbx at solve time), "lbu"/"ubu" (4 doubles, stage 0..N-1): stored per stage
+ *                and returns 0; the engine solves with ONE box for all inputs and stages, so the
+ *                next acados_solve() applies the stored values if they are uniform and otherwise
+ *                returns 1 without solving (the reference's FIXED_U0 pin of stage 0,
+ *                acados_mpc.cpp:605-608, is compiled out at :111)
  *   cost:        "yref" (17 doubles for stage < N, 13 for stage N); "W" (17x17 resp. 13x13,
- *                diagonal read from either major order; applies to every stage) */
+ *                diagonal read from either major order; applies to every stage; state weights
+ *                >= 0, input weights > 0, checked as a whole before anything is stored) */
 int ocp_nlp_constraints_model_set(ocp_nlp_config *config, ocp_nlp_dims *dims, ocp_nlp_in *in, int stage,
                                   const char *field, void *value);
 int ocp_nlp_cost_model_set(ocp_nlp_config *config, ocp_nlp_dims *dims, ocp_nlp_in *in, int stage,

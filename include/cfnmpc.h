@@ -112,10 +112,15 @@ int cfnmpc_set_yref_windows(cfnmpc_solver *s, const double *traj, int n_rows, in
                             const double *des_xyz, double uss, void *stream);
 /* ocp_nlp_cost_model_set(.., k, "W", ..) equivalent (acados_mpc.cpp:596-602, compiled out by
  * SET_WEIGHTS 0 in the reference): diagonal stage / terminal weights for ALL instances and
- * stages; either pointer may be NULL (unchanged).  Entries must be > 0. */
+ * stages; either pointer may be NULL (unchanged).  State weights must be >= 0 (the reference's
+ * dynamic_reconfigure ranges start at 0.0, config/crazyflie_params.cfg), input weights > 0; the
+ * arrays are validated as a whole before anything is changed. */
 int cfnmpc_set_weights(cfnmpc_solver *s, const double *W /*[17]*/, const double *WN /*[13]*/);
-/* ocp_nlp_constraints_model_set(.., 0, "lbu"/"ubu", ..) is NOT offered per stage: the box is
- * the global [u_min, u_max] of cfnmpc_opts (FIXED_U0 is 0 in the reference, acados_mpc.cpp:111). */
+/* ocp_nlp_constraints_model_set(.., k, "lbu"/"ubu", ..) equivalent (acados_mpc.cpp:605-608, compiled
+ * out by FIXED_U0 0 at :111) for the case the engine supports: ONE input box [u_min, u_max] for all
+ * inputs, stages and instances (generate_c_code.py:133-134).  Takes effect at the next
+ * cfnmpc_solve.  Per-stage boxes are not offered. */
+int cfnmpc_set_box(cfnmpc_solver *s, double u_min, double u_max);
 
 /* Iterate (the persistent nlp_out of acados_mpc.cpp:77): initial guess, save / restore. */
 int cfnmpc_init_iterate(cfnmpc_solver *s, int mode, void *stream);
@@ -143,10 +148,22 @@ int cfnmpc_get_x(cfnmpc_solver *s, int stage, double *x /*[B][13]*/, int on_devi
  * (max-norm residual of the last QP).  Any pointer may be NULL. */
 int cfnmpc_get_stats(cfnmpc_solver *s, int *status /*[B]*/, int *qp_iter /*[B]*/, double *res /*[B]*/, int on_device, void *stream);
 
+/* Output stage of the reference node for the whole fleet, on the device (NMPC::iteration,
+ * acados_mpc.cpp:619-670): from the current iterate (u0 = inputs of stage 0, u1 = stage 1, x4 =
+ * state of stage 4) it forms what the node publishes per vehicle,
+ *   motvel  [B][4] int32 : u0 truncated toward zero -- /crazyflie/acados_motvel, the int32 fields of
+ *                          PropellerSpeedsStamped (msg/PropellerSpeedsStamped.msg:2-5, :637-640);
+ *   cmd_vel [B][4] double: linear.x = pitch [deg] = +deg(theta), linear.y = roll [deg] = -deg(phi),
+ *                          linear.z = thrust PWM = (int)((mean(u1)*1000 - 4070.3)/0.2685) (:421-425),
+ *                          angular.z = yaw rate [deg/s] = deg(x4.wz); (phi, theta) from the normalised
+ *                          quaternion of x4 with the node's formulas (:384-404, :645-668).
+ * motvel may be NULL.  on_device as everywhere. */
+int cfnmpc_get_cmd(cfnmpc_solver *s, double *cmd_vel /*[B][4]*/, int *motvel /*[B][4]*/, int on_device, void *stream);
+
 /* Per-phase timing (the role of nlp_out->total_time, acados_mpc.cpp:616): when enabled,
  * cfnmpc_solve brackets its two phases (linearisation, QP) with HIP events on the launch stream;
  * cfnmpc_get_profile waits for them and returns the average durations [ms] over the RTI steps
- * since the last call, then resets.  With overlap_linearise the linearisation figure is the
+ * since the last call (at most 4096 steps are timed between two calls), then resets.  With overlap_linearise the linearisation figure is the
  * time it ADDS to the step (the part not hidden behind the interior-point kernel). */
 int cfnmpc_set_profiling(cfnmpc_solver *s, int enable);
 int cfnmpc_get_profile(cfnmpc_solver *s, double *ms_linearise, double *ms_qp, int *n_steps);
@@ -198,10 +215,12 @@ unsigned long long cfnmpc_fleet_workspace_bytes(const cfnmpc_fleet *f);
 int cfnmpc_fleet_set_x0(cfnmpc_fleet *f, const double *x0, int on_device, void *stream);
 int cfnmpc_fleet_set_yref(cfnmpc_fleet *f, const double *yref, const double *yref_e, int on_device, void *stream);
 int cfnmpc_fleet_set_weights(cfnmpc_fleet *f, const double *W /*[17]*/, const double *WN /*[13]*/);
+int cfnmpc_fleet_set_box(cfnmpc_fleet *f, double u_min, double u_max);
 int cfnmpc_fleet_init_iterate(cfnmpc_fleet *f, int mode, void *stream);
 int cfnmpc_fleet_solve(cfnmpc_fleet *f, int n_rti, void *stream);
 int cfnmpc_fleet_get_u(cfnmpc_fleet *f, int stage, double *u /*[B][4]*/, int on_device, void *stream);
 int cfnmpc_fleet_get_x(cfnmpc_fleet *f, int stage, double *x /*[B][13]*/, int on_device, void *stream);
+int cfnmpc_fleet_get_cmd(cfnmpc_fleet *f, double *cmd_vel /*[B][4]*/, int *motvel /*[B][4]*/, int on_device, void *stream);
 int cfnmpc_fleet_get_stats(cfnmpc_fleet *f, int *status, int *qp_iter, double *res, int on_device, void *stream);
 
 const char *cfnmpc_version(void);

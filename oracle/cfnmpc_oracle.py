@@ -595,6 +595,64 @@ def sample_hover_x0(rng, n, center=(0.0, 0.0, 0.4), scale=1.0):
     return np.concatenate([pos, quat, vel, rate], axis=1)
 
 
+
+# ----------------------------------------------------------------------------------------
+# figure-8 reference of config C4 and the node's output stage
+# ----------------------------------------------------------------------------------------
+def poly_piece_eval(table, t):
+    """Position (x, y, z) of the piecewise 7th-order trajectory at time t: the piece is found by
+    cumulative duration (crazyflie_demo/scripts/uav_trajectory.py:97-105), each axis evaluated by
+    Horner's rule on ascending-power coefficients (:15-20).  table rows: [duration, x^0..x^7,
+    y^0..y^7, z^0..z^7, yaw^0..yaw^7] (crazyflie_demo/scripts/figure8.csv)."""
+    t0 = 0.0
+    for row in table:
+        if t < t0 + row[0]:
+            break
+        t0 += row[0]
+    else:                       # t == total duration: end of the last piece
+        t0 -= row[0]
+    tt = t - t0
+    out = np.zeros(3)
+    for ax in range(3):
+        c = row[1 + 8 * ax: 9 + 8 * ax]
+        acc = 0.0
+        for i in range(8):
+            acc = acc * tt + c[7 - i]
+        out[ax] = acc
+    return out
+
+
+def figure8_rows(table, z0=0.5, N=N_DEFAULT, uss=15.7777):
+    """17-column kinematic NMPC reference synthesised from the polynomial table in the style of
+    crazyflie_controller/traj/helix_traj.txt: one row per 15 ms, identity attitude,
+    zero velocities, the files' hover speed 15.7777 (helix_traj.txt:1), N + 1 copies of the last
+    sample appended for the Tracking window logic (acados_mpc.cpp:460-486)."""
+    total = float(np.sum(table[:, 0]))
+    n = int(np.floor(total / DT)) + 1
+    rows = np.zeros((n + N + 1, NY))
+    for k in range(n):
+        rows[k, 0:3] = poly_piece_eval(table, min(DT * k, total))
+    rows[n:, 0:3] = rows[n - 1, 0:3]
+    rows[:, 2] += z0
+    rows[:, 3] = 1.0
+    rows[:, 13:17] = uss
+    return rows
+
+
+def node_outputs(u0, u1, x4):
+    """What NMPC::iteration publishes (acados_mpc.cpp:628-670): motvel = u0 truncated to int32
+    (msg/PropellerSpeedsStamped.msg:2-5), cmd_vel = [pitch deg, -roll deg, thrust PWM, yaw rate
+    deg/s] from the normalised quaternion of x4 (:384-404), mean(u1) (:421-425) and x4.wz."""
+    pi = 3.14159265358979323846       # acados_mpc.cpp:106
+    q = np.asarray(x4[3:7], dtype=np.float64)
+    q = q / np.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    w, x, y, z = q
+    phi = np.arctan2(2 * (y * z - w * x), 2 * (w * w + z * z) - 1)
+    theta = -np.arcsin(2 * (x * z + w * y))
+    pwm = int((((u1[0] + u1[1] + u1[2] + u1[3]) / 4 * 1000) - 4070.3) / 0.2685)
+    cmd = np.array([1.0 * (theta * 180.0 / pi), -1.0 * (phi * 180.0 / pi), float(pwm), x4[12] * 180.0 / pi])
+    return np.array([int(v) for v in u0], dtype=np.int32), cmd
+
 # ----------------------------------------------------------------------------------------
 # estimator: state assembly + delay compensation (acados_estimator.cpp:327-368, 414-440, 521-634)
 # ----------------------------------------------------------------------------------------

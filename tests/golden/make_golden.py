@@ -10,6 +10,12 @@
   closed_loop.npz   u0/u1/x4 sequences of closed-loop runs (regulation, smooth_step and helix
                     tracking) with exact QP solutions at every step
   postproc.npz      quaternion -> Euler / kRPM -> PWM vectors of the node's output stage
+  figure8.npz       (`python make_golden.py fig8`) config C4: positions of the figure-8 sampled every
+                    15 ms BY THE REFERENCE'S OWN EVALUATOR (crazyflie_demo/scripts/uav_trajectory.py,
+                    imported here from /root/reference), the 17-column reference synthesised from
+                    them, and a 40-step closed loop tracking it with exact QP solutions
+                    (x, u0, u1, x4, the node's cmd_vel / motvel); plus cmd_vel / motvel of the three
+                    older closed loops
 
 The oracle is the numpy/sympy restatement oracle/cfnmpc_oracle.py (parity with acados itself is
 UNPINNED: see its header)."""
@@ -27,7 +33,45 @@ import cfnmpc_oracle as o  # noqa: E402
 REF = "/root/reference"
 
 
+def gen_figure8():
+    """Config C4 fixtures (separate file and seed: the older fixtures stay byte-identical)."""
+    sys.path.insert(0, os.path.join(REF, "crazyflie_demo/scripts"))
+    import uav_trajectory                      # the REFERENCE's evaluator, run in place
+    tr = uav_trajectory.Trajectory()
+    tr.loadcsv(os.path.join(REF, "crazyflie_demo/scripts/figure8.csv"))
+    n = int(np.floor(tr.duration / 0.015)) + 1
+    pos = np.array([tr.eval(0.015 * k).pos for k in range(n)])   # 0.015 (n - 1) < duration
+    table = np.loadtxt(os.path.join(REF, "crazyflie_demo/scripts/figure8.csv"), delimiter=",", skiprows=1, usecols=range(33))
+    N = 50
+    ref = o.figure8_rows(table, z0=0.5, N=N)
+    assert ref.shape[0] == n + N + 1 and np.abs(ref[:n, :2] - pos[:, :2]).max() < 1e-14 and np.abs(ref[:n, 2] - 0.5 - pos[:, 2]).max() < 1e-14
+    rng = np.random.default_rng(20200104)
+    it0 = 137
+    x0 = ref[it0, :13].copy()
+    x0 += 0.3 * (o.sample_hover_x0(rng, 1, center=(0, 0, 0))[0] - np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0]))
+    x0[3:7] /= np.linalg.norm(x0[3:7])
+    s = o.RTISolver(init="hover", qp_solver="dense")
+    x = x0.copy()
+    XS, U0, U1, X4, CMD, MV = [], [], [], [], [], []
+    for t in range(40):
+        yref, yref_e = o.tracking_yref(ref, it0 + t, N)
+        r = s.step(x, yref, yref_e)
+        mv, cmd = o.node_outputs(r["u0"], r["u1"], r["x4"])
+        XS.append(x.copy()); U0.append(r["u0"]); U1.append(r["u1"]); X4.append(r["x4"]); CMD.append(cmd); MV.append(mv)
+        x = o.rk4(x, r["u0"])
+    out = dict(pos=pos, ref=ref, iter0=it0, f8_x=np.array(XS), f8_u0=np.array(U0), f8_u1=np.array(U1), f8_x4=np.array(X4),
+               f8_cmd=np.array(CMD), f8_motvel=np.array(MV))
+    c = np.load(os.path.join(HERE, "closed_loop.npz"))
+    for key in ("reg", "ss", "hx"):
+        both = [o.node_outputs(a, b, d) for a, b, d in zip(c[key + "_u0"], c[key + "_u1"], c[key + "_x4"])]
+        out[key + "_motvel"] = np.array([m for m, _ in both]); out[key + "_cmd"] = np.array([cc for _, cc in both])
+    np.savez_compressed(os.path.join(HERE, "figure8.npz"), **out)
+    print("figure8.npz written:", {k: np.asarray(v).shape for k, v in out.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "fig8":
+        return gen_figure8()
     rng = np.random.default_rng(20200101)
     # ---- reference data files
     smooth = np.loadtxt(os.path.join(REF, "crazyflie_controller/traj/smooth_step.txt"))

@@ -1,4 +1,4 @@
-// cf_nmpc_node.hpp -- ROS-free host-side mirror of the reference NMPC node
+// cf_nmpc_node.hpp -- TEST HARNESS (not part of the product package): ROS-free host-side mirror of the reference NMPC node
 // (crazyflie_controller/src/acados_mpc.cpp, class NMPC :115-719) on top of the acados-named
 // C-ABI of include/acados_solver_crazyflie.h.  Same member / method names and per-step protocol
 // as the reference; ROS messages are replaced by plain structs with the message layouts
@@ -12,12 +12,12 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
-#include <fstream>
-#include <sstream>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
-#include "../../include/acados_solver_crazyflie.h"
+#include "../../include/acados_solver_crazyflie.h"   // the drop-in header under test
 
 namespace cf {
 
@@ -51,13 +51,14 @@ public:
     };
 
     float uss, Ct, mq;  // float as in the reference (acados_mpc.cpp:189)
+    double uss_row;     // value written into the hold rows: uss unless the harness overrides it (App. B2)
     double x0_sign[NX], yref_sign[(NY * N) + NY];
     double xq_des, yq_des, zq_des;
     solver_input acados_in;
     solver_output acados_out;
     int acados_status;
     reference_mode policy;
-    std::vector<std::vector<double>> precomputed_traj;
+    std::vector<double> precomputed_traj;   // [N_STEPS][NY], row-major (the node keeps a vector of rows)
     int N_STEPS, iter;
     PropellerSpeeds last_motvel;  // what would go to /crazyflie/acados_motvel
     Twist last_cmd_vel;           // what would go to /crazyflie/cmd_vel
@@ -70,7 +71,8 @@ public:
         mq = 33e-3f;
         Ct = 3.25e-4f;
         uss = std::sqrt((mq * g0) / (4 * Ct));
-        N_STEPS = ref_traj.empty() ? 0 : readDataFromFile(ref_traj.c_str(), precomputed_traj);
+        uss_row = uss;
+        N_STEPS = ref_traj.empty() ? 0 : load_reference(ref_traj.c_str(), precomputed_traj);
         xq_des = 0; yq_des = 0; zq_des = 0.40;  // App. B4
         iter = 0;
         policy = Regulation;
@@ -84,35 +86,40 @@ public:
         if (enable_regulation) { xq_des = x; yq_des = y; zq_des = z; policy = Regulation; }
     }
 
-    // acados_mpc.cpp:354-382
-    static int readDataFromFile(const char* fileName, std::vector<std::vector<double>>& data) {
-        std::ifstream file(fileName);
-        std::string line;
-        int num_of_steps = 0;
-        if (!file.is_open()) return 0;
-        while (getline(file, line)) {
-            ++num_of_steps;
-            std::istringstream linestream(line);
-            std::vector<double> linedata;
-            double number;
-            while (linestream >> number) linedata.push_back(number);
-            data.push_back(linedata);
+    // Trajectory file of the Tracking policy: one reference row of NY whitespace-separated numbers
+    // per line, one line per sampling period; the row count is the line count (loader semantics of
+    // acados_mpc.cpp:354-382).  Rows land back to back in `rows`; short lines are zero-padded.
+    static int load_reference(const char* path, std::vector<double>& rows) {
+        std::FILE* f = std::fopen(path, "r");
+        if (!f) return 0;
+        int n_lines = 0;
+        char buf[4096];
+        while (std::fgets(buf, sizeof buf, f)) {
+            rows.resize((size_t)(n_lines + 1) * NY, 0.0);
+            char* cur = buf;
+            for (int j = 0; j < NY; j++) {
+                char* end = nullptr;
+                const double v = std::strtod(cur, &end);
+                if (end == cur) break;
+                rows[(size_t)n_lines * NY + j] = v;
+                cur = end;
+            }
+            n_lines++;
         }
-        return num_of_steps;
+        std::fclose(f);
+        return n_lines;
     }
 
-    // acados_mpc.cpp:384-404
-    static euler quatern2euler(double w, double x, double y, double z) {
-        const double R11 = 2 * (w * w + x * x) - 1;
-        const double R21 = 2 * (x * y - w * z);
-        const double R31 = 2 * (x * z + w * y);
-        const double R32 = 2 * (y * z - w * x);
-        const double R33 = 2 * (w * w + z * z) - 1;
-        euler angle;
-        angle.phi = std::atan2(R32, R33);
-        angle.theta = -std::asin(R31);
-        angle.psi = std::atan2(R21, R11);
-        return angle;
+    // Roll / pitch / heading of a unit quaternion (w x y z) in the node's convention
+    // (acados_mpc.cpp:384-404): roll and pitch from the third row of the rotation matrix, heading
+    // from its first column.
+    static euler attitude(const double (&q)[4]) {
+        const double ww = q[0] * q[0];
+        euler e;
+        e.phi = std::atan2(2 * (q[2] * q[3] - q[0] * q[1]), 2 * (ww + q[3] * q[3]) - 1);
+        e.theta = -std::asin(2 * (q[1] * q[3] + q[0] * q[2]));
+        e.psi = std::atan2(2 * (q[1] * q[2] - q[0] * q[3]), 2 * (ww + q[1] * q[1]) - 1);
+        return e;
     }
     static double rad2Deg(double rad) { return rad * 180.0 / pi; }
     // acados_mpc.cpp:421-425 (truncation to int is the wire unit, App. B8)
@@ -129,7 +136,7 @@ public:
             case Tracking:
                 if (iter < N_STEPS - N) {
                     for (int k = 0; k < N + 1; k++)
-                        for (int j = 0; j < NY; j++) yref_sign[k * NY + j] = precomputed_traj[iter + k][j];
+                        for (int j = 0; j < NY; j++) yref_sign[k * NY + j] = row(iter + k)[j];
                     ++iter;
                 } else {
                     policy = Position_Hold;  // the reference keeps the previous window for this step (:486)
@@ -137,8 +144,7 @@ public:
                 break;
             case Position_Hold:
                 for (int k = 0; k < N + 1; k++)
-                    fill_hold_row(k, precomputed_traj[N_STEPS - 1][xq], precomputed_traj[N_STEPS - 1][yq],
-                                  precomputed_traj[N_STEPS - 1][zq]);
+                    fill_hold_row(k, row(N_STEPS - 1)[xq], row(N_STEPS - 1)[yq], row(N_STEPS - 1)[zq]);
                 break;
         }
         // --- read estimate (:560-578)
@@ -170,7 +176,7 @@ public:
         double qn[4] = {acados_out.x4[qw], acados_out.x4[qx], acados_out.x4[qy], acados_out.x4[qz]};
         const double nrm = std::sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
         for (double& c : qn) c /= nrm;
-        const euler eu = quatern2euler(qn[0], qn[1], qn[2], qn[3]);
+        const euler eu = attitude(qn);
         last_cmd_vel.linear_x = 1.0 * rad2Deg(eu.theta);
         last_cmd_vel.linear_y = -1.0 * rad2Deg(eu.phi);
         last_cmd_vel.linear_z = krpm2pwm((acados_out.u1[w1] + acados_out.u1[w2] + acados_out.u1[w3] + acados_out.u1[w4]) / 4);
@@ -179,12 +185,13 @@ public:
     }
 
 private:
+    const double* row(int r) const { return precomputed_traj.data() + (size_t)r * NY; }
     // one row of the Regulation / Position_Hold windows (acados_mpc.cpp:438-454, 497-513)
     void fill_hold_row(int k, double x, double y, double z) {
         double* r = yref_sign + k * NY;
         r[0] = x; r[1] = y; r[2] = z; r[3] = 1.00;
         for (int j = 4; j < 13; j++) r[j] = 0.00;
-        for (int j = 13; j < 17; j++) r[j] = uss;
+        for (int j = 13; j < 17; j++) r[j] = uss_row;
     }
 };
 

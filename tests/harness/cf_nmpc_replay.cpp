@@ -1,10 +1,11 @@
-// cf_nmpc_replay.cpp -- ROS-free closed-loop replay of the reference node's per-step protocol
+// cf_nmpc_replay.cpp -- TEST HARNESS: ROS-free closed-loop replay of the reference node's per-step protocol
 // through the acados-named drop-in (libacados_solver_crazyflie.so).  It plays the part of
 // crazyflie_controller/src/acados_mpc.cpp's main(): it DEFINES the acados globals the
 // generated solver expects from its caller (acados_mpc.cpp:76-84) and drives NMPC::iteration().
 // The plant is the model itself, integrated by the sim solver (crazyflie_acados_sim_solve).
 //
-// usage: cf_nmpc_replay <regulation|tracking> <traj.txt|-> <steps> <x0.txt> <init 0|1> <out.csv>
+// usage: cf_nmpc_replay <regulation|tracking> <traj.txt|-> <steps> <x0.txt> <init 0|1> <out.csv> [uss]
+//   uss: steady-state propeller speed of the hold rows (default: the node's own float value)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,7 @@ int main(int argc, char** argv) {
     if (!out) return 2;
 
     cf::NMPC nmpc(traj);
+    if (argc > 7) nmpc.uss_row = std::atof(argv[7]);
     if (nlp_out == nullptr || nlp_dims == nullptr || nlp_dims->N != cf::N) {
         std::fprintf(stderr, "acados_create() did not populate the caller's globals\n");
         return 3;
@@ -76,7 +78,7 @@ int main(int argc, char** argv) {
         sim_in_set(crazyflie_sim_config, crazyflie_sim_dims, crazyflie_sim_in, "T", &Ts);
         sim_in_set(crazyflie_sim_config, crazyflie_sim_dims, crazyflie_sim_in, "x", x);
         sim_in_set(crazyflie_sim_config, crazyflie_sim_dims, crazyflie_sim_in, "u", nmpc.acados_out.u0);
-        crazyflie_sim_config->ns = 1;
+        crazyflie_sim_config->num_steps = 1;
         if (crazyflie_acados_sim_solve()) return 4;
         sim_out_get(crazyflie_sim_config, crazyflie_sim_dims, crazyflie_sim_out, "xn", x);
     }

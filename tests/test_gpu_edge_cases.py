@@ -381,3 +381,127 @@ def test_step_host_equals_separate_calls(oracle):
         assert np.array_equal(ua, ub) and np.array_equal(xa, xb)
         assert np.array_equal(sa, sb) and np.array_equal(ia, ib) and np.array_equal(ra, rb)
         x = xa[:, 1].copy()
+
+
+def test_acados_shim_setters_box_weights_and_predictor(oracle, cref):
+    """The acados-named drop-in through ctypes: "lbu"/"ubu" are stored per stage and applied when
+    uniform (cfnmpc_set_box underneath), rejected at acados_solve() when stages differ (the
+    reference's FIXED_U0 pin, acados_mpc.cpp:605-608, compiled out at :111); "W" accepts zero state
+    weights (config/crazyflie_params.cfg ranges) and rejects a non-positive input weight without
+    storing anything; the predictor integrates num_steps RK4 steps over T."""
+    import ctypes as C
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from crazyflie_nmpc_amd import _lib
+    _lib.lib()                                        # torch / HIP runtime first (see _lib.lib)
+    L = C.CDLL(os.path.join(root, "crazyflie_nmpc_amd", "libacados_solver_crazyflie.so"))
+    vp = C.c_void_p
+
+    def dbl(a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return a, a.ctypes.data_as(vp)
+
+    assert L.acados_create() == 0
+    try:
+        N = 50
+        rng = np.random.default_rng(3)
+        x0 = oracle.sample_hover_x0(rng, 1, scale=2.0)[0]      # saturating start
+        yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+        xk, px = dbl(x0)
+        for f in (b"lbx", b"ubx"):
+            assert L.ocp_nlp_constraints_model_set(None, None, None, 0, f, px) == 0
+        for k in range(N):
+            r, pr = dbl(yr[k])
+            assert L.ocp_nlp_cost_model_set(None, None, None, k, b"yref", pr) == 0
+        r, pr = dbl(ye)
+        assert L.ocp_nlp_cost_model_set(None, None, None, N, b"yref", pr) == 0
+        assert L.acados_cfnmpc_init_iterate(1) == 0
+        u = np.empty(4); xg = np.empty(13)
+        L.ocp_nlp_out_get(None, None, None, 0, b"u", u.ctypes.data_as(vp))
+        L.ocp_nlp_out_get(None, None, None, 7, b"x", xg.ctypes.data_as(vp))
+        assert np.allclose(u, HOV) and np.array_equal(xg, x0)   # host copy of the iterate refreshed by init
+        # a tighter uniform box on every stage: applied
+        lo, plo = dbl(np.full(4, 2.0)); hi, phi = dbl(np.full(4, 20.0))
+        for k in range(N):
+            assert L.ocp_nlp_constraints_model_set(None, None, None, k, b"lbu", plo) == 0
+            assert L.ocp_nlp_constraints_model_set(None, None, None, k, b"ubu", phi) == 0
+        assert L.acados_solve() == 0
+        U = np.empty((N, 4))
+        for k in range(N):
+            L.ocp_nlp_out_get(None, None, None, k, b"u", U[k].ctypes.data_as(vp))
+        assert U.min() >= 2.0 - 1e-8 and U.max() <= 20.0 + 1e-8 and (np.abs(U - 20.0) < 1e-8).any()
+        opts = cref.default_opts(u_min=2.0, u_max=20.0, active_set=1)
+        xr = np.repeat(x0[None, None, :], N + 1, 1).copy(); ur = np.full((1, N, 4), HOV)
+        st_r, _, _, _ = cref.rti_step(opts, xr, ur, x0[None].copy(), yr[None].copy(), ye[None].copy(), nthreads=1)
+        assert st_r[0] == 0 and np.abs(U - ur[0]).max() < 1e-8
+        # the reference's FIXED_U0 pattern: stage 0 pinned -> per-stage box -> solve refuses
+        pin, ppin = dbl(U[1])
+        assert L.ocp_nlp_constraints_model_set(None, None, None, 0, b"lbu", ppin) == 0
+        assert L.ocp_nlp_constraints_model_set(None, None, None, 0, b"ubu", ppin) == 0
+        assert L.acados_solve() == 1
+        assert L.ocp_nlp_constraints_model_set(None, None, None, 0, b"lbu", plo) == 0
+        assert L.ocp_nlp_constraints_model_set(None, None, None, 0, b"ubu", phi) == 0
+        assert L.acados_solve() == 0
+        assert L.ocp_nlp_constraints_model_set(None, None, None, N, b"lbu", plo) == 1     # no stage N inputs
+        # weights: PSD Q accepted, non-positive R rejected as a whole
+        W = np.diag(np.r_[120.0, 100.0, 100.0, 0.0, 0.0, 0.0, 0.0, 0.7, 1.0, 4.0, 1e-5, 1e-5, 10.0, 0.06, 0.06, 0.06, 0.06])
+        Wc, pW = dbl(W)
+        assert L.ocp_nlp_cost_model_set(None, None, None, 0, b"W", pW) == 0
+        assert L.acados_solve() == 0
+        Wbad = W.copy(); Wbad[0, 0] = 7.0; Wbad[15, 15] = 0.0
+        Wb, pWb = dbl(Wbad)
+        assert L.ocp_nlp_cost_model_set(None, None, None, 0, b"W", pWb) == 1
+        # predictor: T = 60 ms in num_steps RK4 steps (default 4), acados_estimator.cpp:573-593
+        assert L.crazyflie_acados_sim_create() == 0
+
+        class SimCfg(C.Structure):
+            _fields_ = [("ns", C.c_int), ("num_steps", C.c_int)]
+        cfg = C.POINTER(SimCfg).in_dll(L, "crazyflie_sim_config")
+        sin = vp.in_dll(L, "crazyflie_sim_in"); sout = vp.in_dll(L, "crazyflie_sim_out")
+        assert cfg.contents.ns == 4 and cfg.contents.num_steps == 4
+        T, pT = dbl([0.06]); uu, pu = dbl(rng.uniform(5, 20, 4))
+        for f, p in ((b"T", pT), (b"x", px), (b"u", pu)):
+            assert L.sim_in_set(None, None, sin, f, p) == 0
+        xn = np.empty(13)
+        for steps in (4, 1):
+            cfg.contents.num_steps = steps
+            assert L.crazyflie_acados_sim_solve() == 0
+            assert L.sim_out_get(None, None, sout, b"xn", xn.ctypes.data_as(vp)) == 0
+            assert np.abs(xn - cref.sim(x0[None].copy(), uu[None].copy(), 0.06, steps)[0]).max() < 1e-13
+        L.crazyflie_acados_sim_free()
+    finally:
+        L.acados_free()
+
+
+def test_create_rejects_bad_options_and_windows_without_trajectory(oracle):
+    """cfnmpc_create validates the QP options (no NaN / status 4 at run time); device reference
+    windows with n_rows = 0 serve Tracking / Position_Hold instances as Regulation instead of
+    dereferencing a NULL trajectory."""
+    import torch
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import CfnmpcError, INIT_HOVER
+    for kw in (dict(tol=0.0), dict(tau=1.0), dict(tau=0.0), dict(thr0=0.0), dict(lam0_min=-1.0), dict(mu0_scale=-0.1),
+               dict(W=[1.0] * 13 + [0.0] * 4), dict(W=[-1.0] + [1.0] * 16), dict(WN=[float("nan")] + [1.0] * 12)):
+        with pytest.raises(CfnmpcError):
+            BatchSolver(4, default_opts(**kw))
+    s = BatchSolver(5, default_opts(W=[0.0] * 3 + [1e-3] * 4 + [1.0] * 6 + [0.06] * 4))   # PSD Q is fine
+    with pytest.raises(CfnmpcError):
+        s.set_box(3.0, 3.0)
+    dev = torch.device("cuda", 0)
+    B = 5
+    mode = torch.tensor([0, 1, 2, 1, 0], dtype=torch.int32, device=dev)
+    it = torch.zeros(B, dtype=torch.int32, device=dev)
+    des = torch.from_numpy(np.tile([0.1, -0.2, 0.5], (B, 1))).to(dev)
+    s2 = BatchSolver(B)
+    x0 = oracle.sample_hover_x0(np.random.default_rng(1), B)
+    s2.set_x0(x0); s2.init_iterate(INIT_HOVER)
+    s2.set_yref_windows(None, mode, it, des, HOV)
+    s2.solve(1)
+    torch.cuda.synchronize()
+    assert (s2.stats()[0] == 0).all()
+    assert mode.cpu().tolist() == [0, 1, 2, 1, 0] and it.cpu().tolist() == [0] * B
+    ref = BatchSolver(B)
+    yr, ye = oracle.regulation_yref(50, (0.1, -0.2, 0.5))
+    ref.set_x0(x0); ref.init_iterate(INIT_HOVER); ref.set_yref(np.tile(yr, (B, 1, 1)), np.tile(ye, (B, 1)))
+    ref.solve(1)
+    assert np.array_equal(ref.get_u(0), s2.get_u(0))

@@ -8,17 +8,18 @@ HOV = 15.777730167256925
 B, N = 65536, 50
 
 
-def _fleet(oracle, seed=20200103, scale=1.0):
+def _fleet(oracle, seed=20200103, scale=1.0, B=B):
     rng = np.random.default_rng(seed)
     x0 = oracle.sample_hover_x0(rng, B, scale=scale)
     yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
     return x0, np.repeat(yr[None], B, 0).copy(), np.repeat(ye[None], B, 0).copy()
 
 
-def test_full_size_properties_and_spot_parity(oracle, cref):
+@pytest.mark.parametrize("B", [4096, 65536])   # BASELINE.json configs C2 and C3
+def test_full_size_properties_and_spot_parity(oracle, cref, B):
     from crazyflie_nmpc_amd import BatchSolver, sim
     from crazyflie_nmpc_amd.solver import INIT_HOVER
-    x0, yref, yref_e = _fleet(oracle)
+    x0, yref, yref_e = _fleet(oracle, B=B)
     s = BatchSolver(B)
     s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
     x = x0.copy()
@@ -107,3 +108,53 @@ def test_full_size_mixed_horizon_fleet(oracle):
         assert 0.02 < (it > 0).mean() < 0.8
         sim(x, u0, T=0.015, steps=1, out=xn)
         x, xn = xn, x
+
+
+def test_full_size_figure8_tracking_config4(oracle, cref):
+    """Config C4 at full size: 65 536 vehicles tracking the figure-8 reference (figure8.npz['ref'],
+    whose positions come from the reference's own evaluator) with per-vehicle phase offsets, reference
+    windows generated ON THE DEVICE (cfnmpc_set_yref_windows = NMPC::iteration's Tracking policy,
+    acados_mpc.cpp:460-486).  Three closed-loop steps: every status 0, x0 pinned, inputs inside the
+    box; 192 vehicles are re-solved by the CPU restatement with host-built windows (rows
+    iter..iter+N) and must agree to 1e-8."""
+    import os
+    import torch
+    from crazyflie_nmpc_amd import BatchSolver, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ref = np.load(os.path.join(G, "figure8.npz"))["ref"]
+    rng = np.random.default_rng(20200104)            # SURVEY 8d: seed = 20200101 + config index
+    it0 = rng.integers(0, 436, B).astype(np.int32)
+    hover = np.array([0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0])
+    x = ref[it0, :13] + 0.3 * (oracle.sample_hover_x0(rng, B, center=(0, 0, 0)) - hover)
+    x[:, 3:7] /= np.linalg.norm(x[:, 3:7], axis=1, keepdims=True)
+    dev = torch.device("cuda", 0)
+    trj = torch.from_numpy(ref.copy()).to(dev)
+    mode = torch.ones(B, dtype=torch.int32, device=dev)
+    it = torch.from_numpy(it0.copy()).to(dev)
+    des = torch.zeros((B, 3), dtype=torch.float64, device=dev)
+    s = BatchSolver(B)
+    s.set_x0(x); s.init_iterate(INIT_HOVER)
+    idx = np.random.default_rng(2).choice(B, 192, replace=False)
+    xr = np.repeat(x[idx, None, :], N + 1, 1).copy(); ur = np.full((len(idx), N, 4), HOV)
+    opts = cref.default_opts(tol=1e-8, active_set=1)
+    n_constrained = 0
+    for t in range(3):
+        s.set_yref_windows(trj, mode, it, des, 15.7777)
+        s.set_x0(x); s.solve(1)
+        torch.cuda.synchronize()
+        assert np.array_equal(it.cpu().numpy(), it0 + t + 1) and (mode.cpu().numpy() == 1).all()
+        st, itq, rs = s.stats()
+        xg, ug = s.get_iterate()
+        assert (st == 0).all(), np.bincount(st)
+        assert np.abs(xg[:, 0, :] - x).max() < 1e-14
+        assert ug.min() >= -1e-8 and ug.max() <= 22.0 + 1e-8
+        n_constrained += int((itq > 0).sum())
+        yref = np.stack([ref[i + t:i + t + N] for i in it0[idx]])
+        yref_e = np.stack([ref[i + t + N, :13] for i in it0[idx]])
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x[idx].copy(), yref.copy(), yref_e.copy(), nthreads=0)
+        assert (st_r == 0).all() and ((itq[idx] > 0) == (it_r > 0)).all()
+        assert np.abs(ug[idx] - ur).max() < 1e-8 and np.abs(xg[idx] - xr).max() < 1e-8
+        xr[:] = xg[idx]; ur[:] = ug[idx]
+        x = sim(x, ug[:, 0, :].copy(), T=0.015, steps=1)
+    assert n_constrained > 0          # the tracking fleet does exercise the constrained QP path
