@@ -4,29 +4,38 @@
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
 under torch.distributed.run (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json metric: "NMPC RTI steps/sec (batch=65536, N=50, nx=13, nu=4)";
-SURVEY.md section 8d configs C2/C3): per GPU a synthetic fleet of 65536 Crazyflie hover-regulation
+Workload (BASELINE.json metric: "NMPC RTI steps/sec (batch=65536, N=50, nx=13, nu=4) at 1/2/4/8
+MI355X"): a synthetic fleet of 65 536 Crazyflie hover-regulation
 problems, horizon N = 50, run CLOSED LOOP through the RK4 plant (device-resident):
-    step = { x0 <- plant state ; acados_solve() equivalent: linearise + Riccati-IPM QP + update ;
+    step = { x0 <- plant state ; acados_solve() equivalent: linearise + QP + full step ;
              u0 -> plant RK4 step ; 1/20 of the fleet is kicked to a fresh random perturbed state }
 The staggered kicks make every step statistically identical to the time average of SURVEY's
-"20 RTI steps closed loop from a perturbed hover" (so the timed region never degenerates into
-the converged, bound-free regime).  Instances are independent: the batch shards across GPUs
-with no data-path collective ("scaling": "weak" -- 65536 instances per GPU); RCCL is used only
-to aggregate the report (max time, statistics).
+"20 RTI steps closed loop from a perturbed hover" (the timed region never degenerates into the
+converged, bound-free regime).  Instances are independent: the fleet shards across GPUs with no
+data-path collective; RCCL only aggregates the report (max time, statistics).
 
-Also reported on the same line:
-  roofline     -- dominant kernel (k_qp): algorithmic bytes per launch / HIP-event duration vs
-                  8 TB/s (DESIGN.md section 6);
-  cpu_baseline -- the plain-C CPU restatement of the same algorithm (oracle/cfnmpc_ref.c,
-                  "port": acados itself cannot be built here) timed on this host's cores on a
-                  bounded sample of the same workload.
+Scaling: the metric's batch is 65 536 IN TOTAL, so for N > 1 the default is `--scaling strong`
+(65 536 instances split into contiguous shards, 65 536 / N per GPU; `value` = that run) and the
+weak-scaling figure (65 536 per GPU) is measured right after it and reported beside it under
+`weak_scaling`.  `--scaling weak` makes the weak run the timed one.
+
+Also on the same line (rank 0, N = 1):
+  roofline     -- one RTI step's algorithmic bytes / the duration of its kernels, measured with HIP
+                  events on the launch stream over the SAME K timed steps (DESIGN.md section 6);
+  cpu_baseline -- BASELINE.md section 3: the plain-C CPU restatement of the same algorithm
+                  (oracle/cfnmpc_ref.c, "port": acados itself cannot be built here) on this host's
+                  cores: B-lat (1 instance, 1000 steps, median / p99), B-thr (4096 instances x 20
+                  steps, all cores, threads pinned), B-mix (N in {30, 50, 100});
+  sensitivity  -- what the headline depends on: interior point only (active_set = 0), harder
+                  disturbances (kick scale x2, x3 -> larger constrained fraction), config C2
+                  (batch 4096) and config C4 (figure-8 tracking).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -39,6 +48,7 @@ HBM_PEAK = 8.0e12         # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spe
 FP64_VEC_PEAK = 78.6e12   # FLOP/s, FP64 vector (= FP64 matrix) peak of MI355X
 N_HORIZON = 50
 KICK_PERIOD = 20
+TOTAL_BATCH = 65536       # BASELINE.json metric
 
 
 def alg_bytes_step(N):
@@ -47,63 +57,199 @@ def alg_bytes_step(N):
 
 
 def alg_bytes_qp(N):
-    """Share of the QP kernel: stage blocks read once (251 N + 13 words) +
+    """Share of the QP kernels: stage blocks read once (251 N + 13 words) +
     x0, yref, iterate read, iterate write, status (51 N + 54 words)."""
     return 8 * (302 * N + 67)
 
 
-def cpu_baseline(seed, n_inst=2048, n_steps=4, reps=3):
-    """Times the CPU restatement on a bounded sample of the same workload (closed loop).
-    Best of `reps` repetitions for both figures: GPU boxes are shared hosts and single timings
-    of the host cores vary by up to 10x between runs."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (BASELINE.md section 3) -- runs in a child process without torch so that the OpenMP
+# runtime of the restatement starts with pinned threads (OMP_PROC_BIND / OMP_PLACES)
+# ---------------------------------------------------------------------------------------------
+def _cpu_baseline_child(seed):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cfnmpc_oracle as o
     import cref
     cref.build()
-    yr, ye = o.regulation_yref(N_HORIZON, (0.0, 0.0, 0.4))
-    yref = np.repeat(yr[None], n_inst, 0).copy()
-    yref_e = np.repeat(ye[None], n_inst, 0).copy()
-    opts = cref.default_opts(active_set=1)   # same QP method as the engine's default
+    N = N_HORIZON
+    yr, ye = o.regulation_yref(N, (0.0, 0.0, 0.4))
+    opts = cref.default_opts(active_set=1)          # same QP method as the engine's default
     cores = os.cpu_count() or 1
-    best_all, best_one, used, iters = 0.0, 0.0, 1, []
-    for _ in range(reps):
-        rng = np.random.default_rng(seed)
-        x = o.sample_hover_x0(rng, n_inst)
-        xit = np.repeat(x[:, None, :], N_HORIZON + 1, 1).copy()
-        uit = np.full((n_inst, N_HORIZON, 4), o.HOV_W)
-        t_solve = 0.0
-        iters = []
-        for _s in range(n_steps):
-            t0 = time.perf_counter()
-            st, it, rs, used = cref.rti_step(opts, xit, uit, x.copy(), yref, yref_e, nthreads=0)
-            t_solve += time.perf_counter() - t0
-            iters.append(float(it.mean()))
-            x = cref.sim(x, uit[:, 0, :].copy(), 0.015, 1)
-        best_all = max(best_all, n_inst * n_steps / t_solve)
-        # single-thread rate on a small slice of the same states
-        m = min(64, n_inst)
-        xs = np.repeat(x[:m, None, :], N_HORIZON + 1, 1).copy(); us = np.full((m, N_HORIZON, 4), o.HOV_W)
-        t0 = time.perf_counter()
-        cref.rti_step(opts, xs, us, x[:m].copy(), yref[:m].copy(), yref_e[:m].copy(), nthreads=1)
-        best_one = max(best_one, m / (time.perf_counter() - t0))
-    return {
-        "value": best_all, "unit": "RTI steps/s", "cores": int(used),
-        "host_cores": int(cores), "kind": "port",
-        "single_thread_steps_per_s": best_one,
-        "sample": f"best of {reps} x ({n_inst} instances x {n_steps} closed-loop RTI steps of the same hover workload), "
-                  f"oracle/cfnmpc_ref.c (CPU restatement, not acados; same QP method as the engine: active-set solves, "
-                  f"interior point as fall-back), OpenMP over {used} threads; mean QP solves {np.mean(iters):.2f}",
+    rng = np.random.default_rng(seed)
+    # B-lat: one instance, 1000 consecutive closed-loop RTI steps on one core; every 20th step the
+    # vehicle is kicked like the fleet is (otherwise 980 of the steps would be converged ones)
+    lat, bad = [], 0
+    for c in range(50):
+        x = o.sample_hover_x0(rng, 1)
+        r = cref.closed_loop(opts, x, yr[None].copy(), ye[None].copy(), KICK_PERIOD, nthreads=1, latencies=True)
+        lat.append(r["lat_us"]); bad += r["bad"]
+    lat = np.sort(np.concatenate(lat))
+    # B-thr: first 4096 instances of config C2, 20 closed-loop steps each, all host cores
+    B = 4096
+    x2 = o.sample_hover_x0(np.random.default_rng(seed), B)
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    best = None
+    for _ in range(3):       # shared hosts: best of three
+        r = cref.closed_loop(opts, x2.copy(), yref, yref_e, KICK_PERIOD, nthreads=0)
+        if best is None or r["seconds"] < best["seconds"]:
+            best = r
+    thr = B * KICK_PERIOD / best["seconds"]
+    one = None
+    for _ in range(3):
+        r1 = cref.closed_loop(opts, x2[:64].copy(), yref[:64], yref_e[:64], KICK_PERIOD, nthreads=1)
+        one = r1 if one is None or r1["seconds"] < one["seconds"] else one
+    thr1 = 64 * KICK_PERIOD / one["seconds"]
+    # B-mix: 4096 instances of config C5 (N in {30, 50, 100}, delay-compensated x0)
+    hz = np.random.default_rng(seed + 2).choice([30, 50, 100], size=B)
+    xm = cref.sim(x2, np.full((B, 4), o.HOV_W), 0.06, 4)
+    t_mix, stage_steps = 0.0, 0
+    for n in (30, 50, 100):
+        idx = np.nonzero(hz == n)[0]
+        yrn, yen = o.regulation_yref(int(n), (0.0, 0.0, 0.4))
+        rr = cref.closed_loop(cref.default_opts(N=int(n), active_set=1), xm[idx].copy(), np.repeat(yrn[None], len(idx), 0).copy(),
+                              np.repeat(yen[None], len(idx), 0).copy(), KICK_PERIOD, nthreads=0)
+        t_mix += rr["seconds"]; stage_steps += len(idx) * int(n) * KICK_PERIOD
+    out = {
+        "value": thr, "unit": "RTI steps/s", "cores": int(best["threads"]), "host_cores": int(cores), "kind": "port",
+        "per_core_steps_per_s": thr / best["threads"], "single_thread_steps_per_s": thr1,
+        "parallel_efficiency": thr / (best["threads"] * thr1),
+        "latency_us": {"median": float(lat[len(lat) // 2]), "p99": float(lat[int(len(lat) * 0.99)]), "max": float(lat[-1]),
+                       "steps": int(len(lat)), "budget_us": 15000.0, "bad_status": int(bad)},
+        "mixed_horizon_steps_per_s": B * KICK_PERIOD / t_mix, "mixed_horizon_stage_steps_per_s": stage_steps / t_mix,
+        "mean_qp_solves": best["iters"] / (B * KICK_PERIOD),
+        "sample": (f"oracle/cfnmpc_ref.c (CPU restatement, NOT acados; gcc -O3 -march=native -fopenmp, FP64, same QP method as the "
+                   f"engine: active-set solves, interior point as fall-back). B-thr: first {B} instances of config C2 x {KICK_PERIOD} "
+                   f"closed-loop RTI steps, one instance at a time per thread, {best['threads']} pinned threads "
+                   f"(OMP_PROC_BIND=close, OMP_PLACES=cores), best of 3. B-lat: 1 instance, {len(lat)} closed-loop steps on one core "
+                   f"(kicked every {KICK_PERIOD} steps). B-mix: {B} instances N in {{30,50,100}}, delay-compensated x0."),
     }
+    print(json.dumps(out))
+
+
+def cpu_baseline(seed):
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_DYNAMIC="false")
+    env.pop("OMP_NUM_THREADS", None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(seed)], env=env,
+                       capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-500:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+# ---------------------------------------------------------------------------------------------
+# one closed-loop fleet on this rank's GPU
+# ---------------------------------------------------------------------------------------------
+class Fleet:
+    """`n` vehicles: own solver object, device-resident plant state, staggered kicks."""
+
+    def __init__(self, n, dev, rng, workload="hover", kick_scale=1.0, **opt_kw):
+        import torch
+        from crazyflie_nmpc_amd import BatchSolver, default_opts
+        from crazyflie_nmpc_amd.solver import INIT_HOVER
+        from crazyflie_nmpc_amd.synthetic import regulation_row, sample_hover_x0 as sample_x0
+        N = N_HORIZON
+        self.n, self.dev = n, dev
+        self.x = torch.from_numpy(sample_x0(rng, n, scale=kick_scale)).to(dev)
+        self.xn = torch.empty_like(self.x)
+        self.u0 = torch.empty((n, 4), dtype=torch.float64, device=dev)
+        self.cohort = (n + KICK_PERIOD - 1) // KICK_PERIOD
+        self.kicks = torch.from_numpy(sample_x0(rng, self.cohort * KICK_PERIOD, scale=kick_scale)
+                                      .reshape(KICK_PERIOD, self.cohort, 13)).to(dev)
+        self.solver = BatchSolver(n, default_opts(**opt_kw))
+        self.track = workload == "figure8"
+        if self.track:
+            # config C4 (SURVEY section 8d / App. C): figure-8 reference synthesised from the reference's
+            # crazyflie_demo/scripts/figure8.csv (three laps + N+1 hold rows), per-instance phase
+            # offsets, z offset 0.5 m; windows are generated on the device every step
+            from crazyflie_nmpc_amd.trajectories import Figure8, figure8_reference
+            lap = figure8_reference(Figure8(np.load(os.path.join(ROOT, "crazyflie_nmpc_amd", "data", "figure8_coeffs.npy"))), z0=0.5, N=N)
+            lap1 = lap[:-(N + 1)]
+            self.traj = torch.from_numpy(np.concatenate([lap1, lap1, lap1, lap[-(N + 1):]])).to(dev)
+            self.it = torch.from_numpy(rng.integers(0, 436, n).astype(np.int32)).to(dev)
+            self.mode = torch.ones(n, dtype=torch.int32, device=dev)
+            self.des = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+            hover = torch.tensor([0, 0, 0.4, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0], dtype=torch.float64, device=dev)
+            self.pert = 0.3 * (self.kicks - hover)            # perturbations around the reference row
+            self.x = self.traj[self.it.long(), :13] + 0.3 * (self.x - hover)
+            self.x[:, 3:7] /= torch.linalg.norm(self.x[:, 3:7], dim=1, keepdim=True)
+            self.solver.set_yref_windows(self.traj, self.mode, self.it.clone(), self.des, 15.7777)
+        else:
+            row = regulation_row((0.0, 0.0, 0.4))
+            yref = torch.from_numpy(np.tile(row, (n, N, 1))).to(dev)
+            yref_e = torch.from_numpy(np.tile(row[:13], (n, 1))).to(dev)
+            self.solver.set_yref(yref, yref_e)
+            del yref
+        self.solver.set_x0(self.x)
+        self.solver.init_iterate(INIT_HOVER)
+        self.t = 0
+        self.stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step(self):
+        import torch
+        from crazyflie_nmpc_amd import sim
+        t, xc = self.t, self.x
+        c0 = (t % KICK_PERIOD) * self.cohort
+        c1 = min(c0 + self.cohort, self.n)
+        if c1 > c0 and not self.track:
+            xc[c0:c1].copy_(self.kicks[t % KICK_PERIOD, : c1 - c0])  # disturbance of one cohort
+        if self.track:
+            if c1 > c0:   # disturbance relative to the vehicle's current reference row
+                ref = self.traj[self.it[c0:c1].long(), :13]
+                kick = ref + self.pert[t % KICK_PERIOD, : c1 - c0]
+                kick[:, 3:7] /= torch.linalg.norm(kick[:, 3:7], dim=1, keepdim=True)
+                xc[c0:c1].copy_(kick)
+            # NMPC::iteration window logic on the device (acados_mpc.cpp:460-485)
+            self.solver.set_yref_windows(self.traj, self.mode, self.it, self.des, 15.7777)
+        self.solver.set_x0(xc)                               # lbx = ubx = x0 (acados_mpc.cpp:581)
+        self.solver.solve(1, self.stream)                    # acados_solve()  (acados_mpc.cpp:611)
+        self.solver.get_u(0, out=self.u0)                    # ocp_nlp_out_get(.., 0, "u")  (:619)
+        sim(xc, self.u0, T=0.015, steps=1, out=self.xn)      # plant: one RK4 step of the ODE
+        self.x, self.xn = self.xn, xc
+        self.t = t + 1
+
+    def close(self):
+        self.solver.close()
+
+
+def timed_run(fleet, steps, warmup, barrier):
+    """W untimed + exactly K timed steps between barrier + synchronize; the step's kernels are
+    bracketed by HIP events on the launch stream during the SAME K steps (cfnmpc_set_profiling).
+    -> (elapsed seconds, ms linearise, ms qp, stats of the last step)"""
+    for _ in range(warmup):
+        fleet.step()
+    fleet.solver.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fleet.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms_lin, ms_qp, n_prof = fleet.solver.get_profile()
+    fleet.solver.set_profiling(False)
+    assert n_prof == steps, (n_prof, steps)
+    st, it, _rs = fleet.solver.stats()
+    heads = fleet.solver.heads()
+    return elapsed, ms_lin, ms_qp, dict(ok=float((st == 0).sum()), bad=float((st != 0).sum()), solves=float(it.sum()),
+                                        constrained=float((it > 0).sum()), heads=float(heads.sum()))
 
 
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-baseline-child":
+        return _cpu_baseline_child(int(sys.argv[2]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=TOTAL_BATCH,
+                    help="instances: in total with --scaling strong, per GPU with --scaling weak")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default=None,
+                    help="strong (default for N > 1): --batch instances split over the GPUs; weak: --batch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the sensitivity runs (and the weak run beside a strong one)")
     ap.add_argument("--active-horizon", type=int, default=1)
+    ap.add_argument("--active-set", type=int, default=1)
+    ap.add_argument("--cond-n2", type=int, default=None, help="cfnmpc_opts.cond_N2 (partial condensing; default: library default)")
+    ap.add_argument("--kick-scale", type=float, default=1.0)
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (default); gloo only for functional checks of the N > 1 path on "
                          "a box with fewer GPUs than ranks (ranks then share devices)")
@@ -113,9 +259,6 @@ def main():
     ap.add_argument("--overlap", type=int, default=None, help="cfnmpc_opts.overlap_linearise (default: library default)")
     ap.add_argument("--ah-margin", type=float, default=None)
     ap.add_argument("--ah-extra", type=int, default=None)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="sub-batches per GPU, each with its own solver object and HIP stream (overlaps the "
-                         "latency-bound interior-point tail of one shard with the streaming kernels of the others)")
     args = ap.parse_args()
 
     import torch
@@ -143,185 +286,122 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
             red_dev = torch.device("cpu")
 
-    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
-    from crazyflie_nmpc_amd.synthetic import regulation_row, sample_hover_x0 as sample_x0
-    from crazyflie_nmpc_amd.solver import INIT_HOVER
-
-    B, N = args.batch, N_HORIZON
     from crazyflie_nmpc_amd import parallel
+    N = N_HORIZON
+    scaling = args.scaling or "strong"
     seed = parallel.shard_seed(rank)
-    rng = np.random.default_rng(seed)
-    row = regulation_row((0.0, 0.0, 0.4))
-    S = max(1, min(args.streams, B // 1024 if B >= 1024 else 1))
-
-    class Shard:
-        """One sub-batch: own solver object, own HIP stream, device-resident plant state."""
-
-        def __init__(self, lo, hi):
-            n = hi - lo
-            self.n = n
-            self.stream = torch.cuda.Stream(dev) if S > 1 else torch.cuda.current_stream(dev)
-            self.x = torch.from_numpy(sample_x0(rng, n)).to(dev)
-            self.xn = torch.empty_like(self.x)
-            self.u0 = torch.empty((n, 4), dtype=torch.float64, device=dev)
-            self.cohort = (n + KICK_PERIOD - 1) // KICK_PERIOD
-            self.kicks = torch.from_numpy(sample_x0(rng, self.cohort * KICK_PERIOD).reshape(KICK_PERIOD, self.cohort, 13)).to(dev)
-            kw = dict(active_horizon=args.active_horizon)
-            if args.overlap is not None:
-                kw["overlap_linearise"] = args.overlap
-            if args.ah_margin is not None:
-                kw["ah_margin"] = args.ah_margin
-            if args.ah_extra is not None:
-                kw["ah_extra"] = args.ah_extra
-            self.solver = BatchSolver(n, default_opts(**kw))
-            self.track = args.workload == "figure8"
-            if self.track:
-                # config C4 (SURVEY section 8d / App. C): figure-8 reference synthesised from the reference's
-                # crazyflie_demo/scripts/figure8.csv (three laps + N+1 hold rows), per-instance phase
-                # offsets, z offset 0.5 m; windows are generated on the device every step
-                from crazyflie_nmpc_amd.trajectories import Figure8, figure8_reference
-                lap = figure8_reference(Figure8(np.load(os.path.join(ROOT, "crazyflie_nmpc_amd", "data", "figure8_coeffs.npy"))), z0=0.5, N=N)
-                lap1 = lap[:-(N + 1)]
-                self.traj = torch.from_numpy(np.concatenate([lap1, lap1, lap1, lap[-(N + 1):]])).to(dev)
-                self.it = torch.from_numpy(rng.integers(0, 436, n).astype(np.int32)).to(dev)
-                self.mode = torch.ones(n, dtype=torch.int32, device=dev)
-                self.des = torch.zeros((n, 3), dtype=torch.float64, device=dev)
-                hover = torch.tensor([0, 0, 0.4, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0.0], dtype=torch.float64, device=dev)
-                self.pert = 0.3 * (self.kicks - hover)            # perturbations around the reference row
-                self.x = self.traj[self.it.long(), :13] + 0.3 * (self.x - hover)
-                self.x[:, 3:7] /= torch.linalg.norm(self.x[:, 3:7], dim=1, keepdim=True)
-                self.solver.set_yref_windows(self.traj, self.mode, self.it.clone(), self.des, 15.7777)
-            else:
-                yref = torch.from_numpy(np.tile(row, (n, N, 1))).to(dev)
-                yref_e = torch.from_numpy(np.tile(row[:13], (n, 1))).to(dev)
-                self.solver.set_yref(yref, yref_e)
-            self.solver.set_x0(self.x)
-            self.solver.init_iterate(INIT_HOVER)
-            self.t = 0
-
-        def step(self):
-            with torch.cuda.stream(self.stream):
-                t, xc = self.t, self.x
-                c0 = (t % KICK_PERIOD) * self.cohort
-                c1 = min(c0 + self.cohort, self.n)
-                if c1 > c0 and not self.track:
-                    xc[c0:c1].copy_(self.kicks[t % KICK_PERIOD, : c1 - c0])  # disturbance of one cohort
-                if self.track:
-                    if c1 > c0:   # disturbance relative to the vehicle's current reference row
-                        ref = self.traj[self.it[c0:c1].long(), :13]
-                        kick = ref + self.pert[t % KICK_PERIOD, : c1 - c0]
-                        kick[:, 3:7] /= torch.linalg.norm(kick[:, 3:7], dim=1, keepdim=True)
-                        xc[c0:c1].copy_(kick)
-                    # NMPC::iteration window logic on the device (acados_mpc.cpp:460-485)
-                    self.solver.set_yref_windows(self.traj, self.mode, self.it, self.des, 15.7777)
-                self.solver.set_x0(xc)                               # lbx = ubx = x0 (acados_mpc.cpp:581)
-                self.solver.solve(1, self.stream.cuda_stream)        # acados_solve()  (acados_mpc.cpp:611)
-                self.solver.get_u(0, out=self.u0)                    # ocp_nlp_out_get(.., 0, "u")  (:619)
-                sim(xc, self.u0, T=0.015, steps=1, out=self.xn)      # plant: one RK4 step of the ODE
-                self.x, self.xn = self.xn, xc
-                self.t = t + 1
-
-    shards = [Shard(*parallel.shard_range(B, i, S)) for i in range(S)]
-    torch.cuda.synchronize(dev)
-
-    def step():
-        for sh in shards:
-            sh.step()
+    opt_kw = dict(active_horizon=args.active_horizon, active_set=args.active_set)
+    for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2)):
+        if v is not None:
+            opt_kw[k] = v
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # statistics of the last step + per-kernel durations from a short profiled continuation
-    st = np.concatenate([sh.solver.stats()[0] for sh in shards])
-    it = np.concatenate([sh.solver.stats()[1] for sh in shards])
-    heads = np.concatenate([sh.solver.heads() for sh in shards])
-    # kernel durations: ONE shard at a time on an otherwise idle GPU, so that the HIP events bracket
-    # the kernels alone (with overlapping streams an event pair would also span foreign kernels)
-    prof_steps = min(args.steps, 10)
-    ms_lin = ms_qp = 0.0
-    for sh in shards:
+    def measure(batch_rank, steps, warmup, workload=args.workload, kick_scale=args.kick_scale, seed_off=0, **kw):
+        """One closed-loop run of `batch_rank` vehicles on this rank; aggregated over ranks."""
+        okw = dict(opt_kw); okw.update(kw)
+        fleet = Fleet(batch_rank, dev, np.random.default_rng(seed + 1000 * seed_off), workload, kick_scale, **okw)
         torch.cuda.synchronize(dev)
-        sh.solver.set_profiling(True)
-        for _ in range(prof_steps):
-            sh.step()
-        torch.cuda.synchronize(dev)
-        a_, b_, _n = sh.solver.get_profile()
-        sh.solver.set_profiling(False)
-        ms_lin += a_
-        ms_qp += b_
+        elapsed, ms_lin, ms_qp, st = timed_run(fleet, steps, warmup, barrier)
+        fleet.close()
+        del fleet
+        torch.cuda.empty_cache()
+        sums = [st["ok"], st["bad"], st["solves"], st["constrained"], st["heads"], ms_lin, ms_qp, float(batch_rank)]
+        elapsed, sums = parallel.aggregate_report(elapsed, sums, dist, red_dev)
+        tot = sums[7]
+        return dict(elapsed=elapsed, total=tot, value=tot * steps / elapsed, ms_per_step=elapsed / steps * 1e3,
+                    ms_lin=sums[5] / world, ms_qp=sums[6] / world, ok_frac=sums[0] / tot, mean_qp_solves=sums[2] / tot,
+                    frac_constrained=sums[3] / tot, mean_head=sums[4] / tot, batch_rank=batch_rank)
 
-    stats = torch.tensor([float((st == 0).sum()), float((st != 0).sum()), float(it.sum()), float((it > 0).sum()),
-                          float(heads.sum()), ms_lin, ms_qp], dtype=torch.float64, device=red_dev)
-    if dist is not None:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)   # RCCL: aggregate reporting only
-    stats = stats.cpu().numpy()
-    total_inst = B * world
-    ms_lin_avg, ms_qp_avg = stats[5] / world, stats[6] / world
+    if scaling == "strong":
+        lo, hi = parallel.shard_range(args.batch, rank, world)
+        B_rank = hi - lo
+    else:
+        B_rank = args.batch
+    main_run = measure(B_rank, args.steps, args.warmup)
+    weak = None
+    if world > 1 and scaling == "strong" and not args.no_extras:
+        weak = measure(args.batch, args.steps, args.warmup, seed_off=1)
+
+    extras = {}
+    if world == 1 and not args.no_extras and args.batch == TOTAL_BATCH and args.workload == "hover" and args.kick_scale == 1.0 \
+            and args.active_set == 1 and args.cond_n2 is None:
+        ws = min(args.warmup, 20)
+
+        def brief(r):
+            return {"value": r["value"], "ms_per_step": r["ms_per_step"], "kernel_ms": r["ms_lin"] + r["ms_qp"],
+                    "frac_constrained": r["frac_constrained"], "mean_qp_solves": r["mean_qp_solves"], "status_ok_frac": r["ok_frac"]}
+        extras["interior_point_only (active_set=0)"] = brief(measure(B_rank, 20, ws, active_set=0, seed_off=2))
+        extras["kick_scale_x2"] = brief(measure(B_rank, 20, ws, kick_scale=2.0, seed_off=3))
+        extras["kick_scale_x3"] = brief(measure(B_rank, 20, ws, kick_scale=3.0, seed_off=4))
+        extras["full_horizon_sweeps (active_horizon=0)"] = brief(measure(B_rank, 20, ws, active_horizon=0, seed_off=5))
+        extras["config_C2_batch_4096"] = brief(measure(4096, 40, 40, seed_off=6))
+        extras["batch_8192 (one GPU's share of 65536 at 8 GPUs)"] = brief(measure(8192, 40, 40, seed_off=7))
+        extras["config_C4_figure8_tracking"] = brief(measure(B_rank, 20, ws, workload="figure8", seed_off=8))
 
     if rank == 0:
-        value = total_inst * args.steps / elapsed
-        # BASELINE.md section 4 / SURVEY.md section 8d: algorithmic bytes of ONE RTI STEP (B_alg per instance x the
-        # instances of one launch) over the duration of the step's kernels, measured with HIP events on
-        # the launch stream (linearisation phase + QP phase); the QP phase is reported beside it
-        ms_step = ms_lin_avg + ms_qp_avg
-        ach = alg_bytes_step(N) * B / (ms_step * 1e-3)
-        ach_qp = alg_bytes_qp(N) * B / (ms_qp_avg * 1e-3)
+        r = main_run
+        B_launch = r["batch_rank"]          # instances one launch of this rank's kernels covers
+        ms_step = r["ms_lin"] + r["ms_qp"]
+        assert ms_step <= r["ms_per_step"] * 1.001, (ms_step, r["ms_per_step"])   # same K steps: kernels are part of the step
+        ach = alg_bytes_step(N) * B_launch / (ms_step * 1e-3)
+        ach_qp = alg_bytes_qp(N) * B_launch / (r["ms_qp"] * 1e-3)
         traffic = traffic_qp = None
+        tsrc = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                if int(tj.get("batch", -1)) == B:
+                if int(tj.get("batch", -1)) == B_launch:
                     traffic_qp = tj.get("hbm_bytes_per_launch_k_qp")
                     traffic = tj.get("hbm_bytes_per_step")
                     if traffic is None and traffic_qp is not None:
                         traffic = traffic_qp + tj["kernels"]["cfn::k_linearise"]["total_bytes"]
+                    tsrc = ("profiles/pmc_traffic_latest.json (STATIC: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                            "tools/profile_round.sh on the builder's box, same command line; not measured in this run)")
             except Exception:
                 traffic = traffic_qp = None
         out = {
             "metric": "NMPC RTI steps/sec (batch=65536, N=50, nx=13, nu=4)",
-            "value": value, "unit": "RTI steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": r["value"], "unit": "RTI steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("C3 hover regulation" if args.workload == "hover" else
                                     "C4 figure-8 tracking (device-side reference windows)") +
                                    ", closed loop through the RK4 plant, staggered kicks "
-                                   f"(1/{KICK_PERIOD} of the fleet per step)", "batch_per_gpu": B, "horizon_N": N,
-                       "streams_per_gpu": S,
-                       "nx": 13, "nu": 4, "sharding": f"independent instances, {world} shard(s), no data-path collective",
-                       "qp": ("primal-dual active-set solves on the Riccati factorisation (exact, KKT-verified; "
-                              "Mehrotra interior point, tol 1e-8, as fall-back), ") +
-                             ("active-horizon sweeps" if args.active_horizon else "full-horizon sweeps")},
+                                   f"(1/{KICK_PERIOD} of the fleet per step, scale {args.kick_scale:g})",
+                       "total_batch": int(r["total"]), "batch_per_gpu": B_launch, "horizon_N": N, "nx": 13, "nu": 4,
+                       "sharding": (f"{scaling} scaling: " + (f"{args.batch} instances split into {world} contiguous shard(s)" if scaling == "strong"
+                                                             else f"{args.batch} instances per GPU") + ", no data-path collective"),
+                       "qp": (("primal-dual active-set solves on the Riccati factorisation (exact, KKT-verified; "
+                               "Mehrotra interior point, tol 1e-8, as fall-back), ") if args.active_set else
+                              "Mehrotra predictor-corrector interior point on stage-wise Riccati sweeps, tol 1e-8, ") +
+                             ("active-horizon sweeps" if args.active_horizon else "full-horizon sweeps") +
+                             (f", partial condensing N2 = {args.cond_n2}" if args.cond_n2 else "")},
             "roofline": {"bound": "hbm", "kernel": "one RTI step = k_linearise + k_factor + k_forward + k_compact + k_scatter + "
                                                      "k_as + k_ipm_rest (HIP events on the launch stream around the two "
-                                                     "phases, summed over the sub-batch launches)",
+                                                     "phases, averaged over the K timed steps themselves)",
                          "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic,
-                         "alg_bytes_per_launch": alg_bytes_step(N) * B, "kernel_ms": ms_step,
-                         "linearise_ms": ms_lin_avg, "qp_ms": ms_qp_avg,
+                         "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic, "traffic_source": tsrc,
+                         "alg_bytes_per_launch": alg_bytes_step(N) * B_launch, "kernel_ms": ms_step,
+                         "linearise_ms": r["ms_lin"], "qp_ms": r["ms_qp"],
                          "qp_phase": {"kernels": "k_factor + k_forward + k_compact + k_scatter + k_as + k_ipm_rest",
-                                      "alg_bytes_per_launch": alg_bytes_qp(N) * B, "achieved": ach_qp / 1e9,
+                                      "alg_bytes_per_launch": alg_bytes_qp(N) * B_launch, "achieved": ach_qp / 1e9,
                                       "frac": ach_qp / HBM_PEAK, "traffic": traffic_qp},
                          # the same model against the wall clock of the whole closed loop (plant, I/O kernels included)
-                         "step_frac_hbm": alg_bytes_step(N) * value / (world * HBM_PEAK)},
-            "qp_stats": {"status_ok_frac": stats[0] / total_inst, "mean_qp_solves": stats[2] / total_inst,
-                         "frac_constrained": stats[3] / total_inst, "mean_head_stages": stats[4] / total_inst},
+                         "step_frac_hbm": alg_bytes_step(N) * r["value"] / (world * HBM_PEAK)},
+            "qp_stats": {"status_ok_frac": r["ok_frac"], "mean_qp_solves": r["mean_qp_solves"],
+                         "frac_constrained": r["frac_constrained"], "mean_head_stages": r["mean_head"]},
         }
+        if weak is not None:
+            out["weak_scaling"] = {"value": weak["value"], "unit": "RTI steps/s", "batch_per_gpu": weak["batch_rank"],
+                                   "total_batch": int(weak["total"]), "ms_per_step": weak["ms_per_step"],
+                                   "kernel_ms": weak["ms_lin"] + weak["ms_qp"], "steps": args.steps, "warmup": args.warmup}
+        if extras:
+            out["sensitivity"] = extras
         if not args.no_cpu_baseline and world == 1:   # the CPU restatement is timed at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(seed)

@@ -17,9 +17,11 @@
  *
  * Build: make -C oracle   ->  oracle/libcfnmpc_oracle.so
  */
+#define _POSIX_C_SOURCE 200809L
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -700,4 +702,71 @@ void cfo_sim(int B, const double *x, const double *u, double T, int steps, doubl
 #pragma omp parallel for
 #endif
     for (int n = 0; n < B; n++) cfo_rk4(x + (size_t)n * NX, u + (size_t)n * NU, T, steps, xn + (size_t)n * NX);
+}
+
+/* Closed loop for the CPU baseline of bench.py: every instance runs `steps`
+ * consecutive RTI steps against the model as plant (x <- RK4(x, u0, dt)), all inside ONE parallel
+ * region -- one instance at a time per thread, static partition, so a thread's share is one
+ * contiguous block of instances and the region is entered once (B-thr).  With B = 1 and
+ * lat_us != NULL the wall time of every RTI step is recorded (B-lat: acados_solve() latency,
+ * acados_mpc.cpp:611-616).  x [B][13] is the plant state (updated), iterate = hover start
+ * (x_k = x, u_k = hover) as in the GPU benchmark.  Returns the threads used; *seconds = wall time
+ * of the region; iters_sum = total QP solves / interior-point iterations; n_bad = steps whose
+ * status was not 0. */
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+int cfo_closed_loop(const cfo_opts *o, int B, double *x, const double *yref, const double *yref_e, int steps,
+                    int nthreads, double *seconds, long long *iters_sum, long long *n_bad, double *lat_us) {
+    const int N = o->N;
+    const double hov = sqrt((MQ * G0) / (4 * CT));
+    int used = 1;
+    long long it_tot = 0, bad_tot = 0;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#endif
+    const double t_begin = now_s();
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads) reduction(+ : it_tot, bad_tot)
+#endif
+    {
+#ifdef _OPENMP
+#pragma omp single
+        used = omp_get_num_threads();
+#endif
+        double *mem = (double *)malloc(sizeof(double) * (qp_doubles(N) + (size_t)(N + 1) * NX + (size_t)N * NU));
+        qp_t qp;
+        qp_carve(&qp, N, mem);
+        double *xi = mem + qp_doubles(N), *ui = xi + (size_t)(N + 1) * NX;
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (int n = 0; n < B; n++) {
+            double *xp = x + (size_t)n * NX;
+            for (int k = 0; k <= N; k++) memcpy(xi + (size_t)k * NX, xp, sizeof(double) * NX);
+            for (int i = 0; i < N * NU; i++) ui[i] = hov;
+            for (int t = 0; t < steps; t++) {
+                const double t0 = (lat_us && B == 1) ? now_s() : 0.0;
+                linearise(&qp, o, xi, ui, xp, yref + (size_t)n * N * NY, yref_e + (size_t)n * NX);
+                int it = 0;
+                double rs = 0;
+                const int st = ipm_solve(&qp, o, &it, &rs);
+                for (int i = 0; i < (N + 1) * NX; i++) xi[i] += qp.x[i];
+                for (int i = 0; i < N * NU; i++) ui[i] += qp.v[i];
+                if (lat_us && B == 1) lat_us[t] = 1e6 * (now_s() - t0);
+                it_tot += it;
+                bad_tot += st != 0;
+                double xn[NX];
+                cfo_rk4(xp, ui, o->dt, 1, xn);
+                memcpy(xp, xn, sizeof xn);
+            }
+        }
+        free(mem);
+    }
+    *seconds = now_s() - t_begin;
+    if (iters_sum) *iters_sum = it_tot;
+    if (n_bad) *n_bad = bad_tot;
+    return used;
 }

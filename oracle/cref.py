@@ -38,6 +38,7 @@ def lib():
             build()
         _lib = C.CDLL(_SO)
         _lib.cfo_rti_step.restype = C.c_int
+        _lib.cfo_closed_loop.restype = C.c_int
         _lib.cfo_qp_solve.restype = C.c_int
     return _lib
 
@@ -113,3 +114,16 @@ def qp_solve(opts, x_it, u_it, x0, yref, yref_e):
     it = C.c_int(0); res = C.c_double(0)
     st = lib().cfo_qp_solve(C.byref(opts), _p(x_it), _p(u_it), _p(x0), _p(yref), _p(yref_e), _p(dx), _p(du), _p(ll), _p(lu), C.byref(it), C.byref(res))
     return dict(dx=dx, du=du, lam_l=ll, lam_u=lu, status=st, iters=it.value, res=res.value)
+
+
+def closed_loop(opts, x, yref, yref_e, steps, nthreads=0, latencies=False):
+    """Per-instance closed loops inside one parallel region (bench.py cpu_baseline).  x [B][13] is
+    updated in place.  -> dict(seconds, threads, iters, bad, lat_us)"""
+    B = x.shape[0]
+    for a in (x, yref, yref_e):
+        assert a.dtype == np.float64 and a.flags.c_contiguous
+    sec = C.c_double(0); its = C.c_longlong(0); bad = C.c_longlong(0)
+    lat = np.zeros(steps) if (latencies and B == 1) else None
+    used = lib().cfo_closed_loop(C.byref(opts), C.c_int(B), _p(x), _p(yref), _p(yref_e), C.c_int(steps), C.c_int(nthreads),
+                                 C.byref(sec), C.byref(its), C.byref(bad), _p(lat) if lat is not None else None)
+    return dict(seconds=sec.value, threads=int(used), iters=int(its.value), bad=int(bad.value), lat_us=lat)

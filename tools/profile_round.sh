@@ -6,9 +6,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/snap
 rm -rf $O; mkdir -p $O   # (the local gpurun_out/ MERGES files of successive calls: clear gpurun_out/snap before pulling a new snapshot)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 6 --warmup 20 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 6 --warmup 20 --no-cpu-baseline > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline --no-extras > $O/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --steps 6 --warmup 20 --no-cpu-baseline --no-extras > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --steps 6 --warmup 20 --no-cpu-baseline --no-extras > $O/pmc_write.log 2>&1
 python $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write $O/pmc_traffic.json $O/pmc_summary.csv
 cp $O/pmc_traffic.json $R/profiles/pmc_traffic_latest.json   # so that the bench line below carries the fresh figure
 cp $O/stats/*/*kernel_stats.csv $O/kernel_stats.csv
