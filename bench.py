@@ -66,6 +66,29 @@ def alg_bytes_qp(N):
 # CPU baseline -- runs in a child process without torch so that the OpenMP
 # runtime of the restatement starts with pinned threads (OMP_PROC_BIND / OMP_PLACES)
 # ---------------------------------------------------------------------------------------------
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (GPU boxes
+    expose all 256 hardware threads of the host but grant a fraction of them as CPU time; running one
+    OpenMP thread per visible CPU then spends the run being throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())       # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def _cpu_baseline_child(seed):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cfnmpc_oracle as o
@@ -75,6 +98,7 @@ def _cpu_baseline_child(seed):
     yr, ye = o.regulation_yref(N, (0.0, 0.0, 0.4))
     opts = cref.default_opts(active_set=1)          # same QP method as the engine's default
     cores = os.cpu_count() or 1
+    nthr, quota = usable_cpus()
     rng = np.random.default_rng(seed)
     # B-lat: one instance, 1000 consecutive closed-loop RTI steps on one core; every 20th step the
     # vehicle is kicked like the fleet is (otherwise 980 of the steps would be converged ones)
@@ -90,7 +114,7 @@ def _cpu_baseline_child(seed):
     yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
     best = None
     for _ in range(3):       # shared hosts: best of three
-        r = cref.closed_loop(opts, x2.copy(), yref, yref_e, KICK_PERIOD, nthreads=0)
+        r = cref.closed_loop(opts, x2.copy(), yref, yref_e, KICK_PERIOD, nthreads=nthr)
         if best is None or r["seconds"] < best["seconds"]:
             best = r
     thr = B * KICK_PERIOD / best["seconds"]
@@ -107,10 +131,10 @@ def _cpu_baseline_child(seed):
         idx = np.nonzero(hz == n)[0]
         yrn, yen = o.regulation_yref(int(n), (0.0, 0.0, 0.4))
         rr = cref.closed_loop(cref.default_opts(N=int(n), active_set=1), xm[idx].copy(), np.repeat(yrn[None], len(idx), 0).copy(),
-                              np.repeat(yen[None], len(idx), 0).copy(), KICK_PERIOD, nthreads=0)
+                              np.repeat(yen[None], len(idx), 0).copy(), KICK_PERIOD, nthreads=nthr)
         t_mix += rr["seconds"]; stage_steps += len(idx) * int(n) * KICK_PERIOD
     out = {
-        "value": thr, "unit": "RTI steps/s", "cores": int(best["threads"]), "host_cores": int(cores), "kind": "port",
+        "value": thr, "unit": "RTI steps/s", "cores": int(best["threads"]), "host_cores": int(cores), "cpu_quota": quota, "kind": "port",
         "per_core_steps_per_s": thr / best["threads"], "single_thread_steps_per_s": thr1,
         "parallel_efficiency": thr / (best["threads"] * thr1),
         "latency_us": {"median": float(lat[len(lat) // 2]), "p99": float(lat[int(len(lat) * 0.99)]), "max": float(lat[-1]),
@@ -119,15 +143,15 @@ def _cpu_baseline_child(seed):
         "mean_qp_solves": best["iters"] / (B * KICK_PERIOD),
         "sample": (f"oracle/cfnmpc_ref.c (CPU restatement, NOT acados; gcc -O3 -march=native -fopenmp, FP64, same QP method as the "
                    f"engine: active-set solves, interior point as fall-back). B-thr: first {B} instances of config C2 x {KICK_PERIOD} "
-                   f"closed-loop RTI steps, one instance at a time per thread, {best['threads']} pinned threads "
-                   f"(OMP_PROC_BIND=close, OMP_PLACES=cores), best of 3. B-lat: 1 instance, {len(lat)} closed-loop steps on one core "
+                   f"closed-loop RTI steps, one instance at a time per thread, {best['threads']} threads = the CPUs this process may use "
+                   f"(affinity mask capped by the cgroup CPU quota; host has {cores}), OMP_PROC_BIND=close, best of 3. B-lat: 1 instance, {len(lat)} closed-loop steps on one core "
                    f"(kicked every {KICK_PERIOD} steps). B-mix: {B} instances N in {{30,50,100}}, delay-compensated x0."),
     }
     print(json.dumps(out))
 
 
 def cpu_baseline(seed):
-    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_DYNAMIC="false")
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="threads", OMP_DYNAMIC="false")
     env.pop("OMP_NUM_THREADS", None)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(seed)], env=env,
                        capture_output=True, text=True, timeout=900)
