@@ -25,7 +25,7 @@ Also on the same line (rank 0, N = 1):
   cpu_baseline -- BASELINE.md section 3: the plain-C CPU restatement of the same algorithm
                   (oracle/cfnmpc_ref.c, "port": acados itself cannot be built here) on this host's
                   cores: B-lat (1 instance, 1000 steps, median / p99), B-thr (4096 instances x 20
-                  steps, all cores, threads pinned), B-mix (N in {30, 50, 100});
+                  steps, all usable cores), B-mix (N in {30, 50, 100});
   sensitivity  -- what the headline depends on: interior point only (active_set = 0), harder
                   disturbances (kick scale x2, x3 -> larger constrained fraction), config C2
                   (batch 4096) and config C4 (figure-8 tracking).
@@ -70,6 +70,10 @@ def usable_cpus():
     """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (GPU boxes
     expose all 256 hardware threads of the host but grant a fraction of them as CPU time; running one
     OpenMP thread per visible CPU then spends the run being throttled)."""
+    try:   # the parent (HIP / torch runtimes loaded) may hand down a narrowed mask: widen it as far as the cpuset allows
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except Exception:
+        pass
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     quota = None
     try:
@@ -144,15 +148,16 @@ def _cpu_baseline_child(seed):
         "sample": (f"oracle/cfnmpc_ref.c (CPU restatement, NOT acados; gcc -O3 -march=native -fopenmp, FP64, same QP method as the "
                    f"engine: active-set solves, interior point as fall-back). B-thr: first {B} instances of config C2 x {KICK_PERIOD} "
                    f"closed-loop RTI steps, one instance at a time per thread, {best['threads']} threads = the CPUs this process may use "
-                   f"(affinity mask capped by the cgroup CPU quota; host has {cores}), OMP_PROC_BIND=close, best of 3. B-lat: 1 instance, {len(lat)} closed-loop steps on one core "
+                   f"(affinity mask capped by the cgroup CPU quota; host has {cores}), best of 3. B-lat: 1 instance, {len(lat)} closed-loop steps on one core "
                    f"(kicked every {KICK_PERIOD} steps). B-mix: {B} instances N in {{30,50,100}}, delay-compensated x0."),
     }
     print(json.dumps(out))
 
 
 def cpu_baseline(seed):
-    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="threads", OMP_DYNAMIC="false")
-    env.pop("OMP_NUM_THREADS", None)
+    env = dict(os.environ, OMP_PROC_BIND="false", OMP_DYNAMIC="false")   # measured on the GPU box: unbound threads under the CPU quota are fastest
+    for k in ("OMP_NUM_THREADS", "OMP_PLACES", "GOMP_CPU_AFFINITY"):
+        env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", str(seed)], env=env,
                        capture_output=True, text=True, timeout=900)
     if r.returncode != 0:
