@@ -155,6 +155,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->ah_extra = 4;
     o->overlap_linearise = 0;
     o->active_set = 1;
+    o->cond_N2 = 0;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
@@ -167,6 +168,10 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     if (!(o.tol > 0.0) || !(o.tau > 0.0 && o.tau < 1.0) || !(o.thr0 > 0.0) || !(o.lam0_min > 0.0) ||
         !(o.mu0_scale >= 0.0)) return CFNMPC_EINVAL;
     if (!weights_ok(o.W, o.WN)) return CFNMPC_EINVAL;
+    // partial condensing: cond_N2 blocks of at most COND_MMAX stages; not combined with the overlapped preparation
+    if (o.cond_N2 < 0 || o.cond_N2 > o.N) return CFNMPC_EINVAL;
+    const int cond_N2 = (o.cond_N2 == 0 || o.cond_N2 == o.N) ? 0 : o.cond_N2;
+    if (cond_N2 && ((o.N + cond_N2 - 1) / cond_N2 > cfn::COND_MMAX || o.overlap_linearise)) return CFNMPC_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         std::fprintf(stderr, "cfnmpc: no HIP device available (this library has no CPU path)\n");
@@ -213,6 +218,9 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.ah_margin = o.ah_margin;
     P.ah_extra = o.ah_extra;
     P.active_set = o.active_set ? 1 : 0;
+    P.cond_N2 = cond_N2;
+    P.cond_M = cond_N2 ? o.N / cond_N2 : 0;
+    P.cond_rem = cond_N2 ? o.N % cond_N2 : 0;
     // one spare workspace block (index P.NW) parks the idle rows of compacted interior-point waves
     const size_t NW = P.NW + 1, N = P.N;
     int rc = CFNMPC_OK;
@@ -234,6 +242,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4); ALLOC(viol, NW * 4);
     ALLOC(ilist, NW * 4); ALLOC(nipm, 64);
     ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * 32); ALLOC(rank, NW * 4); ALLOC(done, NW * 4);
+    if (cond_N2) ALLOC(cb, NW * 4 * (size_t)cond_N2 * cfn::cb_size(cfn::cond_mmax(P)));
     if (s->overlap) {
         if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->AR2, NW * N * cfn::SZ_A);
         if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->BR2, NW * N * cfn::SZ_B);
@@ -381,7 +390,8 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
             if (e) HIP_TRY(hipEventRecord(e[0], st));
             cfn::launch_linearise(s->P, s->chunks_all, st);
             if (e) HIP_TRY(hipEventRecord(e[1], st));
-            cfn::launch_qp(s->P, st);
+            if (s->P.cond_N2) cfn::launch_qp_cond(s->P, st);   // pcond -> condensed Riccati -> expand (-> interior point)
+            else cfn::launch_qp(s->P, st);
             if (e) HIP_TRY(hipEventRecord(e[2], st));
             std::swap(s->P.xit, s->P.xitn);   // the step's kernels wrote every instance's new iterate there
             std::swap(s->P.uit, s->P.uitn);
@@ -613,6 +623,36 @@ int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, double* A, double* Bm, doub
             }
         }
     }
+    return CFNMPC_OK;
+}
+
+int cfnmpc_debug_get_condensed(cfnmpc_solver* s, int block, double* H, double* D, int* m_out) {
+    if (!s || !H || !D || !s->P.cond_N2 || block < 0 || block >= s->P.cond_N2) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    const cfn::Params& P = s->P;
+    cfn::launch_linearise(P, s->chunks_all, nullptr);
+    cfn::launch_pcond(P, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    const int m = cfn::cond_len(P, block), mu = 4 * m, w = cfn::cond_w(m);
+    const size_t slot = cfn::cb_size(cfn::cond_mmax(P)), B = P.B;
+    std::vector<double> h(slot);
+    // internal -> external order of the 13 state entries of z = (dU, dx, 1) and of the rows of D
+    auto zext = [&](int i) { return (i >= mu && i < mu + 13) ? mu + cfn::ext_of(i - mu) : i; };
+    for (size_t i = 0; i < B; i++) {
+        HIP_TRY(hipMemcpy(h.data(), P.cb + (i * P.cond_N2 + block) * slot, slot * sizeof(double), hipMemcpyDeviceToHost));
+        double* Hi = H + i * (size_t)w * w;
+        double* Di = D + i * (size_t)13 * w;
+        for (int r = 0; r < w; r++)
+            for (int c = 0; c <= r; c++) {
+                const double v = h[(size_t)r * (r + 1) / 2 + c];
+                Hi[zext(r) * w + zext(c)] = v;
+                Hi[zext(c) * w + zext(r)] = v;
+            }
+        const double* d = h.data() + cfn::cond_tri(w);
+        for (int r = 0; r < 13; r++)
+            for (int c = 0; c < w; c++) Di[cfn::ext_of(r) * w + zext(c)] = d[r * w + c];
+    }
+    if (m_out) *m_out = m;
     return CFNMPC_OK;
 }
 

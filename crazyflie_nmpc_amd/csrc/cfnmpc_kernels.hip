@@ -1030,11 +1030,13 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
 // P.uitn): for the ~92 % of the instances whose unconstrained minimiser is feasible that IS the RTI
 // step (the host swaps old and new after the step); the QP kernels overwrite the others.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_forward(Params P) {
+// COND (cfnmpc_opts.cond_N2, partial condensing): the gains of a block's stages are rows of the
+// CONDENSED feedback law, which acts on the state step at the START of the block (dxb); rolling the
+// interior states through the stage dynamics is the `expand` step of partial condensing.
+template <bool COND>
+__device__ __forceinline__ void forward_body(const Params& P, double* xs, double* cs, int* sflag) {
     // 13-vectors travel through LDS tiles [instance][13] so that every global access of the wave
     // is a contiguous run (as in k_linearise); K, d, u, v are 32-byte runs per lane already.
-    __shared__ double xs[64 * 13], cs[64 * 13];
-    __shared__ int sflag[64];
     const int N = P.N;
     const int tid = threadIdx.x;
     const int raw = blockIdx.x * 64 + tid;
@@ -1082,9 +1084,15 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
     bool sawnan = false;
     In cur, nxt;
     load(0, cur);
+    double dxb[13];            // COND: state step at the start of the current block
+    int knext = 0, jblk = 0;   // COND: first stage and index of the next block
     for (int k = 0; k < N; k++) {
         int tl = tid;   // opaque per-stage copy (keeps the transfer offsets out of loop-invariant registers)
         asm volatile("" : "+v"(tl));
+        if constexpr (COND) if (k == knext) {
+            SFOR(i, 0, 13, { dxb[i] = dx[i]; });
+            knext += cond_len(P, jblk++);
+        }
         double xi[13];
         SFOR(i, 0, 13, { xi[i] = xs[tid * 13 + i]; });
         // candidate state of stage k
@@ -1093,7 +1101,7 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
         double du[4];
         SFOR(a, 0, 4, {
             double acc = 0.0;
-            SFOR(l, 0, 13, { acc = __builtin_fma(cur.K[a][l], dx[l], acc); });
+            SFOR(l, 0, 13, { acc = __builtin_fma(cur.K[a][l], COND ? dxb[l] : dx[l], acc); });
             du[a] = -cur.d[a] - acc;
             const double lb = P.u_min - cur.u[a], ub = P.u_max - cur.u[a];
             viol = fmax(viol, fmax(lb - du[a], du[a] - ub));
@@ -1213,6 +1221,17 @@ __global__ __launch_bounds__(64) void k_forward(Params P) {
     if (bad) {
         for (int k = 0; k < N; k++) SFOR(a, 0, 4, { gm(P.uitn)[i4b + (size_t)k * 4 + a] = gm(P.uit)[i4b + (size_t)k * 4 + a]; });
     }
+}
+
+__global__ __launch_bounds__(64) void k_forward(Params P) {
+    __shared__ double xs[64 * 13], cs[64 * 13];
+    __shared__ int sflag[64];
+    forward_body<false>(P, xs, cs, sflag);
+}
+__global__ __launch_bounds__(64) void k_cforward(Params P) {
+    __shared__ double xs[64 * 13], cs[64 * 13];
+    __shared__ int sflag[64];
+    forward_body<true>(P, xs, cs, sflag);
 }
 
 // Stable compaction of the instances that need the interior-point method, grouped by head
@@ -1989,6 +2008,9 @@ void launch_qp_start(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     hipLaunchKernelGGL(k_compact, dim3(N_BIN), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_scatter, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
+}
+void launch_cforward(const Params& P, hipStream_t st) {
+    hipLaunchKernelGGL(k_cforward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
 }
 void launch_qp_ipm(const Params& P, hipStream_t st) {
     if (P.active_set) {

@@ -1,0 +1,603 @@
+// cfnmpc_pcond.hip -- partial condensing path of the batched RTI step (cfnmpc_opts.cond_N2 < N).
+//
+// Role in the reference: PARTIAL_CONDENSING_HPIPM (generate_c_code.py:140, README.md:77) -- HPIPM's
+// d_part_cond / d_ocp_qp_ipm / expand, none of which is under /root/reference (empty acados
+// submodule); this file implements the published algorithm from the mathematics
+// (oracle/cfnmpc_oracle.py: partial_condense / riccati_condensed / expand_condensed are the CPU
+// restatement it is tested against):
+//
+//   k_pcond   : the N stages are regrouped into N2 blocks of m consecutive stages.  With
+//               z = (dU, dx, 1), dU = the 4 m inputs of the block, dx = the state at its start:
+//                   dx_{k0+i} = G_i z,   G_0 = [0 I 0],   G_{i+1} = A_{k0+i} G_i + [B at du_i | b at 1]
+//               the block's cost is 1/2 z'H z with H = sum_i G_i'Q~_i G_i + R, r terms and its
+//               dynamics dx_{k0+m} = D z, D = G_m.  One (instance, block) per lane group; blocks are
+//               independent (grid = instances x N2).
+//   k_cfactor : Riccati recursion over the N2 condensed stages, backward: H~ = H + E'P~E with
+//               E = [D; e_1] and the augmented cost-to-go P~ (13 x 13 matrix + affine row), ONE dense
+//               Cholesky factorisation of the 4m x 4m input block per stage (right-looking, in LDS),
+//               gains K (4m x 13) and feed-forward d by back-substitution, P~ <- Schur complement.
+//               The gains are stored per ORIGINAL stage in the layout of the uncondensed path.
+//   k_forward<COND> (cfnmpc_kernels.hip): forward sweep + `expand`: the inputs of a block are the
+//               condensed feedback law at the state of the block's START, the interior states follow
+//               from the original (matrix-free RK4) stage dynamics.
+//   k_cipm    : instances whose unconstrained minimiser leaves the input box: Mehrotra
+//               predictor-corrector interior point in delta form on the SAME condensed blocks (the
+//               barrier only changes the diagonal of the input block and the gradient), two
+//               factorisations per iteration; expand through the stored (A, B, b).
+//
+// Mapping: one instance per group of LPI lanes (16, 32 or 64), all dense blocks of a group in LDS,
+// generic loops (the block length m is a run-time value up to the template's MMAX).  This path is an
+// OPTION (parity with the reference's solver plan + the N2 sweep of DESIGN.md section 5.8), not the
+// default: condensing raises both the bytes per stage and the flops for this problem's sizes.
+#include <hip/hip_runtime.h>
+
+#include "cfnmpc_model.hpp"
+#include "cfnmpc_ws.hpp"
+
+namespace cfn {
+namespace {
+
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) int gint;
+__device__ __forceinline__ gdouble* gm(double* p) { return (gdouble*)(unsigned long long)p; }
+__device__ __forceinline__ const gdouble* gm(const double* p) { return (const gdouble*)(unsigned long long)p; }
+__device__ __forceinline__ gint* gm(int* p) { return (gint*)(unsigned long long)p; }
+
+__device__ __forceinline__ int tri(int r, int c) { return (r * (r + 1)) / 2 + c; }   // c <= r
+__device__ __forceinline__ int trs(int r, int c) { return r >= c ? tri(r, c) : tri(c, r); }
+__device__ __forceinline__ double rsqrt_nr(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+    const double hs = 0.5 * s;
+    y = y * (1.5 - hs * y * y);
+    y = y * (1.5 - hs * y * y);
+    return y;
+}
+__device__ __forceinline__ double rcp_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+
+// One instance per group of LPI lanes.  Groups without an instance work on the spare workspace
+// block (index NW: finite data, never read by anyone else).
+template <int LPI>
+struct Grp {
+    int lane, g, inst, q;
+    size_t wave;
+    bool valid;
+};
+template <int LPI>
+__device__ __forceinline__ Grp<LPI> grp_id(const Params& P, int first_inst) {
+    Grp<LPI> t;
+    t.lane = threadIdx.x % LPI;
+    t.g = threadIdx.x / LPI;
+    const int raw = first_inst + t.g;
+    t.valid = raw < P.B;
+    t.inst = t.valid ? raw : P.NW * 4 + (t.g & 3);
+    t.wave = (size_t)(t.inst >> 2);
+    t.q = t.inst & 3;
+    return t;
+}
+template <int LPI>
+__device__ __forceinline__ double grp_sum(double v) {
+    for (int off = LPI / 2; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+template <int LPI>
+__device__ __forceinline__ double grp_min(double v) {
+    for (int off = LPI / 2; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+template <int LPI>
+__device__ __forceinline__ double grp_max(double v) {
+    for (int off = LPI / 2; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// element (r, c) of A_k / B_k / b_k of an instance, internal state order, from the wave-blocked
+// row-distributed stage blocks of the linearisation (cfnmpc_ws.hpp)
+template <int LPI>
+__device__ __forceinline__ double a_elem(const Params& P, const Grp<LPI>& t, int k, int r, int c) {
+    if (c < 3) return r == c ? 1.0 : 0.0;
+    const int s = c - 3;
+    const int n = ar_n(s);
+    if (r >= n) return 0.0;
+    return gm(P.AR)[(t.wave * P.N + k) * SZ_A + 4 * ar_pre(s) + t.q * n + r];
+}
+template <int LPI>
+__device__ __forceinline__ double b_elem(const Params& P, const Grp<LPI>& t, int k, int r, int a) {
+    return gm(P.BR)[(t.wave * P.N + k) * SZ_B + (a * 4 + t.q) * 13 + r];
+}
+template <int LPI>
+__device__ __forceinline__ double v13(const double* f, const Grp<LPI>& t, int stages, int k, int r) {
+    return gm(f)[(t.wave * stages + k) * SZ_V13 + t.q * 13 + r];
+}
+template <int LPI>
+__device__ __forceinline__ gdouble* cb_ptr(const Params& P, const Grp<LPI>& t, int j) {
+    return gm(P.cb) + ((size_t)t.inst * P.cond_N2 + j) * cb_size(cond_mmax(P));
+}
+
+// ---------------------------------------------------------------------------------------------
+// pcond: one (instance, block) per group
+// ---------------------------------------------------------------------------------------------
+template <int MMAX, int LPI>
+__global__ __launch_bounds__(64) void k_pcond(Params P) {
+    constexpr int W = cond_w(MMAX), IPW = 64 / LPI;
+    constexpr int GSZ = cond_tri(W) + 13 * W + 169 + 52 + 13 + 13 + 4 + 13 + 4 + 3;   // per group (padded to even below)
+    constexpr int GST = (GSZ + 1) & ~1;
+    __shared__ double lds[IPW * GST];
+    const Grp<LPI> t = grp_id<LPI>(P, blockIdx.x * IPW);
+    double* H = lds + t.g * GST;
+    double* G = H + cond_tri(W);
+    double* Am = G + 13 * W;
+    double* Bm = Am + 169;
+    double* bv = Bm + 52;
+    double* qv = bv + 13;
+    double* rv = qv + 13;
+    double* wq = rv + 4;
+    double* wr = wq + 13;
+    const int j = blockIdx.y, N = P.N;
+    const int m = cond_len(P, j), k0 = cond_start(P, j);
+    const int mu = 4 * m, w = mu + 14, aff = w - 1;
+    for (int e = t.lane; e < cond_tri(w); e += LPI) H[e] = 0.0;
+    for (int e = t.lane; e < 13 * w; e += LPI) {
+        const int r = e / w, c = e - r * w;
+        G[e] = (c == mu + r) ? 1.0 : 0.0;
+    }
+    if (t.lane < 13) wq[t.lane] = P.W[ext_of(t.lane)];
+    if (t.lane < 4) wr[t.lane] = P.W[13 + t.lane];
+    for (int i = 0; i < m; i++) {
+        const int k = k0 + i;
+        __syncthreads();
+        // stage data -> LDS (dense A, B; b; q = Q (xbar - yref), r = R (ubar - yref_u))
+        for (int e = t.lane; e < 169; e += LPI) Am[e] = a_elem(P, t, k, e / 13, e % 13);
+        for (int e = t.lane; e < 52; e += LPI) Bm[e] = b_elem(P, t, k, e / 4, e % 4);
+        if (t.lane < 13) {
+            bv[t.lane] = v13(P.b, t, N, k, t.lane);
+            const double xk = v13(P.xit, t, N + 1, k, t.lane);
+            const double yk = gm(P.yref)[(t.wave * N + k) * SZ_Y + t.q * 17 + t.lane];
+            qv[t.lane] = P.W[ext_of(t.lane)] * (xk - yk);
+        }
+        if (t.lane < 4) {
+            const double uk = gm(P.uit)[((size_t)t.inst * N + k) * 4 + t.lane];
+            const double yr = gm(P.yref)[(t.wave * N + k) * SZ_Y + t.q * 17 + 13 + t.lane];
+            rv[t.lane] = P.W[13 + t.lane] * (uk - yr);
+        }
+        __syncthreads();
+        // H += G~' Q~ G~ over the columns G_i can be non-zero in: inputs of stages < i, dx, 1
+        const int na = 4 * i + 14;
+        for (int ra = 0; ra < na; ra++) {
+            const int r = ra < 4 * i ? ra : mu + (ra - 4 * i);
+            for (int ca = t.lane; ca <= ra; ca += LPI) {
+                const int c = ca < 4 * i ? ca : mu + (ca - 4 * i);
+                double acc = 0.0;
+                if (r == aff) {
+                    for (int l = 0; l < 13; l++) acc += (wq[l] * G[l * w + aff] + qv[l]) * G[l * w + c];
+                } else {
+                    for (int l = 0; l < 13; l++) acc += G[l * w + r] * wq[l] * G[l * w + c];
+                }
+                H[tri(r, c)] += acc;
+            }
+        }
+        if (t.lane < 4) {
+            H[tri(4 * i + t.lane, 4 * i + t.lane)] += wr[t.lane];
+            H[tri(aff, 4 * i + t.lane)] += rv[t.lane];
+        }
+        __syncthreads();
+        // G <- A G + [B at the inputs of stage i] + [b at 1]; a lane owns whole columns
+        const int nb = 4 * (i + 1) + 14;
+        for (int ca = t.lane; ca < nb; ca += LPI) {
+            const int c = ca < 4 * (i + 1) ? ca : mu + (ca - 4 * (i + 1));
+            double gc[13], gn[13];
+            for (int l = 0; l < 13; l++) gc[l] = G[l * w + c];
+            for (int r = 0; r < 13; r++) {
+                double acc = 0.0;
+                for (int l = 0; l < 13; l++) acc += Am[r * 13 + l] * gc[l];
+                gn[r] = acc;
+            }
+            if (c >= 4 * i && c < 4 * i + 4) for (int r = 0; r < 13; r++) gn[r] += Bm[r * 4 + (c - 4 * i)];
+            if (c == aff) for (int r = 0; r < 13; r++) gn[r] += bv[r];
+            for (int r = 0; r < 13; r++) G[r * w + c] = gn[r];
+        }
+    }
+    __syncthreads();
+    gdouble* cb = cb_ptr(P, t, j);
+    for (int e = t.lane; e < cond_tri(w); e += LPI) cb[e] = H[e];
+    for (int e = t.lane; e < 13 * w; e += LPI) cb[cond_tri(w) + e] = G[e];
+}
+
+// ---------------------------------------------------------------------------------------------
+// condensed Riccati stage
+// ---------------------------------------------------------------------------------------------
+template <int MMAX, int LPI>
+struct CfLds {   // LDS carve-up of one group in k_cfactor / k_cipm
+    static constexpr int W = cond_w(MMAX);
+    static constexpr int SZ = (cond_tri(W) + 13 * W + 14 * 14 + 14 * W + 4 * MMAX + 13 + 17 + 1) & ~1;
+    double *H, *Dm, *Pt, *Y, *dinv, *xs, *wv;
+    __device__ __forceinline__ explicit CfLds(double* base) {
+        H = base; Dm = H + cond_tri(W); Pt = Dm + 13 * W; Y = Pt + 196; dinv = Y + 14 * W; xs = dinv + 4 * MMAX; wv = xs + 13;
+    }
+};
+
+// One block of the backward recursion.  ABSOLUTE: start solve with the QP's own affine terms;
+// otherwise the homogeneous Newton system of the interior point: the condensed Hessian gets
+// (Rh - R) on the diagonal of its input block and P.g as its input gradient, all other affine terms
+// are zero.  On entry Pt = augmented cost-to-go behind the block, on exit in front of it.
+template <int MMAX, int LPI, bool ABSOLUTE>
+__device__ __forceinline__ bool cfactor_block(const Params& P, const Grp<LPI>& t, const int j, CfLds<MMAX, LPI>& L) {
+    constexpr int NS = (cond_w(MMAX) + LPI - 1) / LPI;   // rows a lane owns
+    const int N = P.N;
+    const int m = cond_len(P, j), k0 = cond_start(P, j);
+    const int mu = 4 * m, w = mu + 14, aff = w - 1;
+    double *H = L.H, *Dm = L.Dm, *Pt = L.Pt, *Y = L.Y;
+    const gdouble* cb = cb_ptr(P, t, j);
+    const size_t eb = ((size_t)t.inst * N + k0) * 4;   // element-wise arrays of this block's inputs
+    __syncthreads();
+    for (int e = t.lane; e < cond_tri(w); e += LPI) H[e] = cb[e];
+    for (int e = t.lane; e < 13 * w; e += LPI) Dm[e] = cb[cond_tri(w) + e];
+    __syncthreads();
+    if (!ABSOLUTE) {
+        for (int c = t.lane; c < w; c += LPI) H[tri(aff, c)] = c < mu ? gm(P.g)[eb + c] : 0.0;
+        for (int c = t.lane; c < mu; c += LPI) H[tri(c, c)] += gm(P.Rh)[eb + c] - L.wv[13 + (c & 3)];
+        if (t.lane < 13) Dm[t.lane * w + aff] = 0.0;
+        __syncthreads();
+    }
+    // Y = P~ E,  E = [D; e_aff]  (14 x w)
+    for (int i = 0; i < 14; i++)
+        for (int c = t.lane; c < w; c += LPI) {
+            double acc = c == aff ? Pt[i * 14 + 13] : 0.0;
+            for (int l = 0; l < 13; l++) acc += Pt[i * 14 + l] * Dm[l * w + c];
+            Y[i * w + c] = acc;
+        }
+    __syncthreads();
+    // H~ = H + E'Y  (lower triangle)
+    for (int r = 0; r < w; r++)
+        for (int c = t.lane; c <= r; c += LPI) {
+            double acc = r == aff ? Y[13 * w + c] : 0.0;
+            for (int i = 0; i < 13; i++) acc += Dm[i * w + r] * Y[i * w + c];
+            H[tri(r, c)] += acc;
+        }
+    __syncthreads();
+    // right-looking Cholesky of the input block (columns 0 .. mu-1); the trailing rows / columns carry
+    // L_xu and the Schur complement.  A lane owns the rows lane, lane + LPI, ...
+    bool ok = true;
+    for (int k = 0; k < mu; k++) {
+        const double piv = H[tri(k, k)];
+        ok = ok && (piv > 0.0);
+        const double inv = rsqrt_nr(piv);
+        double lr[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int r = t.lane + LPI * s;
+            lr[s] = 0.0;
+            if (r > k && r < w) {
+                lr[s] = H[tri(r, k)] * inv;
+                H[tri(r, k)] = lr[s];      // (only its owner touches H[r][k] in this phase)
+            }
+        }
+        if (t.lane == 0) L.dinv[k] = inv;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const int r = t.lane + LPI * s;
+            if (r > k && r < w)
+                for (int c = k + 1; c <= r; c++) H[tri(r, c)] -= lr[s] * H[tri(c, k)];
+        }
+        __syncthreads();
+    }
+    // [K | d]' = L_xu L_uu^-1 by back-substitution, one of the 14 trailing rows per lane, in place
+    if (t.lane < 14) {
+        const int R = mu + t.lane;
+        for (int c = mu - 1; c >= 0; c--) {
+            double y = H[tri(R, c)];
+            for (int c2 = c + 1; c2 < mu; c2++) y -= H[tri(R, c2)] * H[tri(c2, c)];
+            H[tri(R, c)] = y * L.dinv[c];
+        }
+    }
+    __syncthreads();
+    // gains per ORIGINAL stage in the layout of the uncondensed path: lane a of stage k holds K[a][0..12]
+    for (int e = t.lane; e < 13 * mu; e += LPI) {
+        const int c = e / 13, l = e - c * 13;
+        const int k = k0 + (c >> 2), a = c & 3;
+        gm(P.KR)[(t.wave * N + k) * SZ_K + (l * 4 + t.q) * 4 + a] = H[tri(mu + l, c)];
+    }
+    for (int c = t.lane; c < mu; c += LPI) gm(P.d)[eb + c] = H[tri(mu + 13, c)];
+    // cost-to-go in front of the block
+    for (int e = t.lane; e < 196; e += LPI) {
+        const int i = e / 14, l = e - i * 14;
+        Pt[e] = (i == 13 && l == 13) ? 0.0 : H[trs(mu + i, mu + l)];
+    }
+    return ok;
+}
+
+template <int MMAX, int LPI, bool ABSOLUTE>
+__device__ __forceinline__ bool csweep_factor(const Params& P, const Grp<LPI>& t, CfLds<MMAX, LPI>& L) {
+    const int N = P.N;
+    __syncthreads();
+    for (int e = t.lane; e < 196; e += LPI) L.Pt[e] = 0.0;
+    __syncthreads();
+    if (t.lane < 13) {
+        const double wn = P.WN[ext_of(t.lane)];
+        L.Pt[t.lane * 14 + t.lane] = wn;
+        if (ABSOLUTE) {
+            const double xN = v13(P.xit, t, N + 1, N, t.lane);
+            const double yN = gm(P.yref_e)[t.wave * SZ_V13 + t.q * 13 + t.lane];
+            const double qn = wn * (xN - yN);
+            L.Pt[t.lane * 14 + 13] = qn;
+            L.Pt[13 * 14 + t.lane] = qn;
+        }
+    }
+    bool ok = true;
+    for (int j = P.cond_N2 - 1; j >= 0; j--) ok = cfactor_block<MMAX, LPI, ABSOLUTE>(P, t, j, L) && ok;
+    return ok;
+}
+
+template <int MMAX, int LPI>
+__global__ __launch_bounds__(64) void k_cfactor(Params P) {
+    constexpr int IPW = 64 / LPI;
+    __shared__ double lds[IPW * CfLds<MMAX, LPI>::SZ];
+    const Grp<LPI> t = grp_id<LPI>(P, blockIdx.x * IPW);
+    CfLds<MMAX, LPI> L(lds + t.g * CfLds<MMAX, LPI>::SZ);
+    if (t.lane < 17) L.wv[t.lane] = P.W[t.lane < 13 ? ext_of(t.lane) : t.lane];
+    bool ok = csweep_factor<MMAX, LPI, true>(P, t, L);
+    ok = grp_min<LPI>(ok ? 1.0 : 0.0) > 0.0;
+    if (t.lane == 0 && t.valid) gm(P.status)[t.inst] = ok ? 0 : 4;
+}
+
+// forward sweep of a homogeneous (delta) solve on the condensed blocks: dU_j = -K dx - d at the
+// block start, dx+ = Abar dx + Bbar dU.  Writes the input step (all N stages) to `out`.
+template <int MMAX, int LPI>
+__device__ __forceinline__ void csweep_forward_delta(const Params& P, const Grp<LPI>& t, CfLds<MMAX, LPI>& L, double* out) {
+    const int N = P.N;
+    double* xs = L.xs;      // dx at the block start
+    double* U = L.Y;        // dU of the block (<= 4 MMAX entries; Y is free between factorisations)
+    __syncthreads();
+    if (t.lane < 13) xs[t.lane] = 0.0;
+    __syncthreads();
+    for (int j = 0; j < P.cond_N2; j++) {
+        const int m = cond_len(P, j), k0 = cond_start(P, j);
+        const int mu = 4 * m, w = mu + 14;
+        const size_t eb = ((size_t)t.inst * N + k0) * 4;
+        for (int c = t.lane; c < mu; c += LPI) {
+            const int k = k0 + (c >> 2), a = c & 3;
+            const gdouble* kr = gm(P.KR) + (t.wave * N + k) * SZ_K + t.q * 4 + a;
+            double acc = gm(P.d)[eb + c];
+            for (int l = 0; l < 13; l++) acc += kr[l * 16] * xs[l];
+            U[c] = -acc;
+            gm(out)[eb + c] = -acc;
+        }
+        __syncthreads();
+        double xn = 0.0;
+        if (t.lane < 13) {
+            const gdouble* Dr = cb_ptr(P, t, j) + cond_tri(w) + t.lane * w;
+            for (int c = 0; c < mu; c++) xn += Dr[c] * U[c];
+            for (int l = 0; l < 13; l++) xn += Dr[mu + l] * xs[l];
+        }
+        __syncthreads();
+        if (t.lane < 13) xs[t.lane] = xn;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// interior point on the condensed QP (instances whose unconstrained minimiser leaves the box)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double ratio(double z, double dz, double a) {
+    const double tt = -z * rcp_nr(dz);
+    return (dz < 0.0 && tt < a) ? tt : a;
+}
+
+template <int MMAX, int LPI>
+__global__ __launch_bounds__(64) void k_cipm(Params P) {
+    constexpr int IPW = 64 / LPI;
+    __shared__ double lds[IPW * CfLds<MMAX, LPI>::SZ];
+    const Grp<LPI> t = grp_id<LPI>(P, blockIdx.x * IPW);
+    const double viol = t.valid ? gm(P.viol)[t.inst] : 0.0;
+    const bool infeasible = t.valid && viol > 0.0 && gm(P.status)[t.inst] == 0;
+    if (!__any(infeasible)) return;
+    CfLds<MMAX, LPI> L(lds + t.g * CfLds<MMAX, LPI>::SZ);
+    if (t.lane < 17) L.wv[t.lane] = P.W[t.lane < 13 ? ext_of(t.lane) : t.lane];
+    __syncthreads();
+    const int N = P.N, n = 4 * N;
+    const size_t eb = (size_t)t.inst * N * 4;
+    gdouble *v = gm(P.v) + eb, *tl = gm(P.tl) + eb, *tu = gm(P.tu) + eb, *ll = gm(P.ll) + eb, *lu = gm(P.lu) + eb,
+            *rg = gm(P.rg) + eb, *Rh = gm(P.Rh) + eb, *g = gm(P.g) + eb, *dva = gm(P.dva) + eb, *dvc = gm(P.dvc) + eb;
+    const gdouble* uit = gm(P.uit) + eb;
+    // ---- start: slacks / multipliers shifted positive (delta form around the unconstrained minimiser)
+    double mu = 0.0, res = 0.0;
+    int iters = 0, status = infeasible ? 2 : 0;
+    bool act = infeasible;
+    {
+        const double mu0 = fmax(P.mu0_scale * viol, P.lam0_min);
+        double smu = 0.0, sres = 0.0;
+        for (int e = t.lane; e < n; e += LPI) {
+            const double wu = L.wv[13 + (e & 3)];
+            if (!infeasible) { Rh[e] = wu; g[e] = 0.0; continue; }   // benign zero solve for the wave-mates
+            const double vv = v[e], uk = uit[e];
+            const double lb = P.u_min - uk, ub = P.u_max - uk;
+            const double tle = fmax(vv - lb, P.thr0), tue = fmax(ub - vv, P.thr0);
+            const double itl = rcp_nr(tle), itu = rcp_nr(tue);
+            const double lle = mu0 * itl, lue = mu0 * itu, rge = -lle + lue;
+            tl[e] = tle; tu[e] = tue; ll[e] = lle; lu[e] = lue; rg[e] = rge;
+            const double rl = vv - lb - tle, ru = ub - vv - tue;
+            const double Dl = lle * itl, Du = lue * itu;
+            Rh[e] = wu + Dl + Du;
+            g[e] = rge + lle + Dl * rl - lue - Du * ru;
+            smu += lle * tle + lue * tue;
+            sres = fmax(sres, fmax(fmax(lle * tle, lue * tue), fmax(fabs(rge), fmax(fabs(rl), fabs(ru)))));
+        }
+        mu = grp_sum<LPI>(smu) / (2.0 * n);
+        res = grp_max<LPI>(sres);
+    }
+    while (__any(act)) {
+        if (act) {
+            if (!(res == res)) { status = 4; act = false; }
+            else if (res <= P.tol) { status = 0; act = false; }
+            else if (iters >= P.max_iter) { status = 2; act = false; }
+        }
+        if (!__any(act)) break;
+        if (act) iters++;
+        // predictor
+        bool fok = csweep_factor<MMAX, LPI, false>(P, t, L);
+        csweep_forward_delta<MMAX, LPI>(P, t, L, P.dva);
+        __syncthreads();
+        double smu;
+        {
+            double a = 1.0;
+            for (int e = t.lane; e < n && act; e += LPI) {
+                const double uk = uit[e], lb = P.u_min - uk, ub = P.u_max - uk;
+                const double rl = v[e] - lb - tl[e], ru = ub - v[e] - tu[e];
+                const double dtl = dva[e] + rl, dtu = -dva[e] + ru;
+                const double dll = -ll[e] - (ll[e] * rcp_nr(tl[e])) * dtl, dlu = -lu[e] - (lu[e] * rcp_nr(tu[e])) * dtu;
+                a = ratio(tl[e], dtl, a); a = ratio(tu[e], dtu, a); a = ratio(ll[e], dll, a); a = ratio(lu[e], dlu, a);
+            }
+            a = grp_min<LPI>(a);
+            double mu_aff = 0.0;
+            for (int e = t.lane; e < n && act; e += LPI) {
+                const double uk = uit[e], lb = P.u_min - uk, ub = P.u_max - uk;
+                const double rl = v[e] - lb - tl[e], ru = ub - v[e] - tu[e];
+                const double dtl = dva[e] + rl, dtu = -dva[e] + ru;
+                const double dll = -ll[e] - (ll[e] * rcp_nr(tl[e])) * dtl, dlu = -lu[e] - (lu[e] * rcp_nr(tu[e])) * dtu;
+                mu_aff += (ll[e] + a * dll) * (tl[e] + a * dtl) + (lu[e] + a * dlu) * (tu[e] + a * dtu);
+            }
+            mu_aff = grp_sum<LPI>(mu_aff) / (2.0 * n);
+            const double sr = mu_aff * rcp_nr(mu);
+            smu = sr * sr * sr * mu;
+            for (int e = t.lane; e < n && act; e += LPI) {
+                const double uk = uit[e], lb = P.u_min - uk, ub = P.u_max - uk;
+                const double rl = v[e] - lb - tl[e], ru = ub - v[e] - tu[e];
+                const double dtl = dva[e] + rl, dtu = -dva[e] + ru;
+                const double itl = rcp_nr(tl[e]), itu = rcp_nr(tu[e]);
+                const double dll = -ll[e] - (ll[e] * itl) * dtl, dlu = -lu[e] - (lu[e] * itu) * dtu;
+                g[e] = (dll * dtl - smu) * itl - (dlu * dtu - smu) * itu;
+            }
+        }
+        __syncthreads();
+        // corrector: same matrix, new gradient
+        fok = csweep_factor<MMAX, LPI, false>(P, t, L) && fok;
+        csweep_forward_delta<MMAX, LPI>(P, t, L, P.dvc);
+        __syncthreads();
+        {
+            double a = 1.0;
+            for (int e = t.lane; e < n && act; e += LPI) {
+                const double uk = uit[e], lb = P.u_min - uk, ub = P.u_max - uk;
+                const double dv = dva[e] + dvc[e];
+                const double rl = v[e] - lb - tl[e], ru = ub - v[e] - tu[e];
+                const double dtla = dva[e] + rl, dtua = -dva[e] + ru;
+                const double itl = rcp_nr(tl[e]), itu = rcp_nr(tu[e]);
+                const double Dl = ll[e] * itl, Du = lu[e] * itu;
+                const double cl = (-ll[e] - Dl * dtla) * dtla, cu = (-lu[e] - Du * dtua) * dtua;
+                const double dtl = dv + rl, dtu = -dv + ru;
+                const double dll = (smu - cl) * itl - ll[e] - Dl * dtl, dlu = (smu - cu) * itu - lu[e] - Du * dtu;
+                a = ratio(tl[e], dtl, a); a = ratio(tu[e], dtu, a); a = ratio(ll[e], dll, a); a = ratio(lu[e], dlu, a);
+            }
+            a = fmin(1.0, P.tau * grp_min<LPI>(a));
+            double smu2 = 0.0, sres = 0.0;
+            for (int e = t.lane; e < n && act; e += LPI) {
+                const double wu = L.wv[13 + (e & 3)];
+                const double uk = uit[e], lb = P.u_min - uk, ub = P.u_max - uk;
+                const double dv = dva[e] + dvc[e];
+                const double rl = v[e] - lb - tl[e], ru = ub - v[e] - tu[e];
+                const double dtla = dva[e] + rl, dtua = -dva[e] + ru;
+                const double itl = rcp_nr(tl[e]), itu = rcp_nr(tu[e]);
+                const double Dl = ll[e] * itl, Du = lu[e] * itu;
+                const double cl = (-ll[e] - Dl * dtla) * dtla, cu = (-lu[e] - Du * dtua) * dtua;
+                const double dtl = dv + rl, dtu = -dv + ru;
+                const double dll = (smu - cl) * itl - ll[e] - Dl * dtl, dlu = (smu - cu) * itu - lu[e] - Du * dtu;
+                const double vn = v[e] + a * dv, tln = tl[e] + a * dtl, tun = tu[e] + a * dtu;
+                const double lln = ll[e] + a * dll, lun = lu[e] + a * dlu, rgn = rg[e] * (1.0 - a);
+                const double rln = vn - lb - tln, run = ub - vn - tun;
+                const double Dln = lln * rcp_nr(tln), Dun = lun * rcp_nr(tun);
+                v[e] = vn; tl[e] = tln; tu[e] = tun; ll[e] = lln; lu[e] = lun; rg[e] = rgn;
+                Rh[e] = wu + Dln + Dun;
+                g[e] = rgn + lln + Dln * rln - lun - Dun * run;
+                smu2 += lln * tln + lun * tun;
+                sres = fmax(sres, fmax(fmax(lln * tln, lun * tun), fmax(fabs(rgn), fmax(fabs(rln), fabs(run)))));
+            }
+            smu2 = grp_sum<LPI>(smu2) / (2.0 * n);
+            sres = grp_max<LPI>(sres);
+            const bool fok_g = grp_min<LPI>(fok ? 1.0 : 0.0) > 0.0;
+            if (act) {
+                mu = smu2;
+                res = fok_g ? sres : nan("");
+            }
+        }
+        __syncthreads();
+    }
+    // ---- expand: roll the final inputs through the stored stage dynamics; new iterate = old + step
+    //      (a failed QP keeps the old iterate)
+    {   // (wave-uniform control flow: the wave-mates walk along with their stores masked)
+        const bool take = infeasible && status != 4;
+        double* xs = L.xs;
+        __syncthreads();
+        if (t.lane < 13) xs[t.lane] = v13(P.x0, t, 1, 0, t.lane) - v13(P.xit, t, N + 1, 0, t.lane);
+        __syncthreads();
+        for (int k = 0; k < N; k++) {
+            double du[4];
+            for (int a = 0; a < 4; a++) du[a] = take ? v[k * 4 + a] : 0.0;
+            if (t.lane < 4 && infeasible) gm(P.uitn)[eb + k * 4 + t.lane] = uit[k * 4 + t.lane] + du[t.lane];
+            double xn = 0.0;
+            if (t.lane < 13) {
+                const double xb = v13(P.xit, t, N + 1, k, t.lane);
+                if (infeasible) gm(P.xitn)[(t.wave * (N + 1) + k) * SZ_V13 + t.q * 13 + t.lane] = xb + (take ? xs[t.lane] : 0.0);
+                xn = v13(P.b, t, N, k, t.lane);
+                for (int c = 0; c < 13; c++) xn += a_elem(P, t, k, t.lane, c) * xs[c];
+                for (int a = 0; a < 4; a++) xn += b_elem(P, t, k, t.lane, a) * du[a];
+            }
+            __syncthreads();
+            if (t.lane < 13) xs[t.lane] = xn;
+            __syncthreads();
+        }
+        if (t.lane < 13 && infeasible) {
+            const double xb = v13(P.xit, t, N + 1, N, t.lane);
+            gm(P.xitn)[(t.wave * (N + 1) + N) * SZ_V13 + t.q * 13 + t.lane] = xb + (take ? xs[t.lane] : 0.0);
+        }
+        if (t.lane == 0 && infeasible) {
+            gm(P.status)[t.inst] = status;
+            gm(P.iters)[t.inst] = iters;
+            gm(P.res)[t.inst] = res;
+            gm(P.head)[t.inst] = N;
+        }
+    }
+}
+
+template <int MMAX, int LPI>
+void launch_pcond_t(const Params& P, hipStream_t st) {
+    constexpr int IPW = 64 / LPI;
+    hipLaunchKernelGGL((k_pcond<MMAX, LPI>), dim3((P.B + IPW - 1) / IPW, P.cond_N2), dim3(64), 0, st, P);
+}
+template <int MMAX, int LPI>
+void launch_cfactor_t(const Params& P, hipStream_t st) {
+    constexpr int IPW = 64 / LPI;
+    hipLaunchKernelGGL((k_cfactor<MMAX, LPI>), dim3((P.B + IPW - 1) / IPW), dim3(64), 0, st, P);
+}
+template <int MMAX, int LPI>
+void launch_cipm_t(const Params& P, hipStream_t st) {
+    constexpr int IPW = 64 / LPI;
+    hipLaunchKernelGGL((k_cipm<MMAX, LPI>), dim3((P.B + IPW - 1) / IPW), dim3(64), 0, st, P);
+}
+
+}  // namespace
+
+// template instances: block lengths up to 2, 5 and 10 stages (lanes per instance chosen so that the
+// dense blocks of a wave's groups fit the 64 KB of static LDS)
+#define CFN_COND_DISPATCH(fn)                              \
+    do {                                                   \
+        const int mm = cond_mmax(P);                       \
+        if (mm <= 2) fn<2, 16>(P, st);                     \
+        else if (mm <= 5) fn<5, 16>(P, st);                \
+        else fn<10, 32>(P, st);                            \
+    } while (0)
+
+void launch_pcond(const Params& P, hipStream_t st) { CFN_COND_DISPATCH(launch_pcond_t); }
+void launch_cfactor(const Params& P, hipStream_t st) { CFN_COND_DISPATCH(launch_cfactor_t); }
+void launch_cipm(const Params& P, hipStream_t st) { CFN_COND_DISPATCH(launch_cipm_t); }
+void launch_qp_cond(const Params& P, hipStream_t st) {
+    launch_pcond(P, st);
+    launch_cfactor(P, st);
+    launch_cforward(P, st);
+    launch_cipm(P, st);
+}
+
+}  // namespace cfn

@@ -93,7 +93,25 @@ struct Params {
     int *blkcnt;                 // per 64-instance group of k_forward: instances per compaction bin [group][32]
     int *done;                   // per instance: 1 = finished by the active-set kernel (k_as), 0 = left for k_ipm_rest
     int *rank;                   // per instance: (bin << 8) | rank among the same-bin instances of its group
+    // partial condensing (cfnmpc_opts.cond_N2 < N): the N stages are regrouped into cond_N2 blocks,
+    // the first cond_rem of them cond_M + 1 stages long, the others cond_M (cond_N2 = 0: off)
+    int cond_N2, cond_M, cond_rem;
+    double *cb;                  // condensed blocks, [instance][block][cb_size(w_max)] (layout: cfnmpc_pcond.hip)
 };
+
+// ---- partial condensing geometry --------------------------------------------------------------
+constexpr int COND_MMAX = 10;   // longest block supported (4 * 10 = 40 condensed inputs)
+__host__ __device__ inline int cond_len(const Params& P, int j) { return j < P.cond_rem ? P.cond_M + 1 : P.cond_M; }
+__host__ __device__ inline int cond_start(const Params& P, int j) {
+    return j < P.cond_rem ? j * (P.cond_M + 1) : P.cond_rem * (P.cond_M + 1) + (j - P.cond_rem) * P.cond_M;
+}
+__host__ __device__ inline int cond_mmax(const Params& P) { return P.cond_M + (P.cond_rem ? 1 : 0); }
+// condensed block of m stages: z = (U (4m), dx (13), 1), w = 4m + 14 entries;
+//   H  : symmetric w x w, packed lower (row r, col c <= r at r (r + 1) / 2 + c)   -- cost 1/2 z'H z
+//   D  : 13 x w row-major                                                        -- dx+ = D z
+__host__ __device__ constexpr int cond_w(int m) { return 4 * m + 14; }
+__host__ __device__ constexpr int cond_tri(int w) { return w * (w + 1) / 2; }
+__host__ __device__ constexpr int cb_size(int mmax) { return cond_tri(cond_w(mmax)) + 13 * cond_w(mmax); }
 
 // linearisation of all instances / of the instances in P.ilist; `chunks` = number of workgroups the
 // (independent) shooting intervals of one 64-instance group are spread over
@@ -102,6 +120,13 @@ void launch_linearise_list(const Params& P, int chunks, hipStream_t st);
 void launch_qp(const Params& P, hipStream_t st);        // = launch_qp_start + launch_qp_ipm
 void launch_qp_start(const Params& P, hipStream_t st);  // factor, forward (+ full step of feasible rows), compact
 void launch_qp_ipm(const Params& P, hipStream_t st);    // interior-point instances (+ their full step)
+// partial condensing path (cfnmpc_pcond.hip): pcond -> condensed Riccati -> forward sweep with expand ->
+// interior point on the condensed QP for the constrained instances
+void launch_pcond(const Params& P, hipStream_t st);
+void launch_cfactor(const Params& P, hipStream_t st);
+void launch_cforward(const Params& P, hipStream_t st);   // (in cfnmpc_kernels.hip: k_forward with condensed gains)
+void launch_cipm(const Params& P, hipStream_t st);
+void launch_qp_cond(const Params& P, hipStream_t st);    // = the four above
 void launch_estimate(int B, const double* meas, double* filt, const double* u, double dt, int use_lpf, double delay,
                      int steps, double* x_est, double* x_pred, hipStream_t st);
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st);

@@ -215,6 +215,20 @@ class BatchSolver:
                                                       b.ctypes.data_as(C.c_void_p)), "cfnmpc_debug_get_linearisation")
         return A, Bm, b
 
+    def get_condensed(self, block):
+        """Partial condensing (cond_N2 > 0): condensed block `block` of every instance after a fresh
+        linearisation + pcond -> (H [B][w][w], D [B][13][w], m)."""
+        N2 = int(self.opts.cond_N2)
+        assert 0 < N2 < self.N
+        mmax = -(-self.N // N2)
+        w = 4 * mmax + 14
+        H = np.zeros((self.B, w, w)); D = np.zeros((self.B, NX, w)); m = C.c_int(0)
+        _check(self._L.cfnmpc_debug_get_condensed(self._h, int(block), H.ctypes.data_as(C.c_void_p), D.ctypes.data_as(C.c_void_p),
+                                                  C.byref(m)), "cfnmpc_debug_get_condensed")
+        wj = 4 * m.value + 14
+        return (H.reshape(-1)[:self.B * wj * wj].reshape(self.B, wj, wj).copy(),      # (the library packs with the block's own w)
+                D.reshape(-1)[:self.B * NX * wj].reshape(self.B, NX, wj).copy(), m.value)
+
     def heads(self):
         h = np.empty(self.B, dtype=np.int32)
         _check(self._L.cfnmpc_debug_get_head(self._h, h.ctypes.data_as(C.c_void_p)), "cfnmpc_debug_get_head")

@@ -83,6 +83,19 @@ typedef struct cfnmpc_opts {
                             back to the interior-point iteration if the set does not settle within
                             12 solves.  0 = interior point only (the reference's QP method class).
                             cfnmpc_get_stats reports active-set solves + interior-point iterations. */
+    int cond_N2;         /* QP: partial condensing (PARTIAL_CONDENSING_HPIPM, generate_c_code.py:140; acados'
+                            qp_solver_cond_N, which the generator leaves at its default): 0 or N (default 0) =
+                            none -- the Riccati sweeps run over the N original stages; 0 < cond_N2 < N =
+                            the N stages are regrouped into cond_N2 blocks of consecutive stages (the first
+                            N mod cond_N2 one stage longer; at most 10 stages per block), the interior states
+                            of each block are eliminated exactly (`pcond`: a QP with cond_N2 stages, 13
+                            states, 4 x block-length inputs), that QP is solved by the Riccati recursion with
+                            one dense Cholesky factorisation per block -- interior point on the same
+                            condensed blocks for the instances whose unconstrained minimiser leaves the box
+                            -- and the solution is expanded through the original stage dynamics.  Same primal
+                            solution (strictly convex QP); active_set / active_horizon do not apply.
+                            Measured slower than the uncondensed path at every N2:
+                            an option for parity with the reference's solver plan, not the default.        */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);
@@ -189,6 +202,12 @@ int cfnmpc_estimate(int batch, const double *meas, double *filt, const double *u
 int cfnmpc_debug_get_linearisation(cfnmpc_solver *s, double *A, double *Bm, double *b);
 /* runs only the linearisation kernel */
 int cfnmpc_debug_linearise(cfnmpc_solver *s, void *stream);
+/* partial condensing (cond_N2 > 0): runs linearisation + pcond and copies condensed block `block`
+ * of every instance to the host as dense arrays in the reference's state order, with
+ * z = (dU (4 m), dx (13), 1), w = 4 m + 14, m = stages of that block:
+ *   H [B][w][w] symmetric (cost 1/2 z'H z; the [w-1][w-1] entry is not defined), D [B][13][w]
+ *   (dx at the start of the next block = D z).  *m_out receives m. */
+int cfnmpc_debug_get_condensed(cfnmpc_solver *s, int block, double *H, double *D, int *m_out);
 /* number of leading stages the last QP's interior-point sweeps covered, per instance [B] (host) */
 int cfnmpc_debug_get_head(cfnmpc_solver *s, int *head);
 

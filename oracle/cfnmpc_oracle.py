@@ -246,6 +246,102 @@ def condense(qp: StageQP):
     return H, h, Gam, g
 
 
+# ----------------------------------------------------------------------------------------
+# Partial condensing (HPIPM d_part_cond, selected by PARTIAL_CONDENSING_HPIPM at
+# generate_c_code.py:140; README.md:77).  acados / HPIPM are not under /root/reference, so this
+# restates the published algorithm: the N-stage QP is regrouped into N2 blocks of consecutive
+# stages; inside a block the interior states are eliminated exactly, leaving a QP with N2 stages,
+# nx = 13 states and nu2 = 4 x (block length) inputs whose solution is the SAME primal point.
+# ----------------------------------------------------------------------------------------
+def block_sizes(N, N2):
+    """Stages per block: N2 blocks, the first N mod N2 one stage longer (even split otherwise)."""
+    m, rem = divmod(N, N2)
+    return [m + 1] * rem + [m] * (N2 - rem)
+
+
+def partial_condense(qp: StageQP, N2):
+    """-> list of blocks, each dict(k0, m, D, H):  with z = (U, dx_{k0}, 1), U = (du_{k0} .. du_{k0+m-1}),
+         dx_{k0+m} = D z                         D = [Bbar (13 x 4m) | Abar (13 x 13) | bbar (13)]
+         cost of stages k0 .. k0+m-1 = 1/2 z'H z  H = [[Rbar, Sbar, rbar], [Sbar', Qbar, qbar], [rbar', qbar', *]]
+    (forward recursion G_{i+1} = A G_i + [B at du_{k0+i}] [b at 1], H += G_i' Q~ G_i)."""
+    blocks = []
+    k0 = 0
+    for m in block_sizes(qp.N, N2):
+        mu = NU * m
+        w = mu + NX + 1
+        G = np.zeros((NX, w))
+        G[:, mu:mu + NX] = np.eye(NX)
+        H = np.zeros((w, w))
+        for i in range(m):
+            k = k0 + i
+            Gq = G.copy()
+            H += Gq.T @ (qp.Qd[:, None] * Gq)                      # 1/2 dx' Q dx
+            H[:, w - 1] += Gq.T @ qp.q[k]                            # q_k' dx
+            H[w - 1, :] += Gq.T @ qp.q[k]
+            sl = slice(NU * i, NU * (i + 1))
+            H[sl, sl] += np.diag(qp.Rd)                              # 1/2 du' R du
+            H[sl, w - 1] += qp.r[k]                                  # r_k' du
+            H[w - 1, sl] += qp.r[k]
+            G = qp.A[k] @ G
+            G[:, sl] += qp.B[k]
+            G[:, w - 1] += qp.b[k]
+        H[w - 1, w - 1] = 0.0
+        blocks.append(dict(k0=k0, m=m, D=G, H=H))
+        k0 += m
+    return blocks
+
+
+def riccati_condensed(blocks, QNd, qN, dx0, diag_add=None):
+    """Riccati recursion over the condensed stages (one mu x mu Cholesky per block).  diag_add:
+    optional list of per-block vectors added to the diagonal of Rbar (interior-point barrier).
+    -> (U per block, dx at the block starts incl. the terminal state)"""
+    P = np.diag(QNd).astype(np.float64)
+    p = np.asarray(qN, dtype=np.float64).copy()
+    Ks, ds = [], []
+    for j in range(len(blocks) - 1, -1, -1):
+        bk = blocks[j]
+        mu = NU * bk["m"]
+        w = mu + NX + 1
+        E = np.vstack([bk["D"], np.eye(w)[w - 1]])                  # (14 x w): [dx+; 1] = E z
+        Pt = np.zeros((NX + 1, NX + 1))
+        Pt[:NX, :NX] = P; Pt[:NX, NX] = p; Pt[NX, :NX] = p
+        Hh = bk["H"] + E.T @ Pt @ E
+        if diag_add is not None:
+            Hh[np.arange(mu), np.arange(mu)] += diag_add[j]
+        L = np.linalg.cholesky(Hh[:mu, :mu])
+        KD = np.linalg.solve(L.T, np.linalg.solve(L, Hh[:mu, mu:]))  # [K | d]: U = -K dx - d
+        Ks.append(KD[:, :NX]); ds.append(KD[:, NX])
+        Sch = Hh[mu:, mu:] - Hh[mu:, :mu] @ KD
+        P = 0.5 * (Sch[:NX, :NX] + Sch[:NX, :NX].T)
+        p = Sch[:NX, NX].copy()
+    Ks.reverse(); ds.reverse()
+    xs = [np.asarray(dx0, dtype=np.float64)]
+    Us = []
+    for j, bk in enumerate(blocks):
+        mu = NU * bk["m"]
+        U = -Ks[j] @ xs[-1] - ds[j]
+        Us.append(U)
+        xs.append(bk["D"] @ np.concatenate([U, xs[-1], [1.0]]))
+    return Us, np.array(xs)
+
+
+def expand_condensed(qp: StageQP, Us):
+    """Recover every stage's (dx, du) from the condensed inputs: roll the ORIGINAL stage dynamics."""
+    du = np.concatenate(Us).reshape(qp.N, NU)
+    dx = np.zeros((qp.N + 1, NX))
+    dx[0] = qp.dx0
+    for k in range(qp.N):
+        dx[k + 1] = qp.A[k] @ dx[k] + qp.B[k] @ du[k] + qp.b[k]
+    return dx, du
+
+
+def solve_qp_pcond(qp: StageQP, N2):
+    """Unconstrained minimiser through partial condensing (pcond -> condensed Riccati -> expand)."""
+    blocks = partial_condense(qp, N2)
+    Us, _ = riccati_condensed(blocks, qp.QNd, qp.q[qp.N], qp.dx0)
+    return expand_condensed(qp, Us)
+
+
 def solve_qp_dense(qp: StageQP, tol=1e-11, max_iter=100):
     """Independent high-accuracy solver: primal-dual interior point on the condensed dense QP
     (numpy Cholesky).  Returns dict(dx, du, lam_l, lam_u, iters)."""
