@@ -191,9 +191,14 @@ __global__ __launch_bounds__(64) void k_pcond(Params P) {
             const int c = ca < 4 * (i + 1) ? ca : mu + (ca - 4 * (i + 1));
             double gc[13], gn[13];
             for (int l = 0; l < 13; l++) gc[l] = G[l * w + c];
+            // A is block upper triangular in the internal order p | v | q | w with an identity p-block
+            // (cfnmpc_ws.hpp): row r only meets the columns from its own block on
+#pragma unroll
             for (int r = 0; r < 13; r++) {
-                double acc = 0.0;
-                for (int l = 0; l < 13; l++) acc += Am[r * 13 + l] * gc[l];
+                const int l0 = r < 6 ? 3 : (r < 10 ? 6 : 10);
+                double acc = r < 3 ? gc[r] : 0.0;
+#pragma unroll
+                for (int l = l0; l < 13; l++) acc += Am[r * 13 + l] * gc[l];
                 gn[r] = acc;
             }
             if (c >= 4 * i && c < 4 * i + 4) for (int r = 0; r < 13; r++) gn[r] += Bm[r * 4 + (c - 4 * i)];
@@ -226,7 +231,6 @@ struct CfLds {   // LDS carve-up of one group in k_cfactor / k_cipm
 // are zero.  On entry Pt = augmented cost-to-go behind the block, on exit in front of it.
 template <int MMAX, int LPI, bool ABSOLUTE>
 __device__ __forceinline__ bool cfactor_block(const Params& P, const Grp<LPI>& t, const int j, CfLds<MMAX, LPI>& L) {
-    constexpr int NS = (cond_w(MMAX) + LPI - 1) / LPI;   // rows a lane owns
     const int N = P.N;
     const int m = cond_len(P, j), k0 = cond_start(P, j);
     const int mu = 4 * m, w = mu + 14, aff = w - 1;
@@ -260,42 +264,39 @@ __device__ __forceinline__ bool cfactor_block(const Params& P, const Grp<LPI>& t
         }
     __syncthreads();
     // right-looking Cholesky of the input block (columns 0 .. mu-1); the trailing rows / columns carry
-    // L_xu and the Schur complement.  A lane owns the rows lane, lane + LPI, ...
+    // L_xu and the Schur complement.  Both phases of a column are spread over all lanes of the group:
+    // the scaling over the rows below the pivot, the rank-1 update over the (row, column) pairs of the
+    // trailing triangle.
     bool ok = true;
     for (int k = 0; k < mu; k++) {
         const double piv = H[tri(k, k)];
         ok = ok && (piv > 0.0);
         const double inv = rsqrt_nr(piv);
-        double lr[NS];
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const int r = t.lane + LPI * s;
-            lr[s] = 0.0;
-            if (r > k && r < w) {
-                lr[s] = H[tri(r, k)] * inv;
-                H[tri(r, k)] = lr[s];      // (only its owner touches H[r][k] in this phase)
-            }
-        }
+        for (int r = k + 1 + t.lane; r < w; r += LPI) H[tri(r, k)] *= inv;
         if (t.lane == 0) L.dinv[k] = inv;
         __syncthreads();
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const int r = t.lane + LPI * s;
-            if (r > k && r < w)
-                for (int c = k + 1; c <= r; c++) H[tri(r, c)] -= lr[s] * H[tri(c, k)];
+        const int sdim = w - 1 - k, T = (sdim * (sdim + 1)) / 2;
+        for (int e = t.lane; e < T; e += LPI) {
+            int rr = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            rr += ((rr + 1) * (rr + 2)) / 2 <= e ? 1 : 0;
+            rr -= (rr * (rr + 1)) / 2 > e ? 1 : 0;
+            const int cc = e - (rr * (rr + 1)) / 2;
+            const int r = k + 1 + rr, c = k + 1 + cc;
+            H[tri(r, c)] -= H[tri(r, k)] * H[tri(c, k)];
         }
         __syncthreads();
     }
-    // [K | d]' = L_xu L_uu^-1 by back-substitution, one of the 14 trailing rows per lane, in place
-    if (t.lane < 14) {
-        const int R = mu + t.lane;
-        for (int c = mu - 1; c >= 0; c--) {
-            double y = H[tri(R, c)];
-            for (int c2 = c + 1; c2 < mu; c2++) y -= H[tri(R, c2)] * H[tri(c2, c)];
-            H[tri(R, c)] = y * L.dinv[c];
+    // [K | d]' = L_xu L_uu^-1 for the 14 trailing rows, right-looking from the last column: finish
+    // column c, then take its contribution out of the columns before it (14 x c entries in parallel)
+    for (int c = mu - 1; c >= 0; c--) {
+        if (t.lane < 14) H[tri(mu + t.lane, c)] *= L.dinv[c];
+        __syncthreads();
+        for (int e = t.lane; e < 14 * c; e += LPI) {
+            const int c2 = e / 14, i = e - c2 * 14;
+            H[tri(mu + i, c2)] -= H[tri(mu + i, c)] * H[tri(c, c2)];
         }
+        __syncthreads();
     }
-    __syncthreads();
     // gains per ORIGINAL stage in the layout of the uncondensed path: lane a of stage k holds K[a][0..12]
     for (int e = t.lane; e < 13 * mu; e += LPI) {
         const int c = e / 13, l = e - c * 13;
@@ -580,14 +581,16 @@ void launch_cipm_t(const Params& P, hipStream_t st) {
 
 }  // namespace
 
-// template instances: block lengths up to 2, 5 and 10 stages (lanes per instance chosen so that the
-// dense blocks of a wave's groups fit the 64 KB of static LDS)
+// template instances: block lengths up to 2, 5 and 10 stages; one instance per wavefront (LPI = 64):
+// the dense blocks of an instance take 6 - 26 KB of LDS, so a CU holds as many INSTANCES either way,
+// and with all 64 lanes on one instance every phase finishes ~4x sooner (measured: 16 lanes per
+// instance 3 - 5x slower) and the interior-point kernel only occupies waves that have work
 #define CFN_COND_DISPATCH(fn)                              \
     do {                                                   \
         const int mm = cond_mmax(P);                       \
-        if (mm <= 2) fn<2, 16>(P, st);                     \
-        else if (mm <= 5) fn<5, 16>(P, st);                \
-        else fn<10, 32>(P, st);                            \
+        if (mm <= 2) fn<2, 64>(P, st);                     \
+        else if (mm <= 5) fn<5, 64>(P, st);                \
+        else fn<10, 64>(P, st);                            \
     } while (0)
 
 void launch_pcond(const Params& P, hipStream_t st) { CFN_COND_DISPATCH(launch_pcond_t); }

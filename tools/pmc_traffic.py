@@ -16,7 +16,10 @@ def per_kernel(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"]
+            if "(anonymous namespace)::" in name:      # templated kernels of cfnmpc_pcond.hip
+                name = "cfn::" + name.split("(anonymous namespace)::")[1]
+            acc[name.split("(")[0]].append(float(r["Counter_Value"]))
     return {k: sum(v[-max(1, len(v) // 3):]) / max(1, len(v) // 3) for k, v in acc.items()}
 
 
@@ -30,8 +33,9 @@ def main():
             continue
         r, w = 2.0 * rd.get(k, 0.0) * 1024.0, wr.get(k, 0.0) * 1024.0
         kernels[k] = {"read_bytes": r, "write_bytes": w, "total_bytes": r + w}
-    qp = sum(kernels[k]["total_bytes"] for k in ("cfn::k_factor", "cfn::k_forward", "cfn::k_compact", "cfn::k_scatter", "cfn::k_as",
-                       "cfn::k_ipm_rest", "cfn::k_ipm") if k in kernels)
+    qp = sum(v["total_bytes"] for k, v in kernels.items() if k.split("<")[0] in (
+        "cfn::k_factor", "cfn::k_forward", "cfn::k_compact", "cfn::k_scatter", "cfn::k_as", "cfn::k_ipm_rest", "cfn::k_ipm",
+        "cfn::k_pcond", "cfn::k_cfactor", "cfn::k_cforward", "cfn::k_cipm"))
     json.dump({"batch": batch,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KB); reads = 2 x FETCH_SIZE "
                        "(gfx950 correction, see tools/pmc_traffic.py); average of the last third of the dispatches of "
@@ -42,7 +46,7 @@ def main():
     with open(out_csv, "w") as f:
         f.write("kernel,read_GB,write_GB,total_GB\n")
         for k, v in kernels.items():
-            f.write(f"{k},{v['read_bytes'] / 1e9:.4f},{v['write_bytes'] / 1e9:.4f},{v['total_bytes'] / 1e9:.4f}\n")
+            f.write(f"\"{k}\",{v['read_bytes'] / 1e9:.4f},{v['write_bytes'] / 1e9:.4f},{v['total_bytes'] / 1e9:.4f}\n")
         f.write(f"QP phase (factor+forward+compact+scatter+as+ipm_rest | ipm),,,{qp / 1e9:.4f}\n")
         f.write(f"RTI step (linearise + QP phase),,,{(qp + kernels.get('cfn::k_linearise', {}).get('total_bytes', 0.0)) / 1e9:.4f}\n")
     print(open(out_csv).read())
