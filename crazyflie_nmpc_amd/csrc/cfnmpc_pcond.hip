@@ -2,9 +2,8 @@
 //
 // Role in the reference: PARTIAL_CONDENSING_HPIPM (generate_c_code.py:140, README.md:77) -- HPIPM's
 // d_part_cond / d_ocp_qp_ipm / expand, none of which is under /root/reference (empty acados
-// submodule); this file implements the published algorithm from the mathematics
-// (oracle/cfnmpc_oracle.py: partial_condense / riccati_condensed / expand_condensed are the CPU
-// restatement it is tested against):
+// submodule); this file implements the published algorithm from the mathematics (the tests hold a
+// numpy restatement -- partial_condense / riccati_condensed / expand_condensed -- as the checker):
 //
 //   k_pcond   : the N stages are regrouped into N2 blocks of m consecutive stages.  With
 //               z = (dU, dx, 1), dU = the 4 m inputs of the block, dx = the state at its start:
