@@ -7,7 +7,7 @@ import os
 
 NX, NU, NY, NYN = 13, 4, 17, 13
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcfnmpc.so")
+LIB_PATH = os.environ.get("CFNMPC_LIB") or os.path.join(_HERE, "libcfnmpc.so")   # (CFNMPC_LIB: development aid, A/B builds)
 
 # every symbol include/cfnmpc.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
@@ -29,7 +29,7 @@ class Opts(C.Structure):
                 ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
                 ("lam0_min", C.c_double), ("mu0_scale", C.c_double), ("active_horizon", C.c_int), ("ah_margin", C.c_double),
-                ("ah_extra", C.c_int), ("overlap_linearise", C.c_int), ("active_set", C.c_int), ("cond_N2", C.c_int)]
+                ("ah_extra", C.c_int), ("overlap_linearise", C.c_int), ("active_set", C.c_int), ("forward_sweep", C.c_int), ("cond_N2", C.c_int)]
 
 
 _lib = None

@@ -68,6 +68,7 @@ struct DeviceGuard {
 };
 
 constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the count
+constexpr int FORWARD_RG_BELOW = 6144;        // measured cross-over of the two forward sweeps
 
 template <typename T>
 int dev_alloc(cfnmpc_solver* s, T** p, size_t count) {
@@ -155,6 +156,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->ah_extra = 4;
     o->overlap_linearise = 0;
     o->active_set = 1;
+    o->forward_sweep = 0;
     o->cond_N2 = 0;
 }
 
@@ -218,6 +220,8 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.ah_margin = o.ah_margin;
     P.ah_extra = o.ah_extra;
     P.active_set = o.active_set ? 1 : 0;
+    if (o.forward_sweep < 0 || o.forward_sweep > 2) { delete s; return CFNMPC_EINVAL; }
+    P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && batch < FORWARD_RG_BELOW) ? 1 : 0;
     P.cond_N2 = cond_N2;
     P.cond_M = cond_N2 ? o.N / cond_N2 : 0;
     P.cond_rem = cond_N2 ? o.N % cond_N2 : 0;

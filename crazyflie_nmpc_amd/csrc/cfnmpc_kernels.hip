@@ -1234,6 +1234,90 @@ __global__ __launch_bounds__(64) void k_cforward(Params P) {
     forward_body<true>(P, xs, cs, sflag);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Start solve, forward sweep on the STORED stage blocks -- row groups, four instances per wave.
+// Same results as k_forward up to rounding (dx+ = A dx + B du + b from the stored A, B, b instead of
+// the directional derivative of the RK4 map).  For SMALL fleets: k_forward runs 64 instances per wave,
+// i.e. B / 64 waves of 50 sequential stages at ~4 us each -- with a few thousand instances most SIMDs
+// idle and the step waits for that chain; here a stage costs one 13-term broadcast-FMA chain per
+// product (~1.5 us) and the blocks it reads were written two kernels ago (L2 / MALL-resident at this
+// size).  At large batches the streaming of A and B costs more than the arithmetic saves
+// (DESIGN.md section 5.4), so the choice is by batch size (cfnmpc_opts.forward_sweep).
+// The compaction ranks (per 64-instance group, as k_forward leaves them) come from k_rank.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_forward_rg(Params P) {
+    const Lane t = lane_id(P);
+    const int N = P.N;
+    const double margin = P.ah_margin * (P.u_max - P.u_min);
+    const int a = t.L & 3;
+    const bool lo4 = t.L < 4;
+    double xbcur = ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t), xbnxt;
+    double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - xbcur;
+    FwdIn<true> cur, nxt;
+    load_fwd<true>(P, t, 0, cur);
+    double ucur = gm(P.uit)[i4(P, t, 0, a)], unxt;
+    double viol = 0.0;
+    int last_tight = -1, nviol = 0;
+    bool sawnan = false;
+    for (int k = 0; k < N; k++) {
+        const int kn = imin(k + 1, N - 1);
+        load_fwd<true>(P, t, kn, nxt);
+        unxt = gm(P.uit)[i4(P, t, kn, a)];
+        xbnxt = ld13(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);
+        st13(blk(P.xitn, t, N + 1, k, SZ_V13), t, xbcur + x);
+        const double v = feedback<true>(t, cur, x);      // lanes a < 4: du = -K dx - d
+        if (lo4) {
+            const double lb = P.u_min - ucur, ub = P.u_max - ucur;
+            viol = fmax(viol, fmax(lb - v, v - ub));
+            nviol += (v < lb || v > ub) ? 1 : 0;
+            if (v < lb + margin || v > ub - margin) last_tight = k;
+            sawnan = sawnan || !(v == v);
+            gm(P.v)[i4(P, t, k, t.L)] = v;
+            gm(P.uitn)[i4(P, t, k, t.L)] = ucur + v;
+        }
+        double vr[4];
+        SFOR(c, 0, 4, { vr[c] = bc<c>(v); });
+        x = propagate<true>(t, cur, x, vr);
+        cur = nxt;
+        ucur = unxt;
+        xbcur = xbnxt;
+    }
+    st13(blk(P.xitn, t, N + 1, N, SZ_V13), t, xbcur + x);
+    // reductions over the four input lanes of the row
+    viol = row_max(lo4 ? viol : 0.0);
+    nviol = (int)row_sum(lo4 ? (double)nviol : 0.0);
+    last_tight = (int)row_max(lo4 ? (double)last_tight : -1.0);
+    sawnan = row_max((lo4 && sawnan) ? 1.0 : 0.0) > 0.0;
+    if (sawnan) viol = nan("");
+    const bool okf = t.valid && gm(P.status)[imin(t.inst, P.B - 1)] == 0;
+    const bool bad = t.valid && (!okf || !(viol == viol));
+    const bool infeasible = t.valid && !bad && (viol > 0.0);
+    if (t.L == 0 && t.valid) {
+        const int head = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
+        gm(P.viol)[t.inst] = infeasible ? viol : 0.0;
+        gm(P.status)[t.inst] = bad ? 4 : 0;
+        gm(P.iters)[t.inst] = 0;
+        gm(P.res)[t.inst] = bad ? nan("") : 0.0;
+        gm(P.head)[t.inst] = head;
+        // compaction bin (head class x difficulty), ranked per 64-instance group by k_rank
+        gm(P.rank)[t.inst] = infeasible ? head_cls(P, head) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
+    }
+    keep_row(P, t, bad);   // a failed row keeps its iterate: old -> new
+}
+// per 64-instance group: bin counts and ranks of the constrained instances (the second half of
+// k_forward's epilogue, for the row-group forward sweep)
+__global__ __launch_bounds__(64) void k_rank(Params P) {
+    const int tid = threadIdx.x;
+    const int raw = blockIdx.x * 64 + tid;
+    const int hc = raw < P.B ? gm(P.rank)[raw] : -1;
+    const unsigned long long below = (1ull << tid) - 1ull;
+    SFOR(c, 0, N_BIN, {
+        const unsigned long long m = __ballot(hc == c);
+        if (hc == c) gm(P.rank)[raw] = (c << 8) | __popcll(m & below);
+        if (tid == c) gm(P.blkcnt)[blockIdx.x * BIN_STRIDE + c] = __popcll(m);
+    });
+}
+
 // Stable compaction of the instances that need the interior-point method, grouped by head
 // class (largest first) so that the four rows of a wave work on similar horizons.  k_forward
 // left per-group class counts and per-instance ranks; k_compact (one block) turns the counts
@@ -2005,7 +2089,12 @@ void launch_linearise_list(const Params& P, int chunks, hipStream_t st) {
 }
 void launch_qp_start(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
-    hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+    if (P.forward_rg) {
+        hipLaunchKernelGGL(k_forward_rg, dim3(P.NW), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_rank, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+    } else {
+        hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+    }
     hipLaunchKernelGGL(k_compact, dim3(N_BIN), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_scatter, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
 }

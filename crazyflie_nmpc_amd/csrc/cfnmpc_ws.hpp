@@ -95,6 +95,7 @@ struct Params {
     int *rank;                   // per instance: (bin << 8) | rank among the same-bin instances of its group
     // partial condensing (cfnmpc_opts.cond_N2 < N): the N stages are regrouped into cond_N2 blocks,
     // the first cond_rem of them cond_M + 1 stages long, the others cond_M (cond_N2 = 0: off)
+    int forward_rg;              // 1: forward sweep of the start solve on the stored blocks (k_forward_rg; small fleets)
     int cond_N2, cond_M, cond_rem;
     double *cb;                  // condensed blocks, [instance][block][cb_size(w_max)] (layout: cfnmpc_pcond.hip)
 };

@@ -83,6 +83,12 @@ typedef struct cfnmpc_opts {
                             back to the interior-point iteration if the set does not settle within
                             12 solves.  0 = interior point only (the reference's QP method class).
                             cfnmpc_get_stats reports active-set solves + interior-point iterations. */
+    int forward_sweep;   /* start solve, forward sweep: 1 = matrix-free, one instance per lane (dx+ = A dx + B du + b
+                            as the directional derivative of the RK4 map: fewest bytes, B / 64 wavefronts);
+                            2 = on the stored (A, B, b), four instances per wavefront (16 x more wavefronts, a
+                            shorter dependent chain per stage: faster while the fleet is too small to fill the
+                            GPU); 0 (default) = by batch size (2 below 6144 instances: measured cross-over).  Same results to
+                            rounding.                                                                        */
     int cond_N2;         /* QP: partial condensing (PARTIAL_CONDENSING_HPIPM, generate_c_code.py:140; acados'
                             qp_solver_cond_N, which the generator leaves at its default): 0 or N (default 0) =
                             none -- the Riccati sweeps run over the N original stages; 0 < cond_N2 < N =

@@ -505,3 +505,41 @@ def test_create_rejects_bad_options_and_windows_without_trajectory(oracle):
     ref.set_x0(x0); ref.init_iterate(INIT_HOVER); ref.set_yref(np.tile(yr, (B, 1, 1)), np.tile(ye, (B, 1)))
     ref.solve(1)
     assert np.array_equal(ref.get_u(0), s2.get_u(0))
+
+
+@pytest.mark.parametrize("B", [3, 130, 7000])
+def test_forward_sweep_variants_agree(oracle, cref, B):
+    """cfnmpc_opts.forward_sweep: the matrix-free forward sweep (1, the large-batch kernel) and the
+    sweep on the stored blocks (2, the small-batch kernel) give the same closed loops to rounding --
+    and the default picks by batch size; both against the CPU restatement at 1e-8."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(17)
+    x0 = oracle.sample_hover_x0(rng, B, scale=1.3)
+    yr, ye = oracle.regulation_yref(50, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    sol = {fs: BatchSolver(B, default_opts(forward_sweep=fs)) for fs in (0, 1, 2)}
+    for s in sol.values():
+        s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    nchk = min(B, 64)
+    xr = np.repeat(x0[:nchk, None, :], 51, 1).copy(); ur = np.full((nchk, 50, 4), HOV)
+    opts = cref.default_opts(active_set=1)
+    x = x0.copy()
+    for t in range(6):
+        res = {}
+        for fs, s in sol.items():
+            s.set_x0(x); s.solve(1)
+            st, it, _ = s.stats()
+            assert (st == 0).all()
+            res[fs] = s.get_iterate() + (it,)
+        assert np.abs(res[1][0] - res[2][0]).max() < 1e-9 and np.abs(res[1][1] - res[2][1]).max() < 1e-9
+        assert ((res[1][2] > 0) == (res[2][2] > 0)).all()
+        same = 2 if B < 6144 else 1
+        assert np.array_equal(res[0][0], res[same][0]) and np.array_equal(res[0][1], res[same][1])
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x[:nchk].copy(), yref[:nchk], yref_e[:nchk], nthreads=0)
+        assert np.abs(res[2][1][:nchk] - ur).max() < 1e-8 and np.abs(res[2][0][:nchk] - xr).max() < 1e-8
+        xr[:] = res[2][0][:nchk]; ur[:] = res[2][1][:nchk]
+        for fs, s in sol.items():          # keep the three solvers on ONE trajectory (that of variant 2)
+            if fs != 2:
+                s.set_iterate(res[2][0], res[2][1])
+        x = sim(x, res[2][1][:, 0, :].copy(), T=0.015, steps=1)
