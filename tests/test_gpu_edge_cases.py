@@ -122,14 +122,14 @@ def test_setters_getters_and_weights(oracle, cref):
     s.set_x0(x0); s.set_yref(yref, yref_e)
     xit = np.repeat(x0[:, None, :], N + 1, 1).copy(); uit = np.full((B, N, 4), HOV)
     s.set_iterate(xit, uit); s.solve(1)
-    opts = cref.default_opts()
+    opts = cref.default_opts(active_set=1)     # the engine's default QP method on both sides: exact solutions
     for i in range(17):
         opts.W[i] = W[i]
     for i in range(13):
         opts.WN[i] = WN[i]
     cref.rti_step(opts, xit, uit, x0.copy(), yref, yref_e, nthreads=0)
     xg, ug = s.get_iterate()
-    assert np.abs(ug - uit).max() < 1e-5 and np.abs(xg - xit).max() < 1e-5
+    assert np.abs(ug - uit).max() < 1e-8 and np.abs(xg - xit).max() < 1e-8
     with pytest.raises(CfnmpcError):
         s.set_weights(np.zeros(17), None)
 

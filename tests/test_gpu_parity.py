@@ -104,6 +104,15 @@ def test_closed_loop_rti_matches_oracle(oracle, cref, init, active_horizon, tol,
             assert np.abs(ug[same] - ur[same]).max() < 1e-8, t     # kRPM
             assert np.abs(xg[same] - xr[same]).max() < 1e-8, t
             assert np.abs(ug - ur).max() < 1e-5 and np.abs(xg - xr).max() < 1e-5, t  # borderline exits: tol-level
+        elif active_set and init != "hover":
+            # cold start: the same algorithm on both sides (active-set solves, interior point at `tol` for
+            # the instances whose active set does not settle) -- wherever the solve counts coincide the
+            # iterates agree at FP64 level; an interior-point fall-back that exits one iteration apart
+            # differs at the level of its tolerance
+            same = it == it_r
+            assert same.mean() > 0.9, (t, same.mean())
+            assert np.abs(ug[same] - ur[same]).max() < 1e-8 and np.abs(xg[same] - xr[same]).max() < 1e-8, t
+            assert np.abs(ug - ur).max() < strict and np.abs(xg - xr).max() < strict, (t, np.abs(ug - ur).max())
         else:
             assert np.abs(ug - ur).max() < strict and np.abs(xg - xr).max() < strict, (t, np.abs(ug - ur).max())
             if active_set and init == "hover":
