@@ -28,7 +28,8 @@ Also on the same line (rank 0, N = 1):
                   steps, all usable cores), B-mix (N in {30, 50, 100});
   sensitivity  -- what the headline depends on: interior point only (active_set = 0), harder
                   disturbances (kick scale x2, x3 -> larger constrained fraction), config C2
-                  (batch 4096) and config C4 (figure-8 tracking).
+                  (batch 4096), config C4 (figure-8 tracking), config C5 (mixed horizons, delay-
+                  compensated x0).
 """
 from __future__ import annotations
 
@@ -240,6 +241,75 @@ class Fleet:
         self.solver.close()
 
 
+def mixed_horizon_run(batch, dev, rng, steps, warmup):
+    """Config C5: `batch` vehicles with N in {30, 50, 100} (one cfnmpc_fleet = one solver per horizon
+    bucket behind one handle), regulation targets U(-1,1)^2 x U(0.2,1); the plant applies every input 60 ms
+    = 4 sampling periods after it was computed (the communication delay the reference compensates,
+    acados_mpc.cpp:624, launch/acados_predictor.launch:62) and x0 is the prediction of the state over that
+    delay: the predictor kernel (crazyflie_acados_sim_solve's batch form, acados_estimator.cpp:573-593)
+    applied to the four inputs in flight, oldest first.  (The reference's estimator holds the LATEST input over
+    the whole delay; with raw motor speeds as plant inputs -- no onboard attitude loop in between -- that
+    approximation destabilises the closed loop, measured: the fleet diverges within 60 steps.)  Closed loop,
+    staggered kicks (a kicked vehicle restarts with hover inputs in flight; keeping stale inputs in flight
+    across the jump makes a handful of vehicles per step fall back to 30 - 50 interior-point iterations,
+    which then set the duration of the whole fleet's step: 15 - 24 ms instead of 5.8 ms, measured).  -> dict for the `sensitivity` block."""
+    import torch
+    from crazyflie_nmpc_amd import sim
+    from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    from crazyflie_nmpc_amd.synthetic import HOV_W, sample_hover_x0
+    horizons = rng.choice([30, 50, 100], size=batch)
+    fleet = MixedHorizonFleet(horizons)
+    tgt = np.concatenate([rng.uniform(-1, 1, (batch, 2)), rng.uniform(0.2, 1.0, (batch, 1))], axis=1)
+    fleet.set_regulation(tgt, HOV_W)
+    off = np.concatenate([tgt - [0.0, 0.0, 0.4], np.zeros((batch, 10))], axis=1)
+    x = torch.from_numpy(sample_hover_x0(rng, batch) + off).to(dev)
+    xn, xp = torch.empty_like(x), torch.empty_like(x)
+    u0 = torch.full((batch, 4), HOV_W, dtype=torch.float64, device=dev)
+    uq = [u0.clone() for _ in range(4)]           # inputs in flight: computed at t - 4 .. t - 1
+    cohort = (batch + KICK_PERIOD - 1) // KICK_PERIOD
+    kicks = torch.from_numpy(sample_hover_x0(rng, cohort * KICK_PERIOD).reshape(KICK_PERIOD, cohort, 13)).to(dev)
+    offd = torch.from_numpy(off).to(dev)
+    fleet.set_x0(x); fleet.init_iterate(INIT_HOVER)
+    t = 0
+
+    def step():
+        nonlocal x, xn, t
+        c0 = (t % KICK_PERIOD) * cohort
+        c1 = min(c0 + cohort, batch)
+        nonlocal xp
+        if c1 > c0:   # a kicked vehicle is a fresh one: new state, hover inputs in flight
+            x[c0:c1].copy_(kicks[t % KICK_PERIOD, : c1 - c0] + offd[c0:c1])
+            for q in uq:
+                q[c0:c1] = HOV_W
+        sim(x, uq[t % 4], T=0.015, steps=1, out=xp)   # delay compensation: through the four inputs in flight
+        for j in (1, 2, 3):
+            sim(xp, uq[(t + j) % 4], T=0.015, steps=1, out=xn)
+            xp, xn = xn, xp
+        fleet.set_x0(xp); fleet.solve(1); fleet.get_u(0, u0)
+        sim(x, uq[t % 4], T=0.015, steps=1, out=xn)   # the plant sees the inputs computed 4 periods ago
+        uq[t % 4].copy_(u0)
+        x, xn = xn, x
+        t += 1
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    st, it, _ = fleet.stats()
+    out = {"value": batch * steps / el, "stage_steps_per_s": float(horizons.sum()) * steps / el, "ms_per_step": el / steps * 1e3,
+           "frac_constrained": float((it > 0).mean()), "mean_qp_solves": float(it.mean()), "status_ok_frac": float((st == 0).mean()),
+           "buckets": {int(n): int((horizons == n).sum()) for n in (30, 50, 100)}}
+    fleet.close()
+    del fleet
+    torch.cuda.empty_cache()
+    return out
+
+
 def timed_run(fleet, steps, warmup, barrier):
     """W untimed + exactly K timed steps between barrier + synchronize; the step's kernels are
     bracketed by HIP events on the launch stream during the SAME K steps (cfnmpc_set_profiling).
@@ -370,6 +440,7 @@ def main():
         extras["config_C2_batch_4096"] = brief(measure(4096, 40, 40, seed_off=6))
         extras["batch_8192 (one GPU's share of 65536 at 8 GPUs)"] = brief(measure(8192, 40, 40, seed_off=7))
         extras["config_C4_figure8_tracking"] = brief(measure(B_rank, 20, ws, workload="figure8", seed_off=8))
+        extras["config_C5_mixed_horizons_30_50_100_delay_compensated"] = mixed_horizon_run(B_rank, dev, np.random.default_rng(seed + 9000), 20, ws)
 
     if rank == 0:
         r = main_run

@@ -79,6 +79,25 @@ class MixedHorizonFleet:
         _check(self._L.cfnmpc_fleet_set_weights(self._h, None if w is None else w.ctypes.data_as(C.c_void_p),
                                                 None if wn is None else wn.ctypes.data_as(C.c_void_p)), "cfnmpc_fleet_set_weights")
 
+    def set_box(self, u_min, u_max):
+        _check(self._L.cfnmpc_fleet_set_box(self._h, float(u_min), float(u_max)), "cfnmpc_fleet_set_box")
+
+    def get_cmd(self, cmd_vel=None, motvel=None):
+        """Output stage of the reference node for the whole fleet (cfnmpc_fleet_get_cmd)."""
+        if cmd_vel is None:
+            cmd_vel = np.empty((self.B, 4))
+        if motvel is None:
+            if type(cmd_vel).__module__.startswith("torch"):
+                import torch
+                motvel = torch.empty((self.B, 4), dtype=torch.int32, device=cmd_vel.device)
+            else:
+                motvel = np.empty((self.B, 4), dtype=np.int32)
+        p, dev, st, _k = _arg(cmd_vel, (self.B, 4))
+        pm, devm, _s, _k2 = _arg(motvel, (self.B, 4), np.int32)
+        assert dev == devm
+        _check(self._L.cfnmpc_fleet_get_cmd(self._h, p, pm, dev, st), "cfnmpc_fleet_get_cmd")
+        return cmd_vel, motvel
+
     def init_iterate(self, mode, stream=None):
         _check(self._L.cfnmpc_fleet_init_iterate(self._h, int(mode), C.c_void_p(stream or 0)), "cfnmpc_fleet_init_iterate")
 
