@@ -20,6 +20,9 @@ SYMBOLS = [
     "cfnmpc_fleet_num_buckets", "cfnmpc_fleet_bucket", "cfnmpc_fleet_workspace_bytes", "cfnmpc_fleet_set_x0",
     "cfnmpc_fleet_set_yref", "cfnmpc_fleet_set_weights", "cfnmpc_fleet_init_iterate", "cfnmpc_fleet_solve",
     "cfnmpc_fleet_get_u", "cfnmpc_fleet_get_x", "cfnmpc_fleet_get_stats", "cfnmpc_fleet_set_box", "cfnmpc_fleet_get_cmd",
+    "cfnmpc_multi_create", "cfnmpc_multi_free", "cfnmpc_multi_batch", "cfnmpc_multi_num_shards", "cfnmpc_multi_shard",
+    "cfnmpc_multi_set_x0", "cfnmpc_multi_set_yref", "cfnmpc_multi_set_weights", "cfnmpc_multi_init_iterate", "cfnmpc_multi_solve",
+    "cfnmpc_multi_sync", "cfnmpc_multi_get_u", "cfnmpc_multi_get_x", "cfnmpc_multi_get_cmd", "cfnmpc_multi_get_stats",
 ]
 
 
@@ -99,6 +102,19 @@ def lib():
     L.cfnmpc_fleet_get_u.argtypes = [vp, i32, vp, i32, vp]
     L.cfnmpc_fleet_get_x.argtypes = [vp, i32, vp, i32, vp]
     L.cfnmpc_fleet_get_stats.argtypes = [vp, vp, vp, vp, i32, vp]
+    L.cfnmpc_multi_create.argtypes = [C.POINTER(vp), i32, vp, i32, C.POINTER(Opts)]
+    for n in ("free", "batch", "num_shards", "sync"):
+        getattr(L, "cfnmpc_multi_" + n).argtypes = [vp]
+    L.cfnmpc_multi_shard.argtypes = [vp, i32, C.POINTER(vp), vp, vp, vp, C.POINTER(vp)]
+    L.cfnmpc_multi_set_x0.argtypes = [vp, vp]
+    L.cfnmpc_multi_set_yref.argtypes = [vp, vp, vp]
+    L.cfnmpc_multi_set_weights.argtypes = [vp, vp, vp]
+    L.cfnmpc_multi_init_iterate.argtypes = [vp, i32]
+    L.cfnmpc_multi_solve.argtypes = [vp, i32]
+    L.cfnmpc_multi_get_u.argtypes = [vp, i32, vp]
+    L.cfnmpc_multi_get_x.argtypes = [vp, i32, vp]
+    L.cfnmpc_multi_get_cmd.argtypes = [vp, vp, vp]
+    L.cfnmpc_multi_get_stats.argtypes = [vp, vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int or fn.restype is None or name in ("cfnmpc_version", "cfnmpc_workspace_bytes"):

@@ -46,3 +46,89 @@ def aggregate_report(elapsed: float, sums, dist=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     return float(t.item()), s.cpu().numpy()
+
+
+class MultiGpuFleet:
+    """One fleet over several GPUs from ONE process (C-ABI cfnmpc_multi_*): contiguous shards, one
+    solver + stream per shard, every shard's step launched before anyone waits.  Host arrays cover
+    the whole fleet.  (bench.py keeps the one-process-per-GPU form the driver launches; this is the
+    deployment form for a single controller process.)"""
+
+    def __init__(self, total_batch, device_ids, opts=None):
+        import ctypes as C
+        from . import _lib
+        from .solver import _check, default_opts
+        self._C, self._check = C, _check
+        self._L = _lib.lib()
+        self.B = int(total_batch)
+        self.opts = opts if opts is not None else default_opts()
+        self.N = int(self.opts.N)
+        ids = np.ascontiguousarray(device_ids, dtype=np.int32)
+        h = C.c_void_p()
+        _check(self._L.cfnmpc_multi_create(C.byref(h), len(ids), ids.ctypes.data_as(C.c_void_p), self.B, C.byref(self.opts)),
+               "cfnmpc_multi_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.cfnmpc_multi_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shards(self):
+        """-> [(lo, hi, device)]"""
+        C = self._C
+        out = []
+        for i in range(self._L.cfnmpc_multi_num_shards(self._h)):
+            lo, hi, dev = C.c_int(0), C.c_int(0), C.c_int(0)
+            self._check(self._L.cfnmpc_multi_shard(self._h, i, None, C.byref(lo), C.byref(hi), C.byref(dev), None), "cfnmpc_multi_shard")
+            out.append((lo.value, hi.value, dev.value))
+        return out
+
+    def _p(self, a, shape, dtype=np.float64):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        assert a.shape == tuple(shape), (a.shape, shape)
+        return a, a.ctypes.data_as(self._C.c_void_p)
+
+    def set_x0(self, x0):
+        a, p = self._p(x0, (self.B, 13))
+        self._check(self._L.cfnmpc_multi_set_x0(self._h, p), "cfnmpc_multi_set_x0")
+
+    def set_yref(self, yref, yref_e):
+        a, p = self._p(yref, (self.B, self.N, 17)); b, q = self._p(yref_e, (self.B, 13))
+        self._check(self._L.cfnmpc_multi_set_yref(self._h, p, q), "cfnmpc_multi_set_yref")
+
+    def init_iterate(self, mode):
+        self._check(self._L.cfnmpc_multi_init_iterate(self._h, int(mode)), "cfnmpc_multi_init_iterate")
+
+    def solve(self, n_rti=1):
+        self._check(self._L.cfnmpc_multi_solve(self._h, int(n_rti)), "cfnmpc_multi_solve")
+
+    def sync(self):
+        self._check(self._L.cfnmpc_multi_sync(self._h), "cfnmpc_multi_sync")
+
+    def get_u(self, stage):
+        u = np.empty((self.B, 4))
+        self._check(self._L.cfnmpc_multi_get_u(self._h, int(stage), u.ctypes.data_as(self._C.c_void_p)), "cfnmpc_multi_get_u")
+        return u
+
+    def get_x(self, stage):
+        x = np.empty((self.B, 13))
+        self._check(self._L.cfnmpc_multi_get_x(self._h, int(stage), x.ctypes.data_as(self._C.c_void_p)), "cfnmpc_multi_get_x")
+        return x
+
+    def get_cmd(self):
+        c = np.empty((self.B, 4)); mv = np.empty((self.B, 4), dtype=np.int32)
+        self._check(self._L.cfnmpc_multi_get_cmd(self._h, c.ctypes.data_as(self._C.c_void_p), mv.ctypes.data_as(self._C.c_void_p)), "cfnmpc_multi_get_cmd")
+        return c, mv
+
+    def stats(self):
+        st = np.empty(self.B, dtype=np.int32); it = np.empty(self.B, dtype=np.int32); rs = np.empty(self.B)
+        vp = self._C.c_void_p
+        self._check(self._L.cfnmpc_multi_get_stats(self._h, st.ctypes.data_as(vp), it.ctypes.data_as(vp), rs.ctypes.data_as(vp)), "cfnmpc_multi_get_stats")
+        return st, it, rs

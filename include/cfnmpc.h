@@ -248,6 +248,32 @@ int cfnmpc_fleet_get_x(cfnmpc_fleet *f, int stage, double *x /*[B][13]*/, int on
 int cfnmpc_fleet_get_cmd(cfnmpc_fleet *f, double *cmd_vel /*[B][4]*/, int *motvel /*[B][4]*/, int on_device, void *stream);
 int cfnmpc_fleet_get_stats(cfnmpc_fleet *f, int *status, int *qp_iter, double *res, int on_device, void *stream);
 
+/* ---- one fleet across several GPUs of a node, from ONE process --------------------------------
+ * The reference owns one vehicle per process (acados_mpc.cpp:76-82); instances are independent, so a
+ * fleet splits into contiguous shards with no exchange between devices: shard i
+ * = vehicles [lo_i, hi_i) on HIP device device_ids[i] (ids may repeat), each with its own solver and
+ * stream.  cfnmpc_multi_solve launches every shard's step and returns without waiting; getters wait
+ * for what they read.  Host arrays cover the WHOLE fleet ([B][..] as in the single-device calls).
+ * Device-resident I/O: take a shard's solver / stream with cfnmpc_multi_shard and use the
+ * single-device calls with pointers of that device. */
+typedef struct cfnmpc_multi cfnmpc_multi;
+int cfnmpc_multi_create(cfnmpc_multi **out, int n_shards, const int *device_ids /*[n_shards]*/, int total_batch,
+                        const cfnmpc_opts *opts);
+int cfnmpc_multi_free(cfnmpc_multi *m);
+int cfnmpc_multi_batch(const cfnmpc_multi *m);
+int cfnmpc_multi_num_shards(const cfnmpc_multi *m);
+int cfnmpc_multi_shard(const cfnmpc_multi *m, int shard, cfnmpc_solver **solver, int *lo, int *hi, int *device, void **stream);
+int cfnmpc_multi_set_x0(cfnmpc_multi *m, const double *x0 /*[B][13] host*/);
+int cfnmpc_multi_set_yref(cfnmpc_multi *m, const double *yref /*[B][N][17] host*/, const double *yref_e /*[B][13] host*/);
+int cfnmpc_multi_set_weights(cfnmpc_multi *m, const double *W, const double *WN);
+int cfnmpc_multi_init_iterate(cfnmpc_multi *m, int mode);
+int cfnmpc_multi_solve(cfnmpc_multi *m, int n_rti);   /* asynchronous on every shard's stream */
+int cfnmpc_multi_sync(cfnmpc_multi *m);
+int cfnmpc_multi_get_u(cfnmpc_multi *m, int stage, double *u /*[B][4] host*/);
+int cfnmpc_multi_get_x(cfnmpc_multi *m, int stage, double *x /*[B][13] host*/);
+int cfnmpc_multi_get_cmd(cfnmpc_multi *m, double *cmd_vel /*[B][4] host*/, int *motvel /*[B][4] host or NULL*/);
+int cfnmpc_multi_get_stats(cfnmpc_multi *m, int *status, int *qp_iter, double *res);
+
 const char *cfnmpc_version(void);
 
 #ifdef __cplusplus

@@ -543,3 +543,43 @@ def test_forward_sweep_variants_agree(oracle, cref, B):
             if fs != 2:
                 s.set_iterate(res[2][0], res[2][1])
         x = sim(x, res[2][1][:, 0, :].copy(), T=0.015, steps=1)
+
+
+def test_multi_gpu_fleet_shards_match_single_solver(oracle):
+    """cfnmpc_multi_*: a fleet split into contiguous shards, each with its own solver and stream (here
+    three shards on device 0 -- the box has one GPU; on a node the ids differ), gives per vehicle what
+    ONE solver over the whole fleet gives: full-horizon sweeps make a vehicle's arithmetic independent
+    of its neighbours, so the comparison is bitwise.  Shard bounds as parallel.shard_range."""
+    import torch
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, parallel, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 1001, 50
+    rng = np.random.default_rng(23)
+    x = oracle.sample_hover_x0(rng, B, scale=1.4)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    opts = default_opts(active_horizon=0)
+    m = parallel.MultiGpuFleet(B, [0, 0, 0], opts)
+    assert [(lo, hi) for lo, hi, _ in m.shards()] == [parallel.shard_range(B, r, 3) for r in range(3)]
+    s = BatchSolver(B, opts)
+    for o in (m, s):
+        o.set_x0(x); o.set_yref(yref, yref_e); o.init_iterate(INIT_HOVER)
+    seen = 0
+    for t in range(4):
+        m.set_x0(x); s.set_x0(x)
+        m.solve(1); s.solve(1)
+        m.sync()
+        st, it, _ = m.stats(); st1, it1, _ = s.stats()
+        assert (st == 0).all() and np.array_equal(it, it1)
+        seen += int((it > 0).sum())
+        for k in (0, 1):
+            assert np.array_equal(m.get_u(k), s.get_u(k))
+        assert np.array_equal(m.get_x(4), s.get_x(4))
+        c, mv = m.get_cmd(); c1, mv1 = s.get_cmd()
+        assert np.array_equal(c, c1) and np.array_equal(mv, mv1)
+        x = sim(x, m.get_u(0), T=0.015, steps=1)
+    assert seen > 0
+    if torch.cuda.device_count() > 1:       # a real second device, when the box has one
+        m2 = parallel.MultiGpuFleet(B, [0, 1], opts)
+        m2.set_x0(x); m2.set_yref(yref, yref_e); m2.init_iterate(INIT_HOVER); m2.solve(1); m2.sync()
+        assert (m2.stats()[0] == 0).all()
