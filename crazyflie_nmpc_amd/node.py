@@ -74,6 +74,9 @@ class BatchNMPC:
     def windows(self):
         """Fill yref_sign per vehicle according to its policy (acados_mpc.cpp:430-516)."""
         N = self.N
+        if self.n_steps < N + 1:      # no usable trajectory: Tracking / Position_Hold vehicles are served as Regulation
+            self.yref_sign[:] = self._hold_rows(self.des)     # (as cfnmpc_set_yref_windows does with n_rows < N + 1)
+            return self.yref_sign[:, :N, :], self.yref_sign[:, N, :13]
         reg = self.policy == REGULATION
         if reg.any():
             self.yref_sign[reg] = self._hold_rows(self.des[reg])

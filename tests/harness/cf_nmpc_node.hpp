@@ -129,6 +129,8 @@ public:
 
     // acados_mpc.cpp:427-718; returns the solver status (App. B6)
     int iteration(const CrazyflieState& msg) {
+        // without a usable trajectory the reference would index an empty vector (:460-513): hold instead
+        if (policy != Regulation && N_STEPS < N + 1) policy = Regulation;
         switch (policy) {
             case Regulation:
                 for (int k = 0; k < N + 1; k++) fill_hold_row(k, xq_des, yq_des, zq_des);
