@@ -583,3 +583,40 @@ def test_multi_gpu_fleet_shards_match_single_solver(oracle):
         m2 = parallel.MultiGpuFleet(B, [0, 1], opts)
         m2.set_x0(x); m2.set_yref(yref, yref_e); m2.init_iterate(INIT_HOVER); m2.solve(1); m2.sync()
         assert (m2.stats()[0] == 0).all()
+
+
+def test_fleet_output_stage_and_box(oracle, cref):
+    """cfnmpc_fleet_get_cmd / cfnmpc_fleet_set_box: a mixed-horizon fleet's output stage equals the
+    host mirror on the fleet's own u0 / u1 / x4 (host and device pointers), and a narrower input box
+    reaches every bucket (checked against the CPU restatement with the same box)."""
+    import torch
+    from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
+    from crazyflie_nmpc_amd.node import postprocess
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(41)
+    B = 37
+    hz = rng.choice([30, 50, 100], size=B)
+    f = MixedHorizonFleet(hz)
+    f.set_regulation(np.tile([0.0, 0.0, 0.4], (B, 1)), HOV)
+    x0 = oracle.sample_hover_x0(rng, B, scale=2.0)
+    f.set_box(3.0, 19.0)
+    f.set_x0(x0); f.init_iterate(INIT_HOVER); f.solve(1)
+    st, it, _ = f.stats()
+    assert (st == 0).all() and (it > 0).any()
+    u0, u1, x4 = f.get_u(0), f.get_u(1), f.get_x(4)
+    assert u0.min() >= 3.0 - 1e-8 and u0.max() <= 19.0 + 1e-8
+    cmd, mv = f.get_cmd()
+    ref = postprocess(u0, u1, x4)
+    assert np.array_equal(mv, ref["motvel"]) and np.array_equal(cmd[:, 2], ref["cmd_vel"][:, 2])
+    assert np.abs(cmd - ref["cmd_vel"]).max() < 1e-11
+    dev = torch.device("cuda", 0)
+    cd, md = f.get_cmd(torch.empty((B, 4), dtype=torch.float64, device=dev))
+    torch.cuda.synchronize()
+    assert np.array_equal(cd.cpu().numpy(), cmd) and np.array_equal(md.cpu().numpy(), mv)
+    for n in (30, 50, 100):
+        idx = np.nonzero(hz == n)[0]
+        yr, ye = oracle.regulation_yref(int(n), (0.0, 0.0, 0.4))
+        xr = np.repeat(x0[idx, None, :], n + 1, 1).copy(); ur = np.full((len(idx), n, 4), HOV)
+        cref.rti_step(cref.default_opts(N=int(n), u_min=3.0, u_max=19.0, active_set=1), xr, ur, x0[idx].copy(),
+                      np.repeat(yr[None], len(idx), 0).copy(), np.repeat(ye[None], len(idx), 0).copy(), nthreads=0)
+        assert np.abs(u0[idx] - ur[:, 0]).max() < 1e-8 and np.abs(x4[idx] - xr[:, 4]).max() < 1e-8
