@@ -24,7 +24,9 @@
 //               barrier only changes the diagonal of the input block and the gradient), two
 //               factorisations per iteration; expand through the stored (A, B, b).
 //
-// Mapping: one instance per group of LPI lanes (16, 32 or 64), all dense blocks of a group in LDS,
+// Mapping: one instance per group of LPI lanes -- the code is generic in LPI, the launchers use 64 (one
+// instance per wavefront: measured 3-5x faster than 16 lanes per instance, since the LDS footprint per
+// INSTANCE fixes how many instances a CU holds either way) --, all dense blocks of an instance in LDS,
 // generic loops (the block length m is a run-time value up to the template's MMAX).  This path is an
 // OPTION (parity with the reference's solver plan + the N2 sweep of DESIGN.md section 5.8), not the
 // default: condensing raises both the bytes per stage and the flops for this problem's sizes.
