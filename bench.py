@@ -349,6 +349,7 @@ def main():
     ap.add_argument("--active-set", type=int, default=1)
     ap.add_argument("--cond-n2", type=int, default=None, help="cfnmpc_opts.cond_N2 (partial condensing; default: library default)")
     ap.add_argument("--kick-scale", type=float, default=1.0)
+    ap.add_argument("--step-graph", type=int, default=None, help="cfnmpc_opts.step_graph (captured hipGraph per RTI step)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (default); gloo only for functional checks of the N > 1 path on "
                          "a box with fewer GPUs than ranks (ranks then share devices)")
@@ -390,7 +391,8 @@ def main():
     scaling = args.scaling or "strong"
     seed = parallel.shard_seed(rank)
     opt_kw = dict(active_horizon=args.active_horizon, active_set=args.active_set)
-    for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2)):
+    for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2),
+                 ("step_graph", args.step_graph)):
         if v is not None:
             opt_kw[k] = v
 

@@ -39,6 +39,13 @@ struct cfnmpc_solver {
     hipEvent_t ev_start, ev_aux; // start solve done (on the caller's stream) / early pass done (on aux)
     bool lin_valid;              // (P.AR, P.BR, P.b) hold the linearisation of the current iterate
     int chunks_all, chunks_list; // workgroups per 64-instance group in the two linearisation passes
+    // captured step (cfnmpc_opts.step_graph): the launches of one RTI step as a hipGraph, one per parity of
+    // the iterate buffers (kernel arguments are by value and the host swaps xit / xitn after every step)
+    int use_graph;
+    hipStream_t cap;             // capture stream
+    hipGraphExec_t gexec[2];
+    bool gvalid[2];
+    int parity;                  // which of the two argument sets the NEXT step uses
 };
 
 namespace {
@@ -158,6 +165,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->active_set = 1;
     o->forward_sweep = 0;
     o->cond_N2 = 0;
+    o->step_graph = 0;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
@@ -191,6 +199,11 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     s->aux = nullptr;
     s->ev_start = s->ev_aux = nullptr;
     s->lin_valid = false;
+    s->use_graph = o.step_graph ? 1 : 0;
+    s->cap = nullptr;
+    s->gexec[0] = s->gexec[1] = nullptr;
+    s->gvalid[0] = s->gvalid[1] = false;
+    s->parity = 0;
     // the shooting intervals of a 64-instance group are independent: spread them over enough
     // workgroups to fill the 1024 SIMDs when the batch alone does not (a single instance then
     // linearises its 50 intervals in parallel instead of one after the other)
@@ -220,7 +233,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.ah_margin = o.ah_margin;
     P.ah_extra = o.ah_extra;
     P.active_set = o.active_set ? 1 : 0;
-    if (o.forward_sweep < 0 || o.forward_sweep > 2) { delete s; return CFNMPC_EINVAL; }
+    if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
     P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && batch < FORWARD_RG_BELOW) ? 1 : 0;
     P.cond_N2 = cond_N2;
     P.cond_M = cond_N2 ? o.N / cond_N2 : 0;
@@ -273,6 +286,8 @@ int cfnmpc_free(cfnmpc_solver* s) {
     if (!s) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
+    for (int p = 0; p < 2; p++) if (s->gexec[p]) (void)hipGraphExecDestroy(s->gexec[p]);
+    if (s->cap) (void)hipStreamDestroy(s->cap);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_aux) (void)hipEventDestroy(s->ev_aux);
     for (void* p : s->allocs) (void)hipFree(p);
@@ -311,11 +326,15 @@ int cfnmpc_set_yref_windows(cfnmpc_solver* s, const double* traj, int n_rows, in
     return CFNMPC_OK;
 }
 
+// kernel arguments changed (weights, box): the captured steps hold the old ones
+static void invalidate_graphs(cfnmpc_solver* s) { s->gvalid[0] = s->gvalid[1] = false; }
+
 int cfnmpc_set_weights(cfnmpc_solver* s, const double* W, const double* WN) {
     if (!s || (!W && !WN)) return CFNMPC_EINVAL;
     if (!weights_ok(W, WN)) return CFNMPC_EINVAL;   // validated as a whole before anything is copied
     if (W) for (int i = 0; i < 17; i++) s->P.W[i] = W[i];
     if (WN) for (int i = 0; i < 13; i++) s->P.WN[i] = WN[i];
+    invalidate_graphs(s);
     return CFNMPC_OK;  // kernel arguments: take effect at the next cfnmpc_solve
 }
 
@@ -323,6 +342,7 @@ int cfnmpc_set_box(cfnmpc_solver* s, double u_min, double u_max) {
     if (!s || !(u_max > u_min)) return CFNMPC_EINVAL;
     s->P.u_min = u_min;   // kernel arguments: take effect at the next cfnmpc_solve
     s->P.u_max = u_max;
+    invalidate_graphs(s);
     return CFNMPC_OK;
 }
 
@@ -389,6 +409,30 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
             e = &s->ev[s->ev_used];
             s->ev_used += 3;
         }
+        if (!s->overlap && s->use_graph && !e) {
+            // the step's launches replayed from a captured graph (one per parity of the iterate buffers)
+            const int p = s->parity;
+            if (!s->gvalid[p]) {
+                if (!s->cap) HIP_TRY(hipStreamCreateWithFlags(&s->cap, hipStreamNonBlocking));
+                if (s->gexec[p]) { (void)hipGraphExecDestroy(s->gexec[p]); s->gexec[p] = nullptr; }
+                hipGraph_t g = nullptr;
+                HIP_TRY(hipStreamBeginCapture(s->cap, hipStreamCaptureModeThreadLocal));
+                cfn::launch_linearise(s->P, s->chunks_all, s->cap);
+                if (s->P.cond_N2) cfn::launch_qp_cond(s->P, s->cap);
+                else cfn::launch_qp(s->P, s->cap);
+                HIP_TRY(hipStreamEndCapture(s->cap, &g));
+                const hipError_t ie = hipGraphInstantiate(&s->gexec[p], g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (ie != hipSuccess) return CFNMPC_EHIP;
+                s->gvalid[p] = true;
+            }
+            HIP_TRY(hipGraphLaunch(s->gexec[p], st));
+            std::swap(s->P.xit, s->P.xitn);
+            std::swap(s->P.uit, s->P.uitn);
+            s->parity ^= 1;
+            s->lin_valid = false;
+            continue;
+        }
         if (!s->overlap) {
             // linearise -> QP, everything on the caller's stream
             if (e) HIP_TRY(hipEventRecord(e[0], st));
@@ -399,6 +443,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
             if (e) HIP_TRY(hipEventRecord(e[2], st));
             std::swap(s->P.xit, s->P.xitn);   // the step's kernels wrote every instance's new iterate there
             std::swap(s->P.uit, s->P.uitn);
+            s->parity ^= 1;
             s->lin_valid = false;   // the iterate moved
             continue;
         }

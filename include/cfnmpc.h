@@ -104,6 +104,12 @@ typedef struct cfnmpc_opts {
                             solution (strictly convex QP); active_set / active_horizon do not apply.
                             Measured slower than the uncondensed path at every N2:
                             an option for parity with the reference's solver plan, not the default.        */
+    int step_graph;      /* 1: cfnmpc_solve replays the launches of an RTI step from a captured hipGraph (one per
+                            parity of the two iterate buffers; re-captured after cfnmpc_set_weights / _set_box)
+                            instead of launching its 7-8 kernels one by one; not with overlap_linearise, and
+                            steps timed with cfnmpc_set_profiling are launched individually.  0 (default): the
+                            kernels already run back to back (18 us of gaps per step at 4096 instances), the
+                            graph saves about half of that.                          */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);

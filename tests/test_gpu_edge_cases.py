@@ -620,3 +620,34 @@ def test_fleet_output_stage_and_box(oracle, cref):
         cref.rti_step(cref.default_opts(N=int(n), u_min=3.0, u_max=19.0, active_set=1), xr, ur, x0[idx].copy(),
                       np.repeat(yr[None], len(idx), 0).copy(), np.repeat(ye[None], len(idx), 0).copy(), nthreads=0)
         assert np.abs(u0[idx] - ur[:, 0]).max() < 1e-8 and np.abs(x4[idx] - xr[:, 4]).max() < 1e-8
+
+
+@pytest.mark.parametrize("B", [5, 300, 9000])
+def test_captured_step_graph_is_bit_identical(oracle, B):
+    """cfnmpc_opts.step_graph: replaying the step's launches from a captured hipGraph (one per parity of
+    the iterate buffers) gives bitwise the results of launching them one by one -- over several steps,
+    across n_rti > 1, and after set_weights / set_box (re-capture)."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(29)
+    x = oracle.sample_hover_x0(rng, B, scale=1.3)
+    yr, ye = oracle.regulation_yref(50, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    a = BatchSolver(B, default_opts(step_graph=1)); b = BatchSolver(B, default_opts(step_graph=0))
+    for s in (a, b):
+        s.set_x0(x); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    W = np.array(list(default_opts().W)); W[13:] *= 3.0
+    for t in range(7):
+        if t == 3:
+            for s in (a, b):
+                s.set_weights(W, None)
+        if t == 5:
+            for s in (a, b):
+                s.set_box(2.0, 21.0)
+        n = 2 if t == 4 else 1
+        for s in (a, b):
+            s.set_x0(x); s.solve(n)
+        (xa, ua), (xb, ub) = a.get_iterate(), b.get_iterate()
+        assert np.array_equal(xa, xb) and np.array_equal(ua, ub), t
+        assert np.array_equal(a.stats()[1], b.stats()[1]) and (a.stats()[0] == 0).all()
+        x = sim(x, ua[:, 0, :].copy(), T=0.015, steps=1)
