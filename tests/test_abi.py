@@ -56,3 +56,14 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "cfnmpc_oracle" not in txt and "cfnmpc_ref" not in txt and "cref" not in txt.replace("cref_", ""), f
+
+
+def test_headers_are_plain_c(tmp_path):
+    """include/*.h are the C-ABI: they must compile as C (gcc -std=c99 -pedantic), not only as C++."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "cfnmpc.h"\n#include "acados_solver_crazyflie.h"\n#include "acados_sim_solver_crazyflie.h"\n'
+                   "int use(void) { cfnmpc_opts o; cfnmpc_default_opts(&o); return o.N + (int)sizeof(sim_in) + (int)sizeof(ocp_nlp_out); }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
