@@ -112,3 +112,29 @@ def test_cond_option_validation():
             BatchSolver(4, default_opts(**bad))      # blocks longer than 10 stages / out of range / overlap
     for ok in (0, 50):
         BatchSolver(4, default_opts(cond_N2=ok)).close()    # both mean "no condensing"
+
+
+def test_condensed_mixed_horizon_fleet(oracle):
+    """cond_N2 reaches every bucket of a mixed-horizon fleet (blocks of 3 / 5 / 10 stages for N = 30 / 50 /
+    100 with cond_N2 = 10) and gives the uncondensed fleet's controls; a cond_N2 that would need blocks
+    longer than 10 stages in some bucket is refused at creation."""
+    from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
+    from crazyflie_nmpc_amd.solver import CfnmpcError, INIT_HOVER
+    rng = np.random.default_rng(61)
+    B = 41
+    hz = rng.choice([30, 50, 100], size=B)
+    x0 = oracle.sample_hover_x0(rng, B, scale=1.5)
+    res = []
+    for kw in (dict(cond_N2=10), dict(active_set=0, active_horizon=0)):
+        f = MixedHorizonFleet(hz, **kw)
+        f.set_regulation(np.tile([0.0, 0.0, 0.4], (B, 1)), HOV)
+        f.set_x0(x0); f.init_iterate(INIT_HOVER); f.solve(1)
+        st, it, _ = f.stats()
+        assert (st == 0).all() and (it > 0).any()
+        res.append((f.get_u(0), f.get_u(1), f.get_x(4), it))
+        f.close()
+    (u0c, u1c, x4c, itc), (u0p, u1p, x4p, itp) = res
+    assert np.array_equal(itc, itp)
+    assert np.abs(u0c - u0p).max() < 1e-6 and np.abs(u1c - u1p).max() < 1e-6 and np.abs(x4c - x4p).max() < 1e-6
+    with pytest.raises(CfnmpcError):
+        MixedHorizonFleet(hz, cond_N2=5)          # N = 100 would need 20-stage blocks
