@@ -122,16 +122,27 @@ __device__ __forceinline__ gdouble* cb_ptr(const Params& P, const Grp<LPI>& t, i
 // ---------------------------------------------------------------------------------------------
 // pcond: one (instance, block) per group
 // ---------------------------------------------------------------------------------------------
+// index of the row of entry e of a row-major lower triangle (e = r (r + 1) / 2 + c, c <= r)
+__device__ __forceinline__ int tri_row(const int e) {
+    int r = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    r += ((r + 1) * (r + 2)) / 2 <= e ? 1 : 0;
+    r -= (r * (r + 1)) / 2 > e ? 1 : 0;
+    return r;
+}
+
 template <int MMAX, int LPI>
 __global__ __launch_bounds__(64) void k_pcond(Params P) {
+    // LDS per group: H (packed lower, w x w), G and Gq = diag(Q) G (13 x W, leading dimension W = the
+    // template's widest block: compile-time strides), the stage's dense A, B, b and gradient terms
     constexpr int W = cond_w(MMAX), IPW = 64 / LPI;
-    constexpr int GSZ = cond_tri(W) + 13 * W + 169 + 52 + 13 + 13 + 4 + 13 + 4 + 3;   // per group (padded to even below)
+    constexpr int GSZ = cond_tri(W) + 2 * 13 * W + 169 + 52 + 13 + 13 + 4 + 13 + 4 + 3;
     constexpr int GST = (GSZ + 1) & ~1;
     __shared__ double lds[IPW * GST];
     const Grp<LPI> t = grp_id<LPI>(P, blockIdx.x * IPW);
     double* H = lds + t.g * GST;
     double* G = H + cond_tri(W);
-    double* Am = G + 13 * W;
+    double* Gq = G + 13 * W;
+    double* Am = Gq + 13 * W;
     double* Bm = Am + 169;
     double* bv = Bm + 52;
     double* qv = bv + 13;
@@ -142,42 +153,80 @@ __global__ __launch_bounds__(64) void k_pcond(Params P) {
     const int m = cond_len(P, j), k0 = cond_start(P, j);
     const int mu = 4 * m, w = mu + 14, aff = w - 1;
     for (int e = t.lane; e < cond_tri(w); e += LPI) H[e] = 0.0;
-    for (int e = t.lane; e < 13 * w; e += LPI) {
-        const int r = e / w, c = e - r * w;
+    for (int e = t.lane; e < 13 * W; e += LPI) {
+        const int r = e / W, c = e - r * W;
         G[e] = (c == mu + r) ? 1.0 : 0.0;
     }
+    // structural entries of A (identity p-block, zeros) never change; the stored ones are refreshed per stage
+    for (int e = t.lane; e < 169; e += LPI) Am[e] = (e / 13 == e % 13 && e % 13 < 3) ? 1.0 : 0.0;
     if (t.lane < 13) wq[t.lane] = P.W[ext_of(t.lane)];
     if (t.lane < 4) wr[t.lane] = P.W[13 + t.lane];
+    // this lane's share of a stage's stored entries (decoded once): up to two of A's 97, one of B's 52
+    int aoff[2], adst[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int e = t.lane + LPI * u;
+        aoff[u] = -1; adst[u] = 0;
+        if (e < 97) {
+            int sl = 0;
+            for (int s2 = 0; s2 < 10; s2++) if (e >= ar_pre(s2)) sl = s2;
+            const int r = e - ar_pre(sl);
+            aoff[u] = 4 * ar_pre(sl) + t.q * ar_n(sl) + r;
+            adst[u] = r * 13 + sl + 3;
+        }
+    }
+    constexpr int U = (cond_tri(W) + LPI - 1) / LPI;
+    int pk[U];   // (row | column << 8) of this lane's entries of a row-major lower triangle
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int e = t.lane + LPI * u, r = tri_row(e);
+        pk[u] = r | ((e - (r * (r + 1)) / 2) << 8);
+    }
+    const int boff = t.lane < 52 ? ((t.lane & 3) * 4 + t.q) * 13 + (t.lane >> 2) : -1;   // element (row lane >> 2, input lane & 3)
     for (int i = 0; i < m; i++) {
         const int k = k0 + i;
         __syncthreads();
         // stage data -> LDS (dense A, B; b; q = Q (xbar - yref), r = R (ubar - yref_u))
-        for (int e = t.lane; e < 169; e += LPI) Am[e] = a_elem(P, t, k, e / 13, e % 13);
-        for (int e = t.lane; e < 52; e += LPI) Bm[e] = b_elem(P, t, k, e / 4, e % 4);
+        {
+            const gdouble* ab = gm(P.AR) + (t.wave * N + k) * SZ_A;
+#pragma unroll
+            for (int u = 0; u < 2; u++) if (aoff[u] >= 0) Am[adst[u]] = ab[aoff[u]];
+            if (boff >= 0) Bm[t.lane] = gm(P.BR)[(t.wave * N + k) * SZ_B + boff];
+        }
         if (t.lane < 13) {
             bv[t.lane] = v13(P.b, t, N, k, t.lane);
             const double xk = v13(P.xit, t, N + 1, k, t.lane);
             const double yk = gm(P.yref)[(t.wave * N + k) * SZ_Y + t.q * 17 + t.lane];
-            qv[t.lane] = P.W[ext_of(t.lane)] * (xk - yk);
+            qv[t.lane] = wq[t.lane] * (xk - yk);
         }
         if (t.lane < 4) {
             const double uk = gm(P.uit)[((size_t)t.inst * N + k) * 4 + t.lane];
             const double yr = gm(P.yref)[(t.wave * N + k) * SZ_Y + t.q * 17 + 13 + t.lane];
-            rv[t.lane] = P.W[13 + t.lane] * (uk - yr);
+            rv[t.lane] = wr[t.lane] * (uk - yr);
         }
         __syncthreads();
-        // H += G~' Q~ G~ over the columns G_i can be non-zero in: inputs of stages < i, dx, 1
+        // columns G_i can be non-zero in: inputs of stages < i, dx, 1  (na of them)
         const int na = 4 * i + 14;
-        for (int ra = 0; ra < na; ra++) {
-            const int r = ra < 4 * i ? ra : mu + (ra - 4 * i);
-            for (int ca = t.lane; ca <= ra; ca += LPI) {
+        // Gq = diag(Q) G, with the stage's gradient folded into its affine column: then
+        // H[r][c] += sum_l Gq[l][r] G[l][c] covers the quadratic AND the linear term (aff is the last index)
+        for (int e = t.lane; e < 13 * na; e += LPI) {
+            const int l = e / na, ca = e - l * na;
+            const int c = ca < 4 * i ? ca : mu + (ca - 4 * i);
+            Gq[l * W + c] = wq[l] * G[l * W + c] + (c == aff ? qv[l] : 0.0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = t.lane + LPI * u;
+            if (e < (na * (na + 1)) / 2) {
+                const int ra = pk[u] & 255, ca = pk[u] >> 8;
+                const int r = ra < 4 * i ? ra : mu + (ra - 4 * i);
                 const int c = ca < 4 * i ? ca : mu + (ca - 4 * i);
+                const double* gq = Gq + r;
+                const double* gg = G + c;
                 double acc = 0.0;
-                if (r == aff) {
-                    for (int l = 0; l < 13; l++) acc += (wq[l] * G[l * w + aff] + qv[l]) * G[l * w + c];
-                } else {
-                    for (int l = 0; l < 13; l++) acc += G[l * w + r] * wq[l] * G[l * w + c];
-                }
+#pragma unroll
+                for (int l = 0; l < 13; l++) acc += gq[l * W] * gg[l * W];
                 H[tri(r, c)] += acc;
             }
         }
@@ -191,7 +240,8 @@ __global__ __launch_bounds__(64) void k_pcond(Params P) {
         for (int ca = t.lane; ca < nb; ca += LPI) {
             const int c = ca < 4 * (i + 1) ? ca : mu + (ca - 4 * (i + 1));
             double gc[13], gn[13];
-            for (int l = 0; l < 13; l++) gc[l] = G[l * w + c];
+#pragma unroll
+            for (int l = 0; l < 13; l++) gc[l] = G[l * W + c];
             // A is block upper triangular in the internal order p | v | q | w with an identity p-block
             // (cfnmpc_ws.hpp): row r only meets the columns from its own block on
 #pragma unroll
@@ -202,15 +252,25 @@ __global__ __launch_bounds__(64) void k_pcond(Params P) {
                 for (int l = l0; l < 13; l++) acc += Am[r * 13 + l] * gc[l];
                 gn[r] = acc;
             }
-            if (c >= 4 * i && c < 4 * i + 4) for (int r = 0; r < 13; r++) gn[r] += Bm[r * 4 + (c - 4 * i)];
-            if (c == aff) for (int r = 0; r < 13; r++) gn[r] += bv[r];
-            for (int r = 0; r < 13; r++) G[r * w + c] = gn[r];
+            if (c >= 4 * i && c < 4 * i + 4) {
+#pragma unroll
+                for (int r = 0; r < 13; r++) gn[r] += Bm[r * 4 + (c - 4 * i)];
+            }
+            if (c == aff) {
+#pragma unroll
+                for (int r = 0; r < 13; r++) gn[r] += bv[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 13; r++) G[r * W + c] = gn[r];
         }
     }
     __syncthreads();
     gdouble* cb = cb_ptr(P, t, j);
     for (int e = t.lane; e < cond_tri(w); e += LPI) cb[e] = H[e];
-    for (int e = t.lane; e < 13 * w; e += LPI) cb[cond_tri(w) + e] = G[e];
+    for (int e = t.lane; e < 13 * w; e += LPI) {
+        const int r = e / w, c = e - r * w;
+        cb[cond_tri(w) + e] = G[r * W + c];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -219,10 +279,17 @@ __global__ __launch_bounds__(64) void k_pcond(Params P) {
 template <int MMAX, int LPI>
 struct CfLds {   // LDS carve-up of one group in k_cfactor / k_cipm
     static constexpr int W = cond_w(MMAX);
+    static constexpr int U = (cond_tri(W) + LPI - 1) / LPI;   // triangle entries per lane
     static constexpr int SZ = (cond_tri(W) + 13 * W + 14 * 14 + 14 * W + 4 * MMAX + 13 + 17 + 1) & ~1;
     double *H, *Dm, *Pt, *Y, *dinv, *xs, *wv;
-    __device__ __forceinline__ explicit CfLds(double* base) {
+    int pk[U];   // (row | column << 8) of the lane's entries lane, lane + LPI, ... of a row-major lower triangle
+    __device__ __forceinline__ explicit CfLds(double* base, int lane) {
         H = base; Dm = H + cond_tri(W); Pt = Dm + 13 * W; Y = Pt + 196; dinv = Y + 14 * W; xs = dinv + 4 * MMAX; wv = xs + 13;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = lane + LPI * u, r = tri_row(e);
+            pk[u] = r | ((e - (r * (r + 1)) / 2) << 8);
+        }
     }
 };
 
@@ -238,52 +305,75 @@ __device__ __forceinline__ bool cfactor_block(const Params& P, const Grp<LPI>& t
     double *H = L.H, *Dm = L.Dm, *Pt = L.Pt, *Y = L.Y;
     const gdouble* cb = cb_ptr(P, t, j);
     const size_t eb = ((size_t)t.inst * N + k0) * 4;   // element-wise arrays of this block's inputs
+    constexpr int W = CfLds<MMAX, LPI>::W, UB = 4;
     __syncthreads();
     for (int e = t.lane; e < cond_tri(w); e += LPI) H[e] = cb[e];
-    for (int e = t.lane; e < 13 * w; e += LPI) Dm[e] = cb[cond_tri(w) + e];
+    for (int l = 0; l < 13; l++)
+        for (int c = t.lane; c < w; c += LPI) Dm[l * W + c] = cb[cond_tri(w) + l * w + c];
     __syncthreads();
     if (!ABSOLUTE) {
         for (int c = t.lane; c < w; c += LPI) H[tri(aff, c)] = c < mu ? gm(P.g)[eb + c] : 0.0;
         for (int c = t.lane; c < mu; c += LPI) H[tri(c, c)] += gm(P.Rh)[eb + c] - L.wv[13 + (c & 3)];
-        if (t.lane < 13) Dm[t.lane * w + aff] = 0.0;
+        if (t.lane < 13) Dm[t.lane * W + aff] = 0.0;
         __syncthreads();
     }
-    // Y = P~ E,  E = [D; e_aff]  (14 x w)
-    for (int i = 0; i < 14; i++)
-        for (int c = t.lane; c < w; c += LPI) {
+    // Y = P~ E,  E = [D; e_aff]  (14 x w): a lane owns a column of D
+    for (int c = t.lane; c < w; c += LPI) {
+        double dc[13];
+#pragma unroll
+        for (int l = 0; l < 13; l++) dc[l] = Dm[l * W + c];
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
             double acc = c == aff ? Pt[i * 14 + 13] : 0.0;
-            for (int l = 0; l < 13; l++) acc += Pt[i * 14 + l] * Dm[l * w + c];
-            Y[i * w + c] = acc;
+#pragma unroll
+            for (int l = 0; l < 13; l++) acc += Pt[i * 14 + l] * dc[l];
+            Y[i * W + c] = acc;
         }
+    }
     __syncthreads();
-    // H~ = H + E'Y  (lower triangle)
-    for (int r = 0; r < w; r++)
-        for (int c = t.lane; c <= r; c += LPI) {
-            double acc = r == aff ? Y[13 * w + c] : 0.0;
-            for (int i = 0; i < 13; i++) acc += Dm[i * w + r] * Y[i * w + c];
-            H[tri(r, c)] += acc;
+    // H~ = H + E'Y  (lower triangle, entries dealt out lane by lane)
+#pragma unroll
+    for (int u = 0; u < CfLds<MMAX, LPI>::U; u++) {
+        const int e = t.lane + LPI * u;
+        if (e < cond_tri(w)) {
+            const int r = L.pk[u] & 255, c = L.pk[u] >> 8;
+            const double* dr = Dm + r;
+            const double* yc = Y + c;
+            double acc = r == aff ? yc[13 * W] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 13; i++) acc += dr[i * W] * yc[i * W];
+            H[e] += acc;
         }
+    }
     __syncthreads();
     // right-looking Cholesky of the input block (columns 0 .. mu-1); the trailing rows / columns carry
     // L_xu and the Schur complement.  Both phases of a column are spread over all lanes of the group:
-    // the scaling over the rows below the pivot, the rank-1 update over the (row, column) pairs of the
-    // trailing triangle.
+    // the scaling over the rows below the pivot (a copy of the scaled column goes to `col`), the rank-1
+    // update over the (row, column) pairs of the trailing triangle: entry e of that triangle is (rr, cc)
+    // from the lane's table whatever the column, at H[e + (k + 1) rr + tri(k + 1, k + 1)]
     bool ok = true;
+    double* col = Y;
     for (int k = 0; k < mu; k++) {
         const double piv = H[tri(k, k)];
         ok = ok && (piv > 0.0);
         const double inv = rsqrt_nr(piv);
-        for (int r = k + 1 + t.lane; r < w; r += LPI) H[tri(r, k)] *= inv;
+        for (int r = k + 1 + t.lane; r < w; r += LPI) {
+            const double v = H[tri(r, k)] * inv;
+            H[tri(r, k)] = v;
+            col[r] = v;
+        }
         if (t.lane == 0) L.dinv[k] = inv;
         __syncthreads();
         const int sdim = w - 1 - k, T = (sdim * (sdim + 1)) / 2;
-        for (int e = t.lane; e < T; e += LPI) {
-            int rr = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            rr += ((rr + 1) * (rr + 2)) / 2 <= e ? 1 : 0;
-            rr -= (rr * (rr + 1)) / 2 > e ? 1 : 0;
-            const int cc = e - (rr * (rr + 1)) / 2;
-            const int r = k + 1 + rr, c = k + 1 + cc;
-            H[tri(r, c)] -= H[tri(r, k)] * H[tri(c, k)];
+        double* Hk = H + tri(k + 1, k + 1);
+        const double* colk = col + k + 1;
+#pragma unroll
+        for (int u = 0; u < CfLds<MMAX, LPI>::U; u++) {
+            const int e = t.lane + LPI * u;
+            if (e < T) {
+                const int rr = L.pk[u] & 255, cc = L.pk[u] >> 8;
+                Hk[e + (k + 1) * rr] -= colk[rr] * colk[cc];
+            }
         }
         __syncthreads();
     }
@@ -292,9 +382,18 @@ __device__ __forceinline__ bool cfactor_block(const Params& P, const Grp<LPI>& t
     for (int c = mu - 1; c >= 0; c--) {
         if (t.lane < 14) H[tri(mu + t.lane, c)] *= L.dinv[c];
         __syncthreads();
-        for (int e = t.lane; e < 14 * c; e += LPI) {
-            const int c2 = e / 14, i = e - c2 * 14;
-            H[tri(mu + i, c2)] -= H[tri(mu + i, c)] * H[tri(c, c2)];
+        for (int e0 = t.lane; e0 < 14 * c; e0 += UB * LPI) {
+            int ix[UB];
+            double a[UB], b[UB], h[UB];
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                const int e = e0 + u * LPI < 14 * c ? e0 + u * LPI : e0;
+                const int c2 = e / 14, i = e - c2 * 14;
+                ix[u] = tri(mu + i, c2);
+                a[u] = H[tri(mu + i, c)]; b[u] = H[tri(c, c2)]; h[u] = H[ix[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; u++) if (e0 + u * LPI < 14 * c) H[ix[u]] = h[u] - a[u] * b[u];
         }
         __syncthreads();
     }
@@ -340,7 +439,7 @@ __global__ __launch_bounds__(64) void k_cfactor(Params P) {
     constexpr int IPW = 64 / LPI;
     __shared__ double lds[IPW * CfLds<MMAX, LPI>::SZ];
     const Grp<LPI> t = grp_id<LPI>(P, blockIdx.x * IPW);
-    CfLds<MMAX, LPI> L(lds + t.g * CfLds<MMAX, LPI>::SZ);
+    CfLds<MMAX, LPI> L(lds + t.g * CfLds<MMAX, LPI>::SZ, t.lane);
     if (t.lane < 17) L.wv[t.lane] = P.W[t.lane < 13 ? ext_of(t.lane) : t.lane];
     bool ok = csweep_factor<MMAX, LPI, true>(P, t, L);
     ok = grp_min<LPI>(ok ? 1.0 : 0.0) > 0.0;
@@ -391,14 +490,14 @@ __device__ __forceinline__ double ratio(double z, double dz, double a) {
 }
 
 template <int MMAX, int LPI>
-__global__ __launch_bounds__(64) void k_cipm(Params P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_cipm(Params P) {
     constexpr int IPW = 64 / LPI;
     __shared__ double lds[IPW * CfLds<MMAX, LPI>::SZ];
     const Grp<LPI> t = grp_id<LPI>(P, blockIdx.x * IPW);
     const double viol = t.valid ? gm(P.viol)[t.inst] : 0.0;
     const bool infeasible = t.valid && viol > 0.0 && gm(P.status)[t.inst] == 0;
     if (!__any(infeasible)) return;
-    CfLds<MMAX, LPI> L(lds + t.g * CfLds<MMAX, LPI>::SZ);
+    CfLds<MMAX, LPI> L(lds + t.g * CfLds<MMAX, LPI>::SZ, t.lane);
     if (t.lane < 17) L.wv[t.lane] = P.W[t.lane < 13 ? ext_of(t.lane) : t.lane];
     __syncthreads();
     const int N = P.N, n = 4 * N;
