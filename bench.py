@@ -46,6 +46,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12         # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+FP64_VECTOR_PEAK = 78.6e12   # half the 157.3 TFLOP/s FP32 vector peak of MI355X_MICROARCH.md (256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz)
 FP64_VEC_PEAK = 78.6e12   # FLOP/s, FP64 vector (= FP64 matrix) peak of MI355X
 N_HORIZON = 50
 KICK_PERIOD = 20
@@ -497,7 +498,13 @@ def main():
                                       "alg_bytes_per_launch": alg_bytes_qp(N) * B_launch, "achieved": ach_qp / 1e9,
                                       "frac": ach_qp / HBM_PEAK, "traffic": traffic_qp},
                          # the same model against the wall clock of the whole closed loop (plant, I/O kernels included)
-                         "step_frac_hbm": alg_bytes_step(N) * r["value"] / (world * HBM_PEAK)},
+                         "step_frac_hbm": alg_bytes_step(N) * r["value"] / (world * HBM_PEAK),
+                         # secondary ceiling: FP64 vector rate against the survey's flop model --
+                         # linearise N*4*(150 + 2*60*17), one Riccati solve = N * 10 kflop, (1 + mean extra solves) of them
+                         "fp64_vector": (lambda fl: {"alg_flops_per_step": fl, "achieved_tflops": fl * r["value"] / world / 1e12,
+                                                     "peak_tflops": FP64_VECTOR_PEAK / 1e12,
+                                                     "frac": fl * r["value"] / world / FP64_VECTOR_PEAK})(
+                             N * 4 * (150 + 2 * 60 * 17) + (1.0 + r["mean_qp_solves"]) * N * 10e3)},
             "qp_stats": {"status_ok_frac": r["ok_frac"], "mean_qp_solves": r["mean_qp_solves"],
                          "frac_constrained": r["frac_constrained"], "mean_head_stages": r["mean_head"]},
         }

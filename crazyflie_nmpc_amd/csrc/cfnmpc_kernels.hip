@@ -1251,36 +1251,52 @@ __global__ __launch_bounds__(64) void k_forward_rg(Params P) {
     const double margin = P.ah_margin * (P.u_max - P.u_min);
     const int a = t.L & 3;
     const bool lo4 = t.L < 4;
-    double xbcur = ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t), xbnxt;
+    // three rotating stage buffers: the loads of stage k+2 are issued before the arithmetic of stage k
+    // (small fleets run about one wave per SIMD: memory-level parallelism has to come from the wave itself)
+    struct In { FwdIn<true> f; double u, xb; };
+    auto load = [&](int k, In& in) {
+        load_fwd<true>(P, t, k, in.f);
+        in.u = gm(P.uit)[i4(P, t, k, a)];
+        in.xb = ld13(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);
+    };
+    double xbcur = ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
     double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - xbcur;
-    FwdIn<true> cur, nxt;
-    load_fwd<true>(P, t, 0, cur);
-    double ucur = gm(P.uit)[i4(P, t, 0, a)], unxt;
     double viol = 0.0;
     int last_tight = -1, nviol = 0;
     bool sawnan = false;
-    for (int k = 0; k < N; k++) {
-        const int kn = imin(k + 1, N - 1);
-        load_fwd<true>(P, t, kn, nxt);
-        unxt = gm(P.uit)[i4(P, t, kn, a)];
-        xbnxt = ld13(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);
+    auto body = [&](const In& cur, int k) {
         st13(blk(P.xitn, t, N + 1, k, SZ_V13), t, xbcur + x);
-        const double v = feedback<true>(t, cur, x);      // lanes a < 4: du = -K dx - d
+        const double v = feedback<true>(t, cur.f, x);      // lanes a < 4: du = -K dx - d
         if (lo4) {
-            const double lb = P.u_min - ucur, ub = P.u_max - ucur;
+            const double lb = P.u_min - cur.u, ub = P.u_max - cur.u;
             viol = fmax(viol, fmax(lb - v, v - ub));
             nviol += (v < lb || v > ub) ? 1 : 0;
             if (v < lb + margin || v > ub - margin) last_tight = k;
             sawnan = sawnan || !(v == v);
             gm(P.v)[i4(P, t, k, t.L)] = v;
-            gm(P.uitn)[i4(P, t, k, t.L)] = ucur + v;
+            gm(P.uitn)[i4(P, t, k, t.L)] = cur.u + v;
         }
         double vr[4];
         SFOR(c, 0, 4, { vr[c] = bc<c>(v); });
-        x = propagate<true>(t, cur, x, vr);
-        cur = nxt;
-        ucur = unxt;
-        xbcur = xbnxt;
+        x = propagate<true>(t, cur.f, x, vr);
+        xbcur = cur.xb;
+    };
+    {
+        In b0, b1, b2;
+        load(0, b0);
+        load(imin(1, N - 1), b1);
+        int k = 0;
+        while (k < N) {
+            load(imin(k + 2, N - 1), b2);
+            body(b0, k);
+            if (++k >= N) break;
+            load(imin(k + 2, N - 1), b0);
+            body(b1, k);
+            if (++k >= N) break;
+            load(imin(k + 2, N - 1), b1);
+            body(b2, k);
+            ++k;
+        }
     }
     st13(blk(P.xitn, t, N + 1, N, SZ_V13), t, xbcur + x);
     // reductions over the four input lanes of the row

@@ -10,7 +10,7 @@ from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
 from crazyflie_nmpc_amd.solver import INIT_HOVER
 from crazyflie_nmpc_amd.synthetic import regulation_row, sample_hover_x0
 L = _lib.lib()
-B, N, KP = 65536, 50, 20
+B, N, KP = int(os.environ.get("BATCH", "65536")), 50, 20
 rng = np.random.default_rng(20200103)
 dev = torch.device("cuda", 0)
 x = torch.from_numpy(sample_hover_x0(rng, B)).to(dev)
