@@ -651,3 +651,48 @@ def test_captured_step_graph_is_bit_identical(oracle, B):
         assert np.array_equal(xa, xb) and np.array_equal(ua, ub), t
         assert np.array_equal(a.stats()[1], b.stats()[1]) and (a.stats()[0] == 0).all()
         x = sim(x, ua[:, 0, :].copy(), T=0.015, steps=1)
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_randomised_options_match_restatement(oracle, cref, seed):
+    """Seeded fuzz over everything cfnmpc_opts and the setters expose at once: horizon, interval,
+    every weight, the input box, the batch size, per-stage references, the QP method and both forward
+    sweeps -- two closed-loop RTI steps against the CPU restatement with the same options."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(7700 + seed)
+    N = int(rng.integers(2, 71))
+    dt = float(rng.uniform(0.006, 0.03))
+    B = int(rng.integers(1, 150))
+    d = default_opts()
+    W = np.array(list(d.W)) * np.exp(rng.uniform(np.log(0.3), np.log(3.0), 17))
+    WN = np.array(list(d.WN)) * np.exp(rng.uniform(np.log(0.3), np.log(3.0), 13))
+    u_min, u_max = float(rng.uniform(0.0, 8.0)), float(rng.uniform(18.0, 24.0))
+    active_set, active_horizon = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    forward_sweep = int(rng.integers(1, 3))
+    x0 = oracle.sample_hover_x0(rng, B, scale=float(rng.uniform(0.5, 2.0)))
+    yr, ye = oracle.regulation_yref(N, tuple(rng.uniform(-0.3, 0.3, 3) + np.array([0.0, 0.0, 0.5])))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    yref[:, :, :3] += rng.uniform(-0.05, 0.05, (B, N, 3))       # per-instance, per-stage references
+    yref[:, :, 13:] += rng.uniform(-0.5, 0.5, (B, N, 4))
+    yref_e[:, :3] += rng.uniform(-0.05, 0.05, (B, 3))
+    kw = dict(N=N, dt=dt, W=W, WN=WN, u_min=u_min, u_max=u_max, active_set=active_set)
+    if not active_set:
+        kw["tol"] = 1e-11    # both interior points close to the exact solution
+    s = BatchSolver(B, default_opts(active_horizon=active_horizon, forward_sweep=forward_sweep, **kw))
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    opts = cref.default_opts(**kw)
+    x = x0.copy()
+    for t in range(2):
+        s.set_x0(x); s.solve(1)
+        st, it, _ = s.stats()
+        xg, ug = s.get_iterate()
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        assert (st == st_r).all(), (seed, N, B, st, st_r)
+        ok = st == 0
+        assert ok.mean() > 0.9
+        tol = 5e-8 if active_set else 5e-6     # two interior points agree to the central path's accuracy
+        assert np.abs(ug - ur)[ok].max() < tol and np.abs(xg - xr)[ok].max() < tol, (seed, N, B, active_set)
+        assert (ug[ok] >= u_min - 1e-7).all() and (ug[ok] <= u_max + 1e-7).all()   # (interior point: primal residual <= tol)
+        x = xg[:, 1, :].copy()
