@@ -351,6 +351,7 @@ def main():
     ap.add_argument("--cond-n2", type=int, default=None, help="cfnmpc_opts.cond_N2 (partial condensing; default: library default)")
     ap.add_argument("--kick-scale", type=float, default=1.0)
     ap.add_argument("--step-graph", type=int, default=None, help="cfnmpc_opts.step_graph (captured hipGraph per RTI step)")
+    ap.add_argument("--forward-sweep", type=int, default=None, help="cfnmpc_opts.forward_sweep (0 auto, 1 matrix-free, 2 row groups)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (default); gloo only for functional checks of the N > 1 path on "
                          "a box with fewer GPUs than ranks (ranks then share devices)")
@@ -393,7 +394,7 @@ def main():
     seed = parallel.shard_seed(rank)
     opt_kw = dict(active_horizon=args.active_horizon, active_set=args.active_set)
     for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2),
-                 ("step_graph", args.step_graph)):
+                 ("step_graph", args.step_graph), ("forward_sweep", args.forward_sweep)):
         if v is not None:
             opt_kw[k] = v
 

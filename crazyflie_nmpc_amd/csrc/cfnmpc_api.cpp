@@ -75,7 +75,7 @@ struct DeviceGuard {
 };
 
 constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the count
-constexpr int FORWARD_RG_BELOW = 6144;        // measured cross-over of the two forward sweeps
+constexpr int FORWARD_RG_BELOW = 8192;        // measured cross-over of the two forward sweeps
 
 template <typename T>
 int dev_alloc(cfnmpc_solver* s, T** p, size_t count) {

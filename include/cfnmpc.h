@@ -89,7 +89,7 @@ typedef struct cfnmpc_opts {
                             as the directional derivative of the RK4 map: fewest bytes, B / 64 wavefronts);
                             2 = on the stored (A, B, b), four instances per wavefront (16 x more wavefronts, a
                             shorter dependent chain per stage: faster while the fleet is too small to fill the
-                            GPU); 0 (default) = by batch size (2 below 6144 instances: measured cross-over).  Same results to
+                            GPU); 0 (default) = by batch size (2 below 8192 instances: measured cross-over).  Same results to
                             rounding.                                                                        */
     int cond_N2;         /* QP: partial condensing (PARTIAL_CONDENSING_HPIPM, generate_c_code.py:140; acados'
                             qp_solver_cond_N, which the generator leaves at its default): 0 or N (default 0) =
