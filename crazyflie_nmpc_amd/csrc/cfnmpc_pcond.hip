@@ -183,27 +183,34 @@ __global__ __launch_bounds__(64) void k_pcond(Params P) {
         pk[u] = r | ((e - (r * (r + 1)) / 2) << 8);
     }
     const int boff = t.lane < 52 ? ((t.lane & 3) * 4 + t.q) * 13 + (t.lane >> 2) : -1;   // element (row lane >> 2, input lane & 3)
+    double sa0, sa1, sb, sbv, sx, sy, su, syu;
+    auto load_stage = [&](const int k) {
+        const gdouble* ab = gm(P.AR) + (t.wave * N + k) * SZ_A;
+        sa0 = ab[max(aoff[0], 0)];
+        sa1 = ab[max(aoff[1], 0)];
+        sb = gm(P.BR)[(t.wave * N + k) * SZ_B + max(boff, 0)];
+        const int l13 = min(t.lane, 12), l4 = t.lane & 3;
+        sbv = v13(P.b, t, N, k, l13);
+        sx = v13(P.xit, t, N + 1, k, l13);
+        sy = gm(P.yref)[(t.wave * N + k) * SZ_Y + t.q * 17 + l13];
+        su = gm(P.uit)[((size_t)t.inst * N + k) * 4 + l4];
+        syu = gm(P.yref)[(t.wave * N + k) * SZ_Y + t.q * 17 + 13 + l4];
+    };
+    load_stage(k0);
     for (int i = 0; i < m; i++) {
         const int k = k0 + i;
         __syncthreads();
-        // stage data -> LDS (dense A, B; b; q = Q (xbar - yref), r = R (ubar - yref_u))
-        {
-            const gdouble* ab = gm(P.AR) + (t.wave * N + k) * SZ_A;
-#pragma unroll
-            for (int u = 0; u < 2; u++) if (aoff[u] >= 0) Am[adst[u]] = ab[aoff[u]];
-            if (boff >= 0) Bm[t.lane] = gm(P.BR)[(t.wave * N + k) * SZ_B + boff];
-        }
+        // stage data -> LDS (dense A, B; b; q = Q (xbar - yref), r = R (ubar - yref_u)); the loads of stage
+        // i + 1 were issued before the arithmetic of stage i (clamped addresses, no branches around loads)
+        if (aoff[0] >= 0) Am[adst[0]] = sa0;
+        if (aoff[1] >= 0) Am[adst[1]] = sa1;
+        if (boff >= 0) Bm[t.lane] = sb;
         if (t.lane < 13) {
-            bv[t.lane] = v13(P.b, t, N, k, t.lane);
-            const double xk = v13(P.xit, t, N + 1, k, t.lane);
-            const double yk = gm(P.yref)[(t.wave * N + k) * SZ_Y + t.q * 17 + t.lane];
-            qv[t.lane] = wq[t.lane] * (xk - yk);
+            bv[t.lane] = sbv;
+            qv[t.lane] = wq[t.lane] * (sx - sy);
         }
-        if (t.lane < 4) {
-            const double uk = gm(P.uit)[((size_t)t.inst * N + k) * 4 + t.lane];
-            const double yr = gm(P.yref)[(t.wave * N + k) * SZ_Y + t.q * 17 + 13 + t.lane];
-            rv[t.lane] = wr[t.lane] * (uk - yr);
-        }
+        if (t.lane < 4) rv[t.lane] = wr[t.lane] * (su - syu);
+        if (i + 1 < m) load_stage(k + 1);
         __syncthreads();
         // columns G_i can be non-zero in: inputs of stages < i, dx, 1  (na of them)
         const int na = 4 * i + 14;
@@ -293,6 +300,8 @@ struct CfLds {   // LDS carve-up of one group in k_cfactor / k_cipm
     }
 };
 
+__device__ __forceinline__ double p0_of(double piv, double inv) { return piv * inv; }   // sqrt(piv) from its reciprocal root
+
 // One block of the backward recursion.  ABSOLUTE: start solve with the QP's own affine terms;
 // otherwise the homogeneous Newton system of the interior point: the condensed Hessian gets
 // (Rh - R) on the diagonal of its input block and P.g as its input gradient, all other affine terms
@@ -305,11 +314,22 @@ __device__ __forceinline__ bool cfactor_block(const Params& P, const Grp<LPI>& t
     double *H = L.H, *Dm = L.Dm, *Pt = L.Pt, *Y = L.Y;
     const gdouble* cb = cb_ptr(P, t, j);
     const size_t eb = ((size_t)t.inst * N + k0) * 4;   // element-wise arrays of this block's inputs
-    constexpr int W = CfLds<MMAX, LPI>::W, UB = 4;
+    constexpr int W = CfLds<MMAX, LPI>::W;
     __syncthreads();
-    for (int e = t.lane; e < cond_tri(w); e += LPI) H[e] = cb[e];
-    for (int l = 0; l < 13; l++)
-        for (int c = t.lane; c < w; c += LPI) Dm[l * W + c] = cb[cond_tri(w) + l * w + c];
+    {   // the block's H and D: ALL loads first (one HBM round trip instead of one per loop iteration)
+        double hr[CfLds<MMAX, LPI>::U];
+#pragma unroll
+        for (int u = 0; u < CfLds<MMAX, LPI>::U; u++) hr[u] = cb[min(t.lane + LPI * u, cond_tri(w) - 1)];
+        for (int c = t.lane; c < w; c += LPI) {
+            double dr[13];
+#pragma unroll
+            for (int l = 0; l < 13; l++) dr[l] = cb[cond_tri(w) + l * w + c];
+#pragma unroll
+            for (int l = 0; l < 13; l++) Dm[l * W + c] = dr[l];
+        }
+#pragma unroll
+        for (int u = 0; u < CfLds<MMAX, LPI>::U; u++) if (t.lane + LPI * u < cond_tri(w)) H[t.lane + LPI * u] = hr[u];
+    }
     __syncthreads();
     if (!ABSOLUTE) {
         for (int c = t.lane; c < w; c += LPI) H[tri(aff, c)] = c < mu ? gm(P.g)[eb + c] : 0.0;
@@ -346,54 +366,101 @@ __device__ __forceinline__ bool cfactor_block(const Params& P, const Grp<LPI>& t
         }
     }
     __syncthreads();
-    // right-looking Cholesky of the input block (columns 0 .. mu-1); the trailing rows / columns carry
-    // L_xu and the Schur complement.  Both phases of a column are spread over all lanes of the group:
-    // the scaling over the rows below the pivot (a copy of the scaled column goes to `col`), the rank-1
-    // update over the (row, column) pairs of the trailing triangle: entry e of that triangle is (rr, cc)
-    // from the lane's table whatever the column, at H[e + (k + 1) rr + tri(k + 1, k + 1)]
+    // right-looking Cholesky of the input block (columns 0 .. mu-1) in PANELS of four columns (mu = 4 m);
+    // the trailing rows / columns carry L_xu and the Schur complement.  Per panel: (1) every lane owns
+    // one row below / inside the panel: it factors the 4 x 4 diagonal block redundantly (10 broadcast
+    // reads, four reciprocal square roots) and solves its row against it, the finished panel also goes
+    // to `Lp` as [row][4]; (2) rank-4 update of the trailing triangle, entries dealt out lane by lane:
+    // entry e of that triangle is (rr, cc) from the lane's table whatever the panel, at
+    // H[e + c1 rr + tri(c1, c1)] with c1 the first column behind the panel.
     bool ok = true;
-    double* col = Y;
-    for (int k = 0; k < mu; k++) {
-        const double piv = H[tri(k, k)];
-        ok = ok && (piv > 0.0);
-        const double inv = rsqrt_nr(piv);
-        for (int r = k + 1 + t.lane; r < w; r += LPI) {
-            const double v = H[tri(r, k)] * inv;
-            H[tri(r, k)] = v;
-            col[r] = v;
+    double* Lp = Y;
+    for (int c0 = 0; c0 < mu; c0 += 4) {
+        double dd[10];
+#pragma unroll
+        for (int e = 0; e < 10; e++) dd[e] = H[tri(c0, c0) + (e < 1 ? 0 : (e < 3 ? c0 + e : (e < 6 ? 2 * c0 + e : 3 * c0 + e)))];
+        // dd = [d00 | d10 d11 | d20 d21 d22 | d30 d31 d32 d33]  (rows c0 .. c0+3 of the packed triangle)
+        ok = ok && (dd[0] > 0.0);
+        const double i0 = rsqrt_nr(dd[0]);
+        const double l10 = dd[1] * i0, l20 = dd[3] * i0, l30 = dd[6] * i0;
+        const double p1 = dd[2] - l10 * l10;
+        ok = ok && (p1 > 0.0);
+        const double i1 = rsqrt_nr(p1);
+        const double l21 = (dd[4] - l20 * l10) * i1, l31 = (dd[7] - l30 * l10) * i1;
+        const double p2 = dd[5] - l20 * l20 - l21 * l21;
+        ok = ok && (p2 > 0.0);
+        const double i2 = rsqrt_nr(p2);
+        const double l32 = (dd[8] - l30 * l20 - l31 * l21) * i2;
+        const double p3 = dd[9] - l30 * l30 - l31 * l31 - l32 * l32;
+        ok = ok && (p3 > 0.0);
+        const double i3 = rsqrt_nr(p3);
+        __syncthreads();   // everybody has read the diagonal block
+        for (int r = c0 + t.lane; r < w; r += LPI) {
+            double* hr = H + tri(r, c0);
+            double x0, x1, x2, x3;
+            if (r >= c0 + 4) {
+                x0 = hr[0] * i0;
+                x1 = (hr[1] - x0 * l10) * i1;
+                x2 = (hr[2] - x0 * l20 - x1 * l21) * i2;
+                x3 = (hr[3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+                hr[0] = x0; hr[1] = x1; hr[2] = x2; hr[3] = x3;
+            } else {   // rows of the diagonal block itself: L_pp (the packed row holds r - c0 + 1 entries)
+                const int j = r - c0;
+                x0 = j == 0 ? p0_of(dd[0], i0) : (j == 1 ? l10 : (j == 2 ? l20 : l30));
+                x1 = j == 1 ? p0_of(p1, i1) : (j == 2 ? l21 : (j == 3 ? l31 : 0.0));
+                x2 = j == 2 ? p0_of(p2, i2) : (j == 3 ? l32 : 0.0);
+                x3 = j == 3 ? p0_of(p3, i3) : 0.0;
+                hr[0] = x0;
+                if (j >= 1) hr[1] = x1;
+                if (j >= 2) hr[2] = x2;
+                if (j >= 3) hr[3] = x3;
+            }
+            Lp[4 * r + 0] = x0; Lp[4 * r + 1] = x1; Lp[4 * r + 2] = x2; Lp[4 * r + 3] = x3;
         }
-        if (t.lane == 0) L.dinv[k] = inv;
+        if (t.lane == 0) { L.dinv[c0] = i0; L.dinv[c0 + 1] = i1; L.dinv[c0 + 2] = i2; L.dinv[c0 + 3] = i3; }
         __syncthreads();
-        const int sdim = w - 1 - k, T = (sdim * (sdim + 1)) / 2;
-        double* Hk = H + tri(k + 1, k + 1);
-        const double* colk = col + k + 1;
+        const int c1 = c0 + 4, sdim = w - c1, T = (sdim * (sdim + 1)) / 2;
+        double* Hk = H + tri(c1, c1);
+        const double* Lk = Lp + 4 * c1;
 #pragma unroll
         for (int u = 0; u < CfLds<MMAX, LPI>::U; u++) {
             const int e = t.lane + LPI * u;
             if (e < T) {
                 const int rr = L.pk[u] & 255, cc = L.pk[u] >> 8;
-                Hk[e + (k + 1) * rr] -= colk[rr] * colk[cc];
+                const double* lr = Lk + 4 * rr;
+                const double* lc = Lk + 4 * cc;
+                Hk[e + c1 * rr] -= lr[0] * lc[0] + lr[1] * lc[1] + lr[2] * lc[2] + lr[3] * lc[3];
             }
         }
         __syncthreads();
     }
-    // [K | d]' = L_xu L_uu^-1 for the 14 trailing rows, right-looking from the last column: finish
-    // column c, then take its contribution out of the columns before it (14 x c entries in parallel)
-    for (int c = mu - 1; c >= 0; c--) {
-        if (t.lane < 14) H[tri(mu + t.lane, c)] *= L.dinv[c];
+    // [K | d]' = L_xu L_uu^-1 for the 14 trailing rows, right-looking from the last PANEL: (A) lane i < 14
+    // solves its row against the panel's 4 x 4 triangle (finished entries also to `Xp` as [row][4]),
+    // (B) their contribution leaves the columns before the panel: lane = (row i, column group), no
+    // index decoding
+    double* Xp = Y + 4 * W;
+    const int li = t.lane & 15, lg = t.lane >> 4;
+    for (int c0 = mu - 4; c0 >= 0; c0 -= 4) {
+        if (t.lane < 14) {
+            double* hr = H + tri(mu + t.lane, c0);
+            const double l10 = H[tri(c0 + 1, c0)], l20 = H[tri(c0 + 2, c0)], l21 = H[tri(c0 + 2, c0 + 1)];
+            const double l30 = H[tri(c0 + 3, c0)], l31 = H[tri(c0 + 3, c0 + 1)], l32 = H[tri(c0 + 3, c0 + 2)];
+            const double x3 = hr[3] * L.dinv[c0 + 3];
+            const double x2 = (hr[2] - x3 * l32) * L.dinv[c0 + 2];
+            const double x1 = (hr[1] - x3 * l31 - x2 * l21) * L.dinv[c0 + 1];
+            const double x0 = (hr[0] - x3 * l30 - x2 * l20 - x1 * l10) * L.dinv[c0];
+            hr[0] = x0; hr[1] = x1; hr[2] = x2; hr[3] = x3;
+            Xp[4 * t.lane + 0] = x0; Xp[4 * t.lane + 1] = x1; Xp[4 * t.lane + 2] = x2; Xp[4 * t.lane + 3] = x3;
+        }
         __syncthreads();
-        for (int e0 = t.lane; e0 < 14 * c; e0 += UB * LPI) {
-            int ix[UB];
-            double a[UB], b[UB], h[UB];
-#pragma unroll
-            for (int u = 0; u < UB; u++) {
-                const int e = e0 + u * LPI < 14 * c ? e0 + u * LPI : e0;
-                const int c2 = e / 14, i = e - c2 * 14;
-                ix[u] = tri(mu + i, c2);
-                a[u] = H[tri(mu + i, c)]; b[u] = H[tri(c, c2)]; h[u] = H[ix[u]];
-            }
-#pragma unroll
-            for (int u = 0; u < UB; u++) if (e0 + u * LPI < 14 * c) H[ix[u]] = h[u] - a[u] * b[u];
+        if (li < 14) {
+            const double x0 = Xp[4 * li], x1 = Xp[4 * li + 1], x2 = Xp[4 * li + 2], x3 = Xp[4 * li + 3];
+            double* hr = H + tri(mu + li, 0);
+            const double* l0 = H + tri(c0, 0);
+            const double* l1 = H + tri(c0 + 1, 0);
+            const double* l2 = H + tri(c0 + 2, 0);
+            const double* l3 = H + tri(c0 + 3, 0);
+            for (int c2 = lg; c2 < c0; c2 += LPI / 16) hr[c2] -= x0 * l0[c2] + x1 * l1[c2] + x2 * l2[c2] + x3 * l3[c2];
         }
         __syncthreads();
     }
@@ -435,7 +502,7 @@ __device__ __forceinline__ bool csweep_factor(const Params& P, const Grp<LPI>& t
 }
 
 template <int MMAX, int LPI>
-__global__ __launch_bounds__(64) void k_cfactor(Params P) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MMAX <= 5 ? 3 : 2, MMAX <= 5 ? 3 : 2))) void k_cfactor(Params P) {
     constexpr int IPW = 64 / LPI;
     __shared__ double lds[IPW * CfLds<MMAX, LPI>::SZ];
     const Grp<LPI> t = grp_id<LPI>(P, blockIdx.x * IPW);
@@ -450,35 +517,74 @@ __global__ __launch_bounds__(64) void k_cfactor(Params P) {
 // block start, dx+ = Abar dx + Bbar dU.  Writes the input step (all N stages) to `out`.
 template <int MMAX, int LPI>
 __device__ __forceinline__ void csweep_forward_delta(const Params& P, const Grp<LPI>& t, CfLds<MMAX, LPI>& L, double* out) {
+    // Per block: dU = -(d + K dx), dx+ = D [dU; dx].  K (4m x 13, just written by the factorisation), d and
+    // the block's D come from global memory: all lanes fetch them in ONE batch into registers -- for
+    // block j + 1 before the arithmetic of block j -- and hand them over through LDS (Dm and Y are free
+    // between factorisations), so a block costs no exposed round trip.
+    constexpr int W = CfLds<MMAX, LPI>::W;
+    constexpr int ND = (13 * W + LPI - 1) / LPI, NK = (13 * 4 * MMAX + LPI - 1) / LPI;
     const int N = P.N;
-    double* xs = L.xs;      // dx at the block start
-    double* U = L.Y;        // dU of the block (<= 4 MMAX entries; Y is free between factorisations)
+    double* xs = L.xs;              // dx at the block start
+    double* Kl = L.Y;               // [c][13]
+    double* U = L.Y + 13 * 4 * MMAX;   // dU of the block
+    double* Dm = L.Dm;              // [13][W]
+    double dr[ND], kr[NK], dd;
+    auto fetch = [&](const int j) {
+        const int m = cond_len(P, j), k0 = cond_start(P, j);
+        const int mu = 4 * m, w = mu + 14;
+        const gdouble* cbD = cb_ptr(P, t, j) + cond_tri(w);
+#pragma unroll
+        for (int u = 0; u < ND; u++) {
+            const int e = t.lane + LPI * u, l = min(e / W, 12), c = min(e - (e / W) * W, w - 1);
+            dr[u] = cbD[l * w + c];
+        }
+#pragma unroll
+        for (int u = 0; u < NK; u++) {
+            const int e = t.lane + LPI * u, c = min(e / 13, mu - 1), l = e - (e / 13) * 13;
+            kr[u] = gm(P.KR)[(t.wave * N + k0 + (c >> 2)) * SZ_K + (l * 4 + t.q) * 4 + (c & 3)];
+        }
+        dd = gm(P.d)[((size_t)t.inst * N + k0) * 4 + min(t.lane, mu - 1)];
+    };
     __syncthreads();
     if (t.lane < 13) xs[t.lane] = 0.0;
-    __syncthreads();
+    fetch(0);
     for (int j = 0; j < P.cond_N2; j++) {
         const int m = cond_len(P, j), k0 = cond_start(P, j);
         const int mu = 4 * m, w = mu + 14;
         const size_t eb = ((size_t)t.inst * N + k0) * 4;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < ND; u++) {
+            const int e = t.lane + LPI * u, l = e / W, c = e - l * W;
+            if (l < 13 && c < w) Dm[e] = dr[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NK; u++) {
+            const int e = t.lane + LPI * u;
+            if (e < 13 * mu) Kl[e] = kr[u];
+        }
+        const double dj = dd;
+        if (j + 1 < P.cond_N2) fetch(j + 1);
+        __syncthreads();
         for (int c = t.lane; c < mu; c += LPI) {
-            const int k = k0 + (c >> 2), a = c & 3;
-            const gdouble* kr = gm(P.KR) + (t.wave * N + k) * SZ_K + t.q * 4 + a;
-            double acc = gm(P.d)[eb + c];
-            for (int l = 0; l < 13; l++) acc += kr[l * 16] * xs[l];
+            double acc = dj;
+#pragma unroll
+            for (int l = 0; l < 13; l++) acc += Kl[c * 13 + l] * xs[l];
             U[c] = -acc;
             gm(out)[eb + c] = -acc;
         }
         __syncthreads();
         double xn = 0.0;
         if (t.lane < 13) {
-            const gdouble* Dr = cb_ptr(P, t, j) + cond_tri(w) + t.lane * w;
+            const double* Dr = Dm + t.lane * W;
             for (int c = 0; c < mu; c++) xn += Dr[c] * U[c];
+#pragma unroll
             for (int l = 0; l < 13; l++) xn += Dr[mu + l] * xs[l];
         }
         __syncthreads();
         if (t.lane < 13) xs[t.lane] = xn;
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
