@@ -138,3 +138,42 @@ def test_condensed_mixed_horizon_fleet(oracle):
     assert np.abs(u0c - u0p).max() < 1e-6 and np.abs(u1c - u1p).max() < 1e-6 and np.abs(x4c - x4p).max() < 1e-6
     with pytest.raises(CfnmpcError):
         MixedHorizonFleet(hz, cond_N2=5)          # N = 100 would need 20-stage blocks
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_condensed_randomised_horizons_blocks_and_options(oracle, cref, seed):
+    """Seeded fuzz: horizon, number of blocks (uneven splits included, block lengths 1..10), interval,
+    weights, box and batch at once -- the condensed path against the CPU restatement's interior point
+    (both at tol 1e-11), two closed-loop steps."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(8800 + seed)
+    Nh = int(rng.integers(6, 65))
+    lo = -(-Nh // 10)                                   # blocks of at most 10 stages
+    N2 = int(rng.integers(lo, Nh))                      # lo <= N2 < N
+    dt = float(rng.uniform(0.008, 0.025))
+    B = int(rng.integers(1, 90))
+    d = default_opts()
+    W = np.array(list(d.W)) * np.exp(rng.uniform(np.log(0.5), np.log(2.0), 17))
+    WN = np.array(list(d.WN)) * np.exp(rng.uniform(np.log(0.5), np.log(2.0), 13))
+    u_min, u_max = float(rng.uniform(0.0, 6.0)), float(rng.uniform(19.0, 24.0))
+    x0 = oracle.sample_hover_x0(rng, B, scale=float(rng.uniform(0.5, 2.0)))
+    yr, ye = oracle.regulation_yref(Nh, (0.1, -0.1, 0.5))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    kw = dict(N=Nh, dt=dt, W=W, WN=WN, u_min=u_min, u_max=u_max, tol=1e-11)
+    s = BatchSolver(B, default_opts(cond_N2=N2, **kw))
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    xr = np.repeat(x0[:, None, :], Nh + 1, 1).copy(); ur = np.full((B, Nh, 4), HOV)
+    opts = cref.default_opts(active_set=0, **kw)
+    x = x0.copy()
+    for t in range(2):
+        s.set_x0(x); s.solve(1)
+        st, it, _ = s.stats()
+        xg, ug = s.get_iterate()
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        assert (st == st_r).all(), (seed, Nh, N2, B)
+        ok = st == 0
+        assert ok.mean() > 0.9 and ((it > 0) == (it_r > 0))[ok].all()
+        assert np.abs(ug - ur)[ok].max() < 5e-6 and np.abs(xg - xr)[ok].max() < 5e-6, (seed, Nh, N2, B)
+        xr[:] = xg; ur[:] = ug
+        x = xg[:, 1, :].copy()
