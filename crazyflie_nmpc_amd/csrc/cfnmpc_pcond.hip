@@ -13,8 +13,9 @@
 //               independent (grid = instances x N2).
 //   k_cfactor : Riccati recursion over the N2 condensed stages, backward: H~ = H + E'P~E with
 //               E = [D; e_1] and the augmented cost-to-go P~ (13 x 13 matrix + affine row), ONE dense
-//               Cholesky factorisation of the 4m x 4m input block per stage (right-looking, in LDS),
-//               gains K (4m x 13) and feed-forward d by back-substitution, P~ <- Schur complement.
+//               Cholesky factorisation of the 4m x 4m input block per stage (right-looking in panels of
+//               four columns, in LDS), gains K (4m x 13) and feed-forward d by panel-wise
+//               back-substitution, P~ <- Schur complement.
 //               The gains are stored per ORIGINAL stage in the layout of the uncondensed path.
 //   k_forward<COND> (cfnmpc_kernels.hip): forward sweep + `expand`: the inputs of a block are the
 //               condensed feedback law at the state of the block's START, the interior states follow
@@ -27,7 +28,9 @@
 // Mapping: one instance per group of LPI lanes -- the code is generic in LPI, the launchers use 64 (one
 // instance per wavefront: measured 3-5x faster than 16 lanes per instance, since the LDS footprint per
 // INSTANCE fixes how many instances a CU holds either way) --, all dense blocks of an instance in LDS,
-// generic loops (the block length m is a run-time value up to the template's MMAX).  This path is an
+// the block length m is a run-time value up to the template's MMAX (leading dimensions are the template's).
+// Global loads are batched and issued ahead everywhere: a load inside a run-time loop costs one HBM round
+// trip per iteration, which dominated the first version of these kernels.  This path is an
 // OPTION (parity with the reference's solver plan + the N2 sweep of DESIGN.md section 5.8), not the
 // default: condensing raises both the bytes per stage and the flops for this problem's sizes.
 #include <hip/hip_runtime.h>
