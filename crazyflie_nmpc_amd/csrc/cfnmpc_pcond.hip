@@ -526,6 +526,7 @@ __device__ __forceinline__ void csweep_forward_delta(const Params& P, const Grp<
     // between factorisations), so a block costs no exposed round trip.
     constexpr int W = CfLds<MMAX, LPI>::W;
     constexpr int ND = (13 * W + LPI - 1) / LPI, NK = (13 * 4 * MMAX + LPI - 1) / LPI;
+    static_assert(LPI >= 4 * MMAX, "one input of a block per lane (dd)");
     const int N = P.N;
     double* xs = L.xs;              // dx at the block start
     double* Kl = L.Y;               // [c][13]
