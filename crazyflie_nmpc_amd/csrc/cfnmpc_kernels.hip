@@ -506,10 +506,13 @@ static_assert(WT_TILE >= 13 * WT_ROW && WT_TILE % 2 == 0, "W transpose tile");
 //           stage k.  ABSOLUTE: start solve with the QP's own affine terms (q_k, b_k, r_k);
 //   otherwise R^ and g come from the interior-point state (homogeneous Newton system).
 //   wt: LDS [13*17] (transpose of W), sb: LDS [4*16] (columns of B for lanes 0..3).
-template <bool ABSOLUTE, bool AS = false>
+//   ZL: the stage's outputs go to the instance-contiguous compact store of the level-synchronous
+//   active-set passes (t.inst = compact slot; layouts at zrow() below); act = false: compute only,
+//   store nothing (a row of a pass wave that has not joined the backward sweep yet).
+template <bool ABSOLUTE, bool AS = false, bool ZL = false>
 __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, const int k, double (&Pa)[13],
                                              const StageIn<ABSOLUTE>& in, const double wq, const double is13,
-                                             double* wt, double* sb) {
+                                             double* wt, double* sb, const bool act = true) {
     const double(&ar)[10] = in.ar;
     const double(&br)[4] = in.br;
     if (ABSOLUTE) {
@@ -554,9 +557,9 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     dot2bc<13, 0>(Srow[0], Srow[1], bcl, V[0], V[1]);
     dot2bc<13, 0>(Srow[2], Srow[3], bcl, V[2], V[3]);
     SFOR(c, 0, 4, { settle(Srow[c]); });
-    if (AS && t.L < 4) {
-        gdouble* sr = blk(P.cS, t, P.N, k, SZ_S4) + t.q * 4 + t.L;
-        SFOR(c, 0, 4, { sr[c * 16] = Srow[c]; });
+    if (AS && t.L < 4 && act) {
+        gdouble* sr = ZL ? gm(P.cS) + ((size_t)t.inst * P.N + k) * 16 + t.L : blk(P.cS, t, P.N, k, SZ_S4) + t.q * 4 + t.L;
+        SFOR(c, 0, 4, { sr[c * (ZL ? 4 : 16)] = Srow[c]; });
     }
     double S[10], Si[10];
     SFOR(a, 0, 4, { SFOR(c, a, 4, { S[s4(a, c)] = bc<a>(Srow[c]); }); });
@@ -588,9 +591,10 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         // active-set solve: the forward sweep evaluates the multipliers of the fixed inputs from the
         // stage's own blocks, B'pi_{k+1} = G dx_k + (B'PB) du_free + rho -- keep G (gain layout),
         // rho (lane 13) and the rows of S (off-diagonal entries = B'PB, untouched by the fixing weight)
-        gdouble* gr = blk(P.cGR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
+        gdouble* gr = ZL ? gm(P.cGR) + ((size_t)t.inst * P.N + k) * 52 + imin(t.L, 12) * 4
+                         : blk(P.cGR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
         gdouble* dst = t.L == 13 ? gm(P.crho) + i4(P, t, k, 0) : gr;
-        if (t.L < 14) SFOR(a, 0, 4, { dst[a] = Gp[a]; });
+        if (t.L < 14 && act) SFOR(a, 0, 4, { dst[a] = Gp[a]; });
     }
     chol4_finish(ch, Si);
     const bool ok = ch.ok;
@@ -611,9 +615,10 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     {
         // lanes 0..12 store their column of the gain, lane 13 the feed-forward: one masked
         // region with per-lane addresses
-        gdouble* kr = blk(P.KR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
+        gdouble* kr = ZL ? gm(P.KR) + ((size_t)t.inst * P.N + k) * 52 + imin(t.L, 12) * 4
+                         : blk(P.KR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
         gdouble* dst = t.L == 13 ? gm(P.d) + i4(P, t, k, 0) : kr;
-        if (t.L < 14) SFOR(a, 0, 4, { dst[a] = Kp[a]; });
+        if (t.L < 14 && act) SFOR(a, 0, 4, { dst[a] = Kp[a]; });
         if (!ABSOLUTE && t.L == 0) {  // only the corrector of the interior-point iteration reads it
             gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S);
             SFOR(e, 0, 10, { sv[t.q * 10 + e] = Si[e]; });
@@ -1374,6 +1379,7 @@ __global__ __launch_bounds__(256) void k_scatter(Params P) {
         base[N_BIN] = acc;
         if (blockIdx.x == 0) gm(P.nipm)[0] = acc;
     }
+    if (blockIdx.x == 0 && P.ascnt && threadIdx.x < 32) gm(P.ascnt)[threadIdx.x] = 0;   // work lists of the active-set passes
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P.B) return;
@@ -1437,7 +1443,9 @@ __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave
 // One wave = four compacted constrained instances.  MODE 0: everything (active-set solves if
 // P.active_set, then the interior point for the rows that did not settle); MODE 1: active-set
 // solves only -- rows that settle and pass the tail check are finished and flagged in P.done, the
-// others are left untouched for a MODE 2 launch; MODE 2: interior point for the rows without flag.
+// others are left untouched for a MODE 2 launch; MODE 2: interior point for the rows without flag;
+// MODE 3: MODE 1 for the rows the level-synchronous pipeline's commit kernel flagged (P.done = 2: settled,
+// but a tail input left the box -- solve again over the longer head it wrote to P.head).
 template <int MODE>
 __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64]) {
 #ifdef CFN_PROF
@@ -1450,8 +1458,9 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     if (blockIdx.x * 4 >= nipm) return;  // wave-uniform: no work for this wave
     bool has = slot < nipm;
     const int inst0 = has ? gm(P.ilist)[imin(slot, nipm - 1)] : 0;
-    if (MODE == 2) {
-        has = has && gm(P.done)[inst0] == 0;
+    constexpr bool AS_ONLY = MODE == 1 || MODE == 3;
+    if (MODE == 2 || MODE == 3) {   // MODE 2: rows left for the interior point (done = 0); MODE 3: rows the
+        has = has && gm(P.done)[inst0] == (MODE == 2 ? 0 : 2);   // commit kernel sent back for a longer head (done = 2)
         if (!__any(has)) return;
     }
     const Lane t = lane_indirect(P, inst0, has);
@@ -1509,7 +1518,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         }
     };
     RowIPM R;
-    bool accepted = MODE != 1;   // MODE 1: only rows finished by the active-set solve are final
+    bool accepted = !AS_ONLY;   // MODE 1: only rows finished by the active-set solve are final
 
     for (int attempt = 0; attempt < 3; attempt++) {
         R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
@@ -1567,7 +1576,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             }
         }
         if (as_done) { R.status = 0; R.iters = as_iters; }
-        if constexpr (MODE != 1) {
+        if constexpr (!AS_ONLY) {
         if (infeasible && !as_done) {
             // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
             const double mu0 = fmax(P.mu0_scale * viol, P.lam0_min);
@@ -1731,7 +1740,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 }
             }
         }
-        }   // MODE != 1
+        }   // !AS_ONLY
 
         PROF_T(4)
         // ---- expand: dynamics-exact roll-out; head stages use the QP inputs, tail stages the
@@ -1776,8 +1785,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         // MODE 1: a row is finished iff its active set settled and its tail stays in the box; a
         // settled row whose tail leaves the box gets a longer head (below), one that did not
         // settle is left to the interior-point kernel
-        if (MODE == 1) accepted = as_done && kviol < 0;
-        const bool redo = MODE == 1 ? (t.valid && as_done && kviol >= 0 && head < N)
+        if (AS_ONLY) accepted = as_done && kviol < 0;
+        const bool redo = AS_ONLY ? (t.valid && as_done && kviol >= 0 && head < N)
                                     : (t.valid && R.status != 4 && kviol >= 0 && head < N);
         if (!__any(redo)) break;
         // rare: a tail input left the box -> solve again (whole wave) over the smallest head class
@@ -1790,7 +1799,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         chk = -1;
         SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
     }
-    if (MODE == 1 && t.L == 0 && t.valid) gm(P.done)[t.inst] = accepted ? 1 : 0;
+    if (AS_ONLY && t.L == 0 && t.valid) gm(P.done)[t.inst] = accepted ? 1 : 0;
     if (t.L == 0 && infeasible && accepted) {
         gm(P.status)[t.inst] = R.status;
         gm(P.iters)[t.inst] = R.iters;
@@ -1799,7 +1808,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     }
     // the roll-out already left the new iterate of an accepted row in place; a row whose QP failed
     // keeps its old iterate (MODE 1 leaves the rows it did not finish to the MODE 2 launch)
-    keep_row(P, t, MODE != 1 && infeasible && !(accepted && R.status != 4));
+    keep_row(P, t, !AS_ONLY && infeasible && !(accepted && R.status != 4));
 #ifdef CFN_PROF
     PROF_T(7)
     if (threadIdx.x == 0) {
@@ -1830,6 +1839,487 @@ __global__ __launch_bounds__(64) void k_ipm_rest(Params P) {  // interior point 
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
     qp_wave<2>(P, wtile, btile);
+}
+__global__ __launch_bounds__(64) void k_as_retry(Params P) {  // MODE 3: rows the commit kernel sent back
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<3>(P, wtile, btile);
+}
+
+// =============================================================================================
+// Level-synchronous active-set passes (cfnmpc_opts.as_pipeline)
+// =============================================================================================
+// The monolithic k_as keeps four constrained instances in one wave until the slowest of them has
+// settled (up to 12 solves + roll-out + retries, 432 registers, one wave per SIMD): the kernel lasts as
+// long as its hardest wave and its SIMDs idle behind rows that finished long ago.  Here ONE launch =
+// ONE active-set solve (backward factorisation with the fixed inputs + forward sweep with
+// re-classification) of every instance that has not settled yet:
+//   k_asp<true>  : pass 0 over the compacted list (k_scatter order: head class x difficulty); gathers the
+//                  head stages from the instance's home blocks on the way (the backward sweep reads A, B
+//                  there and leaves a compact copy);
+//   k_asp<false> : pass p >= 1 over the work list the previous pass appended to (atomic append into bins
+//                  by restart stage, longest first, so that the four rows of a wave sweep similar
+//                  lengths); the last launch loops in-wave over the remaining solves (few rows left);
+//   k_ascommit   : rows that settled: new iterate = candidate of the start solve + delta (head stages:
+//                  element-wise from the pass's own du / dx; tail: delta rolled through the closed loop
+//                  A - B K of the unconstrained feedback law, whose inputs are verified against the box);
+//                  a row whose tail leaves the box is handed to k_as_retry (longer head), one that did not
+//                  settle to k_ipm_rest -- both normally find nothing to do.
+// The kernels hold only the two active-set sweeps (<= 256 registers: two waves per SIMD) and run a
+// grid-stride loop over groups of four rows.  Compact store, INSTANCE-CONTIGUOUS (a row may sit in
+// any wave from pass to pass): slot c owns field + (c N + k) S, S = 97 (A: [slot][lanes < ar_n]),
+// 52 (B: [a][13]), 52 (K, G: [l][4]), 16 (rows of S: [c][a]), 4 (element state, instance-major as before),
+// 13 per stage 0..N (dx), 14 x 13 per saved cost-to-go.  Results do not depend on which rows share a
+// wave: every row restarts its factorisation at its own stage with its own saved cost-to-go.
+constexpr int AS_NKB = 7, AS_SETS = 3;
+__host__ __device__ constexpr int as_kbin(int len) {   // len = stages the next factorisation covers
+    return len > 32 ? 0 : (len > 24 ? 1 : (len > 16 ? 2 : (len > 12 ? 3 : (len > 8 ? 4 : (len > 4 ? 5 : 6)))));
+}
+__device__ __forceinline__ void zld_ar_raw(const gdouble* b, const Lane& t, double (&ar)[10]) {
+    SFOR(s, 0, 10, { ar[s] = b[ar_pre(s) + imin(t.L, ar_n(s) - 1)]; });
+}
+__device__ __forceinline__ void zld_ar(const gdouble* b, const Lane& t, double (&ar)[10]) {
+    SFOR(s, 0, 10, {
+        const double v = b[ar_pre(s) + imin(t.L, ar_n(s) - 1)];
+        ar[s] = t.L < ar_n(s) ? v : 0.0;
+    });
+}
+__device__ __forceinline__ void zld_rows4_raw(const gdouble* b, const Lane& t, double (&r)[4]) {
+    SFOR(a, 0, 4, { r[a] = b[a * 13 + imin(t.L, 12)]; });
+}
+__device__ __forceinline__ void zld_rows4(const gdouble* b, const Lane& t, double (&r)[4]) {
+    SFOR(a, 0, 4, {
+        const double v = b[a * 13 + imin(t.L, 12)];
+        r[a] = t.L < 13 ? v : 0.0;
+    });
+}
+struct ZStage {
+    StageIn<true> in;
+    double v0, uk, c, cls;   // lanes a < 4 (replicated over a = L & 3)
+};
+// issue the loads of stage k (no use of the values here: the caller consumes them one stage later)
+template <bool FIRST>
+__device__ __forceinline__ void zload_stage(const Params& P, const Params& Q, const Lane& th, const Lane& tc, const int k,
+                                            ZStage& z) {
+    const int a = tc.L & 3;
+    if (FIRST) {   // from the instance's home blocks (interleaved with its three wave-mates)
+        ld_ar_raw(blk(P.AR, th, P.N, k, SZ_A), th, z.in.ar);
+        ld_rows4_raw(blk(P.BR, th, P.N, k, SZ_B), th, z.in.br);
+        z.v0 = gm(P.v)[i4(P, th, k, a)];
+        z.uk = gm(P.uit)[i4(P, th, k, a)];
+        z.c = 0.0; z.cls = 0.0;
+    } else {
+        const size_t s = (size_t)tc.inst * P.N + k;
+        zld_ar_raw(gm(Q.AR) + s * 97, tc, z.in.ar);
+        zld_rows4_raw(gm(Q.BR) + s * 52, tc, z.in.br);
+        z.c = gm(Q.tl)[i4(Q, tc, k, a)];
+        z.cls = gm(Q.tu)[i4(Q, tc, k, a)];
+        z.v0 = 0.0; z.uk = 0.0;
+    }
+}
+// Backward sweep of one active-set solve over stages kw .. 0 (kw = the wave's largest restart stage).
+// Row state: head (its own head class), chk (checkpoint index of that class, -1: terminal cost),
+// join (the stage ITS sweep starts at: head - 1, or the last stage whose class changed in the previous
+// solve; -1: the row takes no part).  A row computes from stage kw on (wave-uniform code) but loads
+// its cost-to-go when the sweep reaches `join` and stores nothing before that.
+template <bool FIRST>
+__device__ __forceinline__ bool zsweep_factor(const Params& P, const Params& Q, const Lane& th, const Lane& tc,
+                                              const int head, const int chk, const int join, const int kw,
+                                              double* wt, double* sb) {
+    double Pa[13];
+    SFOR(j, 0, 13, { Pa[j] = 0.0; });
+    double wq = 0.0;
+    SFOR(j, 0, 13, { if (tc.L == j) wq = P.W[ext_of(j)]; });
+    const double is13 = tc.L == 13 ? 1.0 : 0.0;
+    auto start_row = [&](int k) {   // rows with join == k: cost-to-go of stage k + 1
+        if (k != join) return;
+        if (k + 1 < head) {         // saved by an earlier solve of this instance
+            const gdouble* ps = gm(Q.cPs) + ((size_t)tc.inst * AS_PSAVE + (k + 1)) * 182 + imin(tc.L, 13);
+            SFOR(j, 0, 13, { Pa[j] = ps[j * 14]; });
+        } else if (chk < 0) {
+            SFOR(j, 0, 13, { Pa[j] = (tc.L == j) ? P.WN[ext_of(j)] : 0.0; });
+        } else {                    // checkpoint of the unconstrained tail (home block)
+            const gdouble* pc = gm(P.Pchk) + ((size_t)th.wave * N_CHK + chk) * SZ_P;
+            SFOR(j, 0, 13, {
+                const double v = pc[(j * 4 + th.q) * 13 + imin(tc.L, 12)];
+                Pa[j] = tc.L < 13 ? v : 0.0;
+            });
+        }
+    };
+    bool ok = true;
+    auto stage = [&](ZStage& z, int k) {
+        if (__any(k == join)) start_row(k);
+        const bool act = k <= join;
+        const int a = tc.L & 3;
+        if (FIRST) {   // initial classification from the unconstrained minimiser
+            const double lb = P.u_min - z.uk, ub = P.u_max - z.uk;
+            z.cls = z.v0 < lb ? 1.0 : (z.v0 > ub ? 2.0 : 0.0);
+            z.c = z.cls == 1.0 ? lb - z.v0 : (z.cls == 2.0 ? ub - z.v0 : 0.0);
+            if (act) {     // compact copy of the stage
+                const size_t s = (size_t)tc.inst * P.N + k;
+                gdouble* ca = gm(Q.AR) + s * 97;
+                SFOR(sl, 0, 10, { if (tc.L < ar_n(sl)) ca[ar_pre(sl) + tc.L] = z.in.ar[sl]; });
+                gdouble* cb = gm(Q.BR) + s * 52;
+                SFOR(aa, 0, 4, { if (tc.L < 13) cb[aa * 13 + tc.L] = z.in.br[aa]; });
+                if (tc.L < 4) {
+                    const size_t idx = i4(Q, tc, k, tc.L);
+                    gm(Q.v)[idx] = z.v0; gm(Q.uit)[idx] = z.uk; gm(Q.tl)[idx] = z.c; gm(Q.tu)[idx] = z.cls;
+                }
+            }
+        }
+        const double ra = tc.wu;
+        z.in.Rh = z.cls != 0.0 ? AS_BIG * fmax(1.0, ra) : ra;
+        z.in.g = 0.0;
+        z.in.qv = 0.0;
+        const double cm = tc.L < 4 ? z.c : 0.0;
+        double bv = 0.0;
+        SFOR(aa, 0, 4, { bv += z.in.br[aa] * bc<aa>(cm); });
+        z.in.bv = bv;
+        (void)a;
+        const bool fo = factor_stage<true, true, true>(Q, tc, k, Pa, z.in, wq, is13, wt, sb, act);
+        ok = ok && (fo || !act);
+        if (act && k > 0 && k < AS_PSAVE && tc.L < 14) {
+            gdouble* ps = gm(Q.cPs) + ((size_t)tc.inst * AS_PSAVE + k) * 182 + tc.L;
+            SFOR(j, 0, 13, { ps[j * 14] = Pa[j]; });
+        }
+    };
+    ZStage bufA, bufB;
+    zload_stage<FIRST>(P, Q, th, tc, kw, bufA);
+    int k = kw;
+    while (k >= 0) {
+        zload_stage<FIRST>(P, Q, th, tc, imax(k - 1, 0), bufB);
+        stage(bufA, k);
+        if (--k < 0) break;
+        zload_stage<FIRST>(P, Q, th, tc, imax(k - 1, 0), bufA);
+        stage(bufB, k);
+        --k;
+    }
+    return ok;
+}
+// Forward sweep of the solve over stages [0, hw) (hw = the wave's largest head): du -> Q.dva, dx -> P.czdx,
+// multipliers and re-classification on the way (sweep_forward_as on the compact z layout).  Returns the
+// last stage < head of the row in which an input changed its class (-1: none).
+__device__ __forceinline__ int zsweep_forward(const Params& P, const Params& Q, const Lane& tc, const int head, const int hw) {
+    struct In { double kg[13], ar[10], br[4], d, sr[4], rho, c, cls, v0, uk; };
+    const int a = tc.L & 3;
+    const bool lo4 = tc.L < 4;
+    auto load = [&](int k, In& in) {
+        const size_t s = (size_t)tc.inst * P.N + k;
+        const gdouble* src = (lo4 ? gm(Q.KR) : gm(Q.cGR)) + s * 52 + a;
+        SFOR(l, 0, 13, { in.kg[l] = src[l * 4]; });
+        zld_ar(gm(Q.AR) + s * 97, tc, in.ar);
+        zld_rows4(gm(Q.BR) + s * 52, tc, in.br);
+        const gdouble* sr = gm(Q.cS) + s * 16 + a;
+        SFOR(c, 0, 4, { in.sr[c] = sr[c * 4]; });
+        const size_t idx = i4(Q, tc, k, a);
+        in.d = gm(Q.d)[idx];
+        in.rho = gm(Q.crho)[idx];
+        in.c = gm(Q.tl)[idx]; in.cls = gm(Q.tu)[idx]; in.v0 = gm(Q.v)[idx]; in.uk = gm(Q.uit)[idx];
+    };
+    double x = 0.0;
+    int jm = -1;
+    gdouble* zx = gm(P.czdx) + (size_t)tc.inst * (P.N + 1) * 13 + imin(tc.L, 12);
+    auto body = [&](const In& cur, int k) {
+        double acc = 0.0;
+        dotbc<13, 0>(acc, cur.kg, x);        // lanes 0..3: K[a] dx, lanes 4..7: G[a] dx
+        settle(acc);
+        double dv = lo4 ? -cur.d - acc : 0.0;
+        dv = (lo4 && cur.cls != 0.0) ? cur.c : dv;
+        if (lo4) gm(Q.dva)[i4(Q, tc, k, tc.L)] = dv;
+        double gd = shift4(acc);             // lane a <- lane a + 4
+        double vr[4], fr[4];
+        SFOR(c, 0, 4, { vr[c] = bc<c>(dv); });
+        const double dfree = cur.cls == 0.0 ? dv : 0.0;
+        SFOR(c, 0, 4, { fr[c] = bc<c>(dfree); });
+        SFOR(c, 0, 4, { gd += cur.sr[c] * fr[c]; });     // + (B'PB)[a][free] du_free
+        if (lo4) {
+            const double grad = tc.wu * cur.c + gd + cur.rho;   // multiplier of a fixed input
+            const double lb = P.u_min - cur.uk, ub = P.u_max - cur.uk;
+            const double vn = cur.v0 + dv;
+            double nc;
+            if (cur.cls == 0.0) nc = vn < lb ? 1.0 : (vn > ub ? 2.0 : 0.0);
+            else if (cur.cls == 1.0) nc = grad > 0.0 ? 1.0 : 0.0;
+            else nc = grad < 0.0 ? 2.0 : 0.0;
+            jm = (nc != cur.cls && k < head) ? k : jm;
+            const size_t idx = i4(Q, tc, k, a);
+            gm(Q.tu)[idx] = nc;
+            gm(Q.tl)[idx] = nc == 1.0 ? lb - cur.v0 : (nc == 2.0 ? ub - cur.v0 : 0.0);
+        }
+        double xn = tc.L < 3 ? x : 0.0;
+        dotbc<10, 3>(xn, cur.ar, x);
+        SFOR(c, 0, 4, { xn += cur.br[c] * vr[c]; });
+        x = xn;
+        if (tc.L < 13) zx[(size_t)(k + 1) * 13] = x;   // dx_{k+1} of this solve
+    };
+    In b0, b1;
+    load(0, b0);
+    int k = 0;
+    while (k < hw) {
+        load(imin(k + 1, hw - 1), b1);
+        body(b0, k);
+        if (++k >= hw) break;
+        load(imin(k + 1, hw - 1), b0);
+        body(b1, k);
+        ++k;
+    }
+    return (int)row_max((double)jm);
+}
+__device__ __forceinline__ Params compact_params(const Params& P) {
+    Params Q = P;
+    Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
+    return Q;
+}
+// One group of four rows of a pass: compact slots, home lanes, per-row sweep state.
+struct AspGroup {
+    Lane th, tc;
+    int c, inst, head, chk, join;
+    bool has;
+};
+struct AspLists {   // work lists of this pass
+    int nwork, pre[AS_NKB], set_in, set_out, cap;
+};
+template <bool FIRST>
+__device__ __forceinline__ AspLists asp_lists(const Params& P, const int pass) {
+    AspLists w;
+    w.cap = (P.NW + 1) * 4;   // compact slots incl. the four spare ones
+    w.set_in = pass % AS_SETS; w.set_out = (pass + 1) % AS_SETS;
+    w.nwork = 0;
+    if (FIRST) {
+        w.nwork = gm(P.nipm)[0];
+    } else {
+        SFOR(b, 0, AS_NKB, { w.pre[b] = w.nwork; w.nwork += gm(P.ascnt)[w.set_in * AS_NKB + b]; });
+    }
+    return w;
+}
+template <bool FIRST>
+__device__ __forceinline__ AspGroup asp_group(const Params& P, const AspLists& w, const int g) {
+    AspGroup r;
+    const int row = threadIdx.x >> 4;
+    const int wi = g * 4 + row;
+    r.has = wi < w.nwork;
+    r.c = w.cap - 4 + row;         // rows without work scribble on a spare slot
+    if (r.has) {
+        if (FIRST) {
+            r.c = wi;
+        } else {
+            int b = 0, base = 0;
+            SFOR(bb, 1, AS_NKB, { if (wi >= w.pre[bb]) { b = bb; base = w.pre[bb]; } });
+            r.c = gm(P.aslist)[(size_t)(w.set_in * AS_NKB + b) * w.cap + (wi - base)];
+        }
+    }
+    r.inst = r.has ? gm(P.ilist)[r.c] : 0;
+    r.th = lane_indirect(P, r.inst, r.has);
+    r.tc = r.th;
+    r.tc.inst = r.c; r.tc.wave = r.c >> 2; r.tc.q = r.c & 3;
+    r.head = r.has ? gm(P.head)[r.inst] : 0;
+    r.chk = -1;
+    SFOR(cc, 0, N_CHK, { if (r.head == chk_stage(cc) && r.head < P.N) r.chk = cc; });
+    r.join = r.has ? (FIRST ? r.head - 1 : gm(P.askst)[r.c]) : -1;
+    return r;
+}
+__device__ __forceinline__ int wave_max(int v) {   // over the four rows (v is row-uniform)
+    v = max(v, __shfl_xor(v, 16));
+    return max(v, __shfl_xor(v, 32));
+}
+// what becomes of a row after a solve: settled -> commit; not positive definite or out of solves -> interior
+// point; otherwise it joins the next pass's list, binned by the length of its next factorisation
+__device__ __forceinline__ void asp_finish(const Params& P, const AspLists& w, const AspGroup& r, const int solves,
+                                           const bool ok, const int jm) {
+    if (!r.has || r.tc.L != 0) return;
+    if (ok && jm < 0) {
+        gm(P.asst)[r.c] = 1;
+        gm(P.iters)[r.inst] = solves;
+    } else if (!ok || solves >= AS_MAX_SOLVES) {
+        gm(P.asst)[r.c] = 0;
+    } else {
+        const int join = (jm + 1 < AS_PSAVE) ? jm : r.head - 1;   // restart stage of the next factorisation
+        gm(P.askst)[r.c] = join;
+        const int b = as_kbin(join + 1);
+        const int pos = atomicAdd(P.ascnt + w.set_out * AS_NKB + b, 1);
+        gm(P.aslist)[(size_t)(w.set_out * AS_NKB + b) * w.cap + pos] = r.c;
+    }
+}
+// pass p, backward half: one factorisation per listed row; leaves `ok` per compact slot
+template <bool FIRST>
+__device__ __forceinline__ void asf_body(const Params& P, const int pass, double (*wtile)[WT_TILE], double (*btile)[64]) {
+    const AspLists w = asp_lists<FIRST>(P, pass);
+    const Params Q = compact_params(P);
+    const int row = threadIdx.x >> 4;
+    for (int g = blockIdx.x; g * 4 < w.nwork; g += gridDim.x) {
+        const AspGroup r = asp_group<FIRST>(P, w, g);
+        const int kw = wave_max(r.join);
+        if (kw < 0) continue;
+        bool ok = zsweep_factor<FIRST>(P, Q, r.th, r.tc, r.head, r.chk, r.join, kw, wtile[row], btile[row]);
+        ok = row_min(ok ? 1.0 : 0.0) > 0.0;
+        if (r.has && r.tc.L == 0) gm(P.asok)[r.c] = ok ? 1 : 0;
+    }
+}
+// pass p, forward half: inputs, multipliers, re-classification; builds the next pass's lists
+template <bool FIRST>
+__device__ __forceinline__ void asw_body(const Params& P, const int pass) {
+    const AspLists w = asp_lists<FIRST>(P, pass);
+    // (the set the NEXT pass appends to was this pass's predecessor's input: nobody reads it any more)
+    if (blockIdx.x == 0 && threadIdx.x < AS_NKB) gm(P.ascnt)[((pass + 2) % AS_SETS) * AS_NKB + threadIdx.x] = 0;
+    const Params Q = compact_params(P);
+    for (int g = blockIdx.x; g * 4 < w.nwork; g += gridDim.x) {
+        const AspGroup r = asp_group<FIRST>(P, w, g);
+        const int hw = wave_max(r.head);
+        if (hw <= 0) continue;
+        const int jm = zsweep_forward(P, Q, r.tc, r.head, hw);
+        const bool ok = r.has && gm(P.asok)[r.c] != 0;
+        asp_finish(P, w, r, pass + 1, ok, jm);
+    }
+}
+// the remaining solves of the rows still unsettled after the single-solve passes, in-wave (few rows: one
+// wave per SIMD, no spills)
+__device__ __forceinline__ void asp_body(const Params& P, const int pass, const int nsolve, double (*wtile)[WT_TILE],
+                                         double (*btile)[64]) {
+    const AspLists w = asp_lists<false>(P, pass);
+    if (blockIdx.x == 0 && threadIdx.x < AS_NKB) gm(P.ascnt)[((pass + 2) % AS_SETS) * AS_NKB + threadIdx.x] = 0;
+    const Params Q = compact_params(P);
+    const int row = threadIdx.x >> 4;
+    for (int g = blockIdx.x; g * 4 < w.nwork; g += gridDim.x) {
+        AspGroup r = asp_group<false>(P, w, g);
+        bool active = r.has, ok = true;
+        int jm = 0, done_here = 0;
+        for (int it = 0; it < nsolve; it++) {
+            const int kw = wave_max(active ? r.join : -1), hw = wave_max(active ? r.head : 0);
+            if (kw < 0) break;
+            bool fo = zsweep_factor<false>(P, Q, r.th, r.tc, r.head, r.chk, active ? r.join : -1, kw, wtile[row], btile[row]);
+            fo = row_min(fo ? 1.0 : 0.0) > 0.0;
+            const int j = zsweep_forward(P, Q, r.tc, active ? r.head : 0, hw);
+            if (active) {
+                done_here++;
+                ok = fo; jm = j;
+                if (!ok || jm < 0) active = false;
+                else r.join = (jm + 1 < AS_PSAVE) ? jm : r.head - 1;
+            }
+        }
+        asp_finish(P, w, r, pass + done_here, ok, jm);
+    }
+}
+__global__ __launch_bounds__(64, 2) void k_asf_first(Params P) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    asf_body<true>(P, 0, wtile, btile);
+}
+__global__ __launch_bounds__(64, 2) void k_asf(Params P, int pass) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    asf_body<false>(P, pass, wtile, btile);
+}
+__global__ __launch_bounds__(64, 2) void k_asw_first(Params P) { asw_body<true>(P, 0); }
+__global__ __launch_bounds__(64, 2) void k_asw(Params P, int pass) { asw_body<false>(P, pass); }
+__global__ __launch_bounds__(64) void k_asp(Params P, int pass, int nsolve) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    asp_body(P, pass, nsolve, wtile, btile);
+}
+// Settled rows: new iterate = candidate (start solve) + delta.  One wave = four consecutive compact slots.
+__global__ __launch_bounds__(64, 2) void k_ascommit(Params P) {
+    const int nipm = gm(P.nipm)[0];
+    const int N = P.N;
+    const int row = threadIdx.x >> 4;
+    const Params Q = compact_params(P);
+    for (int g = blockIdx.x; g * 4 < nipm; g += gridDim.x) {
+        const int c = g * 4 + row;
+        const bool has = c < nipm;
+        const int inst = has ? gm(P.ilist)[c] : 0;
+        const bool go = has && gm(P.asst)[imin(c, nipm - 1)] == 1;
+        if (!__any(go)) {
+            if (has && (threadIdx.x & 15) == 0) gm(P.done)[inst] = 0;
+            continue;
+        }
+        const Lane t = lane_indirect(P, inst, go);
+        const int head = go ? gm(P.head)[inst] : N;
+        const int a = t.L & 3;
+        const bool lo4 = t.L < 4;
+        int hmin = head;
+        hmin = min(hmin, __shfl_xor(hmin, 16)); hmin = min(hmin, __shfl_xor(hmin, 32));
+        const int lx = t.q * 13 + imin(t.L, 12);
+        const gdouble* zx = gm(P.czdx) + (size_t)c * (N + 1) * 13 + imin(t.L, 12);
+        const size_t cb4 = (size_t)c * N * 4 + a;
+        double x = 0.0;   // dx_k (lanes 0..12)
+        int kviol = -1;
+        // (1) stages before the shortest head of the wave: element-wise, nothing read from the home blocks
+        //     but the candidate itself (batches of four stages, loads first)
+        for (int k0 = 0; k0 < hmin; k0 += 4) {
+            double un[4], xc[4], dv[4], zv[4];
+            SFOR(j, 0, 4, {
+                const int k = imin(k0 + j, hmin - 1);
+                un[j] = gm(P.uitn)[i4(P, t, k, a)];
+                xc[j] = blk(P.xitn, t, N + 1, k + 1, SZ_V13)[lx];
+                dv[j] = gm(Q.dva)[cb4 + (size_t)k * 4];
+                zv[j] = zx[(size_t)(k + 1) * 13];
+            });
+            SFOR(j, 0, 4, {
+                const int k = k0 + j;
+                if (k < hmin && go) {
+                    if (lo4) gm(P.uitn)[i4(P, t, k, t.L)] = un[j] + dv[j];
+                    if (t.L < 13) blk(P.xitn, t, N + 1, k + 1, SZ_V13)[lx] = xc[j] + zv[j];
+                }
+            });
+        }
+        if (hmin > 0) x = t.L < 13 ? zx[(size_t)hmin * 13] : 0.0;
+        // (2) from there on: rows still inside their head keep adding the pass's own du / dx, the others roll
+        //     delta through the closed loop of the unconstrained feedback law (K, A, B of the home blocks)
+        struct In { double kr[13], ar[10], br[4], un, xc, dv, zx; };
+        auto load = [&](int k, In& in) {
+            ld_cols4(blk(P.KR, t, N, k, SZ_K), t, in.kr);
+            ld_ar(blk(P.AR, t, N, k, SZ_A), t, in.ar);
+            ld_rows4(blk(P.BR, t, N, k, SZ_B), t, in.br);
+            in.un = gm(P.uitn)[i4(P, t, k, a)];
+            in.xc = blk(P.xitn, t, N + 1, k + 1, SZ_V13)[lx];
+            in.dv = gm(Q.dva)[cb4 + (size_t)imin(k, imax(head - 1, 0)) * 4];
+            in.zx = zx[(size_t)imin(k + 1, head) * 13];
+        };
+        auto body = [&](const In& cur, int k) {
+            const bool tail = k >= head;
+            double acc = 0.0;
+            dotbc<13, 0>(acc, cur.kr, x);
+            double v = lo4 ? -acc : 0.0;
+            settle(v);
+            v = tail ? v : (lo4 ? cur.dv : 0.0);
+            const double un = cur.un + v;
+            if (lo4 && go) {
+                if (tail && !((un >= P.u_min) && (un <= P.u_max))) kviol = k;
+                gm(P.uitn)[i4(P, t, k, t.L)] = un;
+            }
+            double vr[4];
+            SFOR(cc, 0, 4, { vr[cc] = bc<cc>(v); });
+            double xn = t.L < 3 ? x : 0.0;
+            dotbc<10, 3>(xn, cur.ar, x);
+            SFOR(cc, 0, 4, { xn += cur.br[cc] * vr[cc]; });
+            x = (k + 1 <= head) ? (t.L < 13 ? cur.zx : 0.0) : xn;
+            if (t.L < 13 && go) blk(P.xitn, t, N + 1, k + 1, SZ_V13)[lx] = cur.xc + x;
+        };
+        if (hmin < N) {
+            In b0, b1;
+            load(hmin, b0);
+            int k = hmin;
+            while (k < N) {
+                load(imin(k + 1, N - 1), b1);
+                body(b0, k);
+                if (++k >= N) break;
+                load(imin(k + 1, N - 1), b0);
+                body(b1, k);
+                ++k;
+            }
+        }
+        kviol = (int)row_max((double)kviol);
+        if (has && t.L == 0) {
+            if (!go) {
+                gm(P.done)[inst] = 0;          // did not settle: interior point
+            } else if (kviol < 0) {
+                gm(P.done)[inst] = 1;
+                gm(P.status)[inst] = 0;
+                gm(P.res)[inst] = 0.0;
+            } else {                           // tail left the box: again over a longer head (k_as_retry)
+                gm(P.done)[inst] = 2;
+                gm(P.head)[inst] = max(head_class(P, kviol + 5), head);
+            }
+        }
+    }
 }
 #ifdef CFN_PROF
 // isolated sweeps on one wave per SIMD (development aid): every wave repeats the sweep `reps` times
@@ -2097,6 +2587,8 @@ __global__ void k_init_iterate(Params P, int mode) {
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+static inline int imin_h(int a, int b) { return a < b ? a : b; }
+static inline int imax_h(int a, int b) { return a > b ? a : b; }
 void launch_linearise(const Params& P, int chunks, hipStream_t st) {
     hipLaunchKernelGGL(k_linearise, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P);
 }
@@ -2118,7 +2610,22 @@ void launch_cforward(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_cforward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
 }
 void launch_qp_ipm(const Params& P, hipStream_t st) {
-    if (P.active_set) {
+    if (P.active_set && P.as_passes > 0) {
+        // level-synchronous active-set passes: as_passes launches of one solve each, the last one loops over
+        // the remaining solves in-wave; then commit, retries over a longer head, interior point for the rest
+        const int G = imax_h(1, imin_h(P.as_grid, P.NW));
+        hipLaunchKernelGGL(k_asf_first, dim3(G), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_asw_first, dim3(G), dim3(64), 0, st, P);
+        for (int p = 1; p < P.as_passes; p++) {
+            hipLaunchKernelGGL(k_asf, dim3(G), dim3(64), 0, st, P, p);
+            hipLaunchKernelGGL(k_asw, dim3(G), dim3(64), 0, st, P, p);
+        }
+        if (P.as_passes < AS_MAX_SOLVES)
+            hipLaunchKernelGGL(k_asp, dim3(imax_h(1, G / 2)), dim3(64), 0, st, P, P.as_passes, AS_MAX_SOLVES - P.as_passes);
+        hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_as_retry, dim3(P.NW), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_ipm_rest, dim3(P.NW), dim3(64), 0, st, P);
+    } else if (P.active_set) {
         hipLaunchKernelGGL(k_as, dim3(P.NW), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_ipm_rest, dim3(P.NW), dim3(64), 0, st, P);
     } else {

@@ -95,6 +95,12 @@ struct Params {
     int *rank;                   // per instance: (bin << 8) | rank among the same-bin instances of its group
     // partial condensing (cfnmpc_opts.cond_N2 < N): the N stages are regrouped into cond_N2 blocks,
     // the first cond_rem of them cond_M + 1 stages long, the others cond_M (cond_N2 = 0: off)
+    // level-synchronous active-set passes (cfnmpc_opts.as_pipeline; k_asp / k_ascommit in cfnmpc_kernels.hip)
+    int as_passes;               // 0: monolithic k_as; p > 0: p single-solve launches + one launch for the remaining solves
+    int as_grid;                 // wavefronts per pass launch (grid-stride over the work list)
+    int *aslist, *ascnt;         // work lists [set 0..2][bin 0..6][compact slots], their lengths [set][bin]
+    int *askst, *asst, *asok;    // per compact slot: restart stage of its next solve; 1 = settled (to be committed); last factorisation positive definite
+    double *czdx;                // per compact slot: dx_k of its last solve, (N + 1) x 13
     int forward_rg;              // 1: forward sweep of the start solve on the stored blocks (k_forward_rg; small fleets)
     int cond_N2, cond_M, cond_rem;
     double *cb;                  // condensed blocks, [instance][block][cb_size(w_max)] (layout: cfnmpc_pcond.hip)

@@ -1,0 +1,92 @@
+"""Level-synchronous active-set passes (cfnmpc_opts.as_passes > 0: k_asp_first / k_asp / k_ascommit) against
+the monolithic kernel (as_passes = -1) and against the CPU restatement: the solves are the same solves
+(identical counts instance by instance), the new iterate is `candidate + delta` instead of a fresh
+roll-out (rounding-level differences only)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HOV = 15.777730167256925
+
+
+def _fleet(oracle, B, scale, seed, N=50):
+    rng = np.random.default_rng(seed)
+    x0 = oracle.sample_hover_x0(rng, B, scale=scale)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    return x0, np.repeat(yr[None], B, 0).copy(), np.repeat(ye[None], B, 0).copy()
+
+
+@pytest.mark.parametrize("B,scale,passes", [(200, 1.0, 1), (200, 1.5, 3), (1027, 2.0, 4), (1027, 2.5, 12), (4099, 1.0, 2), (4099, 3.0, 6)])
+def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, passes):
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    x0, yref, yref_e = _fleet(oracle, B, scale, 77 + passes)
+    a = BatchSolver(B, default_opts(as_passes=-1))
+    b = BatchSolver(B, default_opts(as_passes=passes))
+    for s in (a, b):
+        s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    x = x0.copy()
+    n_con = n_multi = 0
+    for t in range(8):
+        for s in (a, b):
+            s.set_x0(x); s.solve(1)
+        sa, ia, _ = a.stats(); sb, ib, _ = b.stats()
+        xa, ua = a.get_iterate(); xb, ub = b.get_iterate()
+        assert np.array_equal(sa, sb), (t, np.nonzero(sa != sb)[0][:10], sa[sa != sb][:10], sb[sa != sb][:10])
+        ok = sa == 0
+        as_only = ok & (ia <= 12) & (ib <= 12)
+        assert np.array_equal(ia[as_only], ib[as_only]), (t, ia[as_only & (ia != ib)][:10], ib[as_only & (ia != ib)][:10])
+        # exact QP solutions on both sides: FP64-level agreement (kRPM / state units); instances that went
+        # through the interior point (tol 1e-8) agree at its accuracy
+        assert np.abs(ua[as_only] - ub[as_only]).max() < 1e-8 and np.abs(xa[as_only] - xb[as_only]).max() < 1e-8, (
+            t, np.abs(ua[as_only] - ub[as_only]).max(), np.abs(xa[as_only] - xb[as_only]).max())
+        assert np.abs(ua[ok] - ub[ok]).max() < 5e-4 and np.abs(xa[ok] - xb[ok]).max() < 5e-4
+        # (the monolithic kernel gives the four rows of a wave their largest head class, the passes each row
+        #  its own: heads may differ, the unique QP solution does not)
+        # every input of the new iterate respects the box
+        assert ub[ok].min() > -1e-9 and ub[ok].max() < 22 + 1e-9
+        n_con += int((ib > 0).sum()); n_multi += int((ib > 1).sum())
+        u0 = a.get_u(0)
+        x = sim(x, u0, T=0.015, steps=1)
+        b.set_iterate(xa, ua)          # keep both on the same trajectory
+    assert n_con > 20 and n_multi > 5     # constrained QPs with more than one solve were exercised
+
+
+def test_level_synchronous_passes_match_cpu_restatement(oracle, cref):
+    """192 instances, 12 closed-loop steps, full-horizon sweeps: same solves pass by pass as the restatement's
+    as_solve, iterates at FP64 level."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 192, 50
+    x0, yref, yref_e = _fleet(oracle, B, 1.3, 5)
+    opts = cref.default_opts(active_set=1)
+    xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    for ah in (0, 1):
+        s = BatchSolver(B, default_opts(active_horizon=ah, as_passes=3))
+        s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+        x = x0.copy()
+        xr[:] = x0[:, None, :]; ur[:] = HOV
+        tot = 0
+        for t in range(12):
+            s.set_x0(x); s.solve(1)
+            st, it, _ = s.stats()
+            st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+            xg, ug = s.get_iterate()
+            assert (st == 0).all() and (st_r == 0).all()
+            if ah == 0:
+                assert np.array_equal(it, it_r), (t, it[it != it_r], it_r[it != it_r])
+            else:
+                assert ((it > 0) == (it_r > 0)).all()
+            assert np.abs(ug - ur).max() < 1e-8 and np.abs(xg - xr).max() < 1e-8, (t, np.abs(ug - ur).max())
+            tot += int((it > 0).sum())
+            x = sim(x, s.get_u(0), T=0.015, steps=1)
+            ur[:] = ug; xr[:] = xg
+        assert tot > 50
+
+
+def test_pipeline_option_validation():
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    for bad in (-2, 13):
+        with pytest.raises(Exception):
+            BatchSolver(8, default_opts(as_passes=bad))
+    BatchSolver(8, default_opts(as_passes=12)).close()

@@ -1,0 +1,52 @@
+"""What the driver's SCALE run launches: `python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...` -- driven here with two ranks sharing the one GPU of the test box (gloo for the report's
+two all-reduces, the data path has no collective), asserting on the JSON line."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(extra):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo",
+           "--batch", "8192", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"] + extra
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_strong_scaling_line():
+    d = _run([])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 2
+    assert d["scaling"] == "strong" and d["unit"] == "RTI steps/s" and d["dtype"] == "f64"
+    assert d["config"]["total_batch"] == 8192 and d["config"]["batch_per_gpu"] == 4096
+    assert d["weak_scaling"]["total_batch"] == 16384 and d["weak_scaling"]["batch_per_gpu"] == 8192
+    assert d["qp_stats"]["status_ok_frac"] == 1.0
+    assert d["value"] > 0 and abs(d["value"] - 8192 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+
+
+def test_bench_two_ranks_weak_scaling_line():
+    d = _run(["--scaling", "weak"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["total_batch"] == 16384 and d["config"]["batch_per_gpu"] == 8192
+    assert "weak_scaling" not in d
+    assert d["qp_stats"]["status_ok_frac"] == 1.0
