@@ -75,8 +75,6 @@ struct DeviceGuard {
 };
 
 constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the count
-constexpr int AS_LEVEL_SYNC_FROM = 16384;     // level-synchronous active-set passes from this batch size on
-constexpr int AS_PASSES_DEFAULT = 4;
 constexpr int FORWARD_RG_BELOW = 8192;        // measured cross-over of the two forward sweeps
 
 template <typename T>
@@ -238,11 +236,12 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.active_set = o.active_set ? 1 : 0;
     if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
     P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && batch < FORWARD_RG_BELOW) ? 1 : 0;
-    if (o.as_passes < -1 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
-    P.as_passes = o.as_passes > 0 ? o.as_passes : (o.as_passes == 0 && batch >= AS_LEVEL_SYNC_FROM ? AS_PASSES_DEFAULT : 0);
-    if (const char* e = std::getenv("CFNMPC_AS_PASSES")) {   // development aid
+    if (o.as_passes < -2 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
+    // internal: 0 = monolithic k_as, -1 = every solve in one launch on the compact z store + commit, p > 0 = p single-solve passes
+    P.as_passes = o.as_passes > 0 ? o.as_passes : (o.as_passes == -2 ? -1 : 0);
+    if (const char* e = std::getenv("CFNMPC_AS_PASSES")) {   // development aid (internal encoding)
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 12) P.as_passes = v;
+        if (v >= -1 && v <= 12) P.as_passes = v;
     }
     {   // pass launches: two wavefronts per SIMD of this device
         hipDeviceProp_t prop;
@@ -274,7 +273,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(ilist, NW * 4); ALLOC(nipm, 64);
     ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * 32); ALLOC(rank, NW * 4); ALLOC(done, NW * 4);
     ALLOC(ascnt, 32); ALLOC(askst, NW * 4); ALLOC(asst, NW * 4); ALLOC(asok, NW * 4);
-    if (P.as_passes > 0) { ALLOC(aslist, (size_t)3 * 7 * NW * 4); ALLOC(czdx, NW * 4 * (N + 1) * 13); }
+    if (P.as_passes != 0) { ALLOC(aslist, (size_t)3 * 7 * NW * 4); ALLOC(czdx, NW * 4 * (N + 1) * 13); }
     if (cond_N2) ALLOC(cb, NW * 4 * (size_t)cond_N2 * cfn::cb_size(cfn::cond_mmax(P)));
     if (s->overlap) {
         if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->AR2, NW * N * cfn::SZ_A);

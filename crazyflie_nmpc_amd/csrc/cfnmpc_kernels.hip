@@ -1872,6 +1872,14 @@ __global__ __launch_bounds__(64) void k_as_retry(Params P) {  // MODE 3: rows th
 // 13 per stage 0..N (dx), 14 x 13 per saved cost-to-go.  Results do not depend on which rows share a
 // wave: every row restarts its factorisation at its own stage with its own saved cost-to-go.
 constexpr int AS_NKB = 7, AS_SETS = 3;
+// The passes keep the cost-to-go of every AS_PGRAN-th stage only (it is 182 of the ~470 doubles a factor stage
+// moves): a later factorisation restarts at the first such stage behind the last change, i.e. repeats up to
+// AS_PGRAN - 1 stages more than necessary (identical arithmetic, identical results).
+constexpr int AS_PGRAN = 4;
+__device__ __forceinline__ int as_restart(int jm, int head) {   // jm = last stage whose class changed
+    const int jr = ((jm + AS_PGRAN) / AS_PGRAN) * AS_PGRAN - 1;   // smallest stage >= jm with a saved successor
+    return (jr + 1 < head && (jr + 1) / AS_PGRAN < AS_PSAVE) ? jr : head - 1;
+}
 __host__ __device__ constexpr int as_kbin(int len) {   // len = stages the next factorisation covers
     return len > 32 ? 0 : (len > 24 ? 1 : (len > 16 ? 2 : (len > 12 ? 3 : (len > 8 ? 4 : (len > 4 ? 5 : 6)))));
 }
@@ -1934,7 +1942,7 @@ __device__ __forceinline__ bool zsweep_factor(const Params& P, const Params& Q, 
     auto start_row = [&](int k) {   // rows with join == k: cost-to-go of stage k + 1
         if (k != join) return;
         if (k + 1 < head) {         // saved by an earlier solve of this instance
-            const gdouble* ps = gm(Q.cPs) + ((size_t)tc.inst * AS_PSAVE + (k + 1)) * 182 + imin(tc.L, 13);
+            const gdouble* ps = gm(Q.cPs) + ((size_t)tc.inst * AS_PSAVE + (k + 1) / AS_PGRAN) * 182 + imin(tc.L, 13);
             SFOR(j, 0, 13, { Pa[j] = ps[j * 14]; });
         } else if (chk < 0) {
             SFOR(j, 0, 13, { Pa[j] = (tc.L == j) ? P.WN[ext_of(j)] : 0.0; });
@@ -1978,8 +1986,8 @@ __device__ __forceinline__ bool zsweep_factor(const Params& P, const Params& Q, 
         (void)a;
         const bool fo = factor_stage<true, true, true>(Q, tc, k, Pa, z.in, wq, is13, wt, sb, act);
         ok = ok && (fo || !act);
-        if (act && k > 0 && k < AS_PSAVE && tc.L < 14) {
-            gdouble* ps = gm(Q.cPs) + ((size_t)tc.inst * AS_PSAVE + k) * 182 + tc.L;
+        if (act && k > 0 && k % AS_PGRAN == 0 && k / AS_PGRAN < AS_PSAVE && tc.L < 14) {
+            gdouble* ps = gm(Q.cPs) + ((size_t)tc.inst * AS_PSAVE + k / AS_PGRAN) * 182 + tc.L;
             SFOR(j, 0, 13, { ps[j * 14] = Pa[j]; });
         }
     };
@@ -2132,7 +2140,7 @@ __device__ __forceinline__ void asp_finish(const Params& P, const AspLists& w, c
     } else if (!ok || solves >= AS_MAX_SOLVES) {
         gm(P.asst)[r.c] = 0;
     } else {
-        const int join = (jm + 1 < AS_PSAVE) ? jm : r.head - 1;   // restart stage of the next factorisation
+        const int join = as_restart(jm, r.head);   // restart stage of the next factorisation
         gm(P.askst)[r.c] = join;
         const int b = as_kbin(join + 1);
         const int pos = atomicAdd(P.ascnt + w.set_out * AS_NKB + b, 1);
@@ -2170,29 +2178,34 @@ __device__ __forceinline__ void asw_body(const Params& P, const int pass) {
         asp_finish(P, w, r, pass + 1, ok, jm);
     }
 }
-// the remaining solves of the rows still unsettled after the single-solve passes, in-wave (few rows: one
-// wave per SIMD, no spills)
+// Several solves in-wave (one wave per SIMD, no spills): FIRST = false -- the remaining solves of the rows still
+// unsettled after the single-solve passes (few rows); FIRST = true -- every solve of every constrained instance
+// in one launch (as_passes = -2: no level synchronisation at all, the shortest dependent chain -- for small
+// fleets, where the SIMDs idle anyway), the first one gathering from the home blocks.
+template <bool FIRST>
 __device__ __forceinline__ void asp_body(const Params& P, const int pass, const int nsolve, double (*wtile)[WT_TILE],
                                          double (*btile)[64]) {
-    const AspLists w = asp_lists<false>(P, pass);
+    const AspLists w = asp_lists<FIRST>(P, pass);
     if (blockIdx.x == 0 && threadIdx.x < AS_NKB) gm(P.ascnt)[((pass + 2) % AS_SETS) * AS_NKB + threadIdx.x] = 0;
     const Params Q = compact_params(P);
     const int row = threadIdx.x >> 4;
     for (int g = blockIdx.x; g * 4 < w.nwork; g += gridDim.x) {
-        AspGroup r = asp_group<false>(P, w, g);
+        AspGroup r = asp_group<FIRST>(P, w, g);
         bool active = r.has, ok = true;
         int jm = 0, done_here = 0;
         for (int it = 0; it < nsolve; it++) {
             const int kw = wave_max(active ? r.join : -1), hw = wave_max(active ? r.head : 0);
             if (kw < 0) break;
-            bool fo = zsweep_factor<false>(P, Q, r.th, r.tc, r.head, r.chk, active ? r.join : -1, kw, wtile[row], btile[row]);
+            bool fo;
+            if (FIRST && it == 0) fo = zsweep_factor<true>(P, Q, r.th, r.tc, r.head, r.chk, r.join, kw, wtile[row], btile[row]);
+            else fo = zsweep_factor<false>(P, Q, r.th, r.tc, r.head, r.chk, active ? r.join : -1, kw, wtile[row], btile[row]);
             fo = row_min(fo ? 1.0 : 0.0) > 0.0;
             const int j = zsweep_forward(P, Q, r.tc, active ? r.head : 0, hw);
             if (active) {
                 done_here++;
                 ok = fo; jm = j;
                 if (!ok || jm < 0) active = false;
-                else r.join = (jm + 1 < AS_PSAVE) ? jm : r.head - 1;
+                else r.join = as_restart(jm, r.head);
             }
         }
         asp_finish(P, w, r, pass + done_here, ok, jm);
@@ -2213,10 +2226,18 @@ __global__ __launch_bounds__(64, 2) void k_asw(Params P, int pass) { asw_body<fa
 __global__ __launch_bounds__(64) void k_asp(Params P, int pass, int nsolve) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    asp_body(P, pass, nsolve, wtile, btile);
+    asp_body<false>(P, pass, nsolve, wtile, btile);
+}
+__global__ __launch_bounds__(64) void k_asp_all(Params P) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    asp_body<true>(P, 0, AS_MAX_SOLVES, wtile, btile);
 }
 // Settled rows: new iterate = candidate (start solve) + delta.  One wave = four consecutive compact slots.
-__global__ __launch_bounds__(64, 2) void k_ascommit(Params P) {
+// DEEP: three rotating stage buffers in the tail loop (one wave per SIMD: small fleets, where the tail is a
+// latency chain); otherwise two (two waves per SIMD: large fleets, where it is bound by the home blocks' bytes).
+template <bool DEEP>
+__device__ __forceinline__ void ascommit_body(const Params& P) {
     const int nipm = gm(P.nipm)[0];
     const int N = P.N;
     const int row = threadIdx.x >> 4;
@@ -2293,7 +2314,7 @@ __global__ __launch_bounds__(64, 2) void k_ascommit(Params P) {
             x = (k + 1 <= head) ? (t.L < 13 ? cur.zx : 0.0) : xn;
             if (t.L < 13 && go) blk(P.xitn, t, N + 1, k + 1, SZ_V13)[lx] = cur.xc + x;
         };
-        if (hmin < N) {
+        if (hmin < N && !DEEP) {
             In b0, b1;
             load(hmin, b0);
             int k = hmin;
@@ -2303,6 +2324,23 @@ __global__ __launch_bounds__(64, 2) void k_ascommit(Params P) {
                 if (++k >= N) break;
                 load(imin(k + 1, N - 1), b0);
                 body(b1, k);
+                ++k;
+            }
+        }
+        if (hmin < N && DEEP) {
+            In b0, b1, b2;
+            load(hmin, b0);
+            load(imin(hmin + 1, N - 1), b1);
+            int k = hmin;
+            while (k < N) {
+                load(imin(k + 2, N - 1), b2);
+                body(b0, k);
+                if (++k >= N) break;
+                load(imin(k + 2, N - 1), b0);
+                body(b1, k);
+                if (++k >= N) break;
+                load(imin(k + 2, N - 1), b1);
+                body(b2, k);
                 ++k;
             }
         }
@@ -2321,6 +2359,8 @@ __global__ __launch_bounds__(64, 2) void k_ascommit(Params P) {
         }
     }
 }
+__global__ __launch_bounds__(64, 2) void k_ascommit(Params P) { ascommit_body<false>(P); }
+__global__ __launch_bounds__(64) void k_ascommit1(Params P) { ascommit_body<true>(P); }
 #ifdef CFN_PROF
 // isolated sweeps on one wave per SIMD (development aid): every wave repeats the sweep `reps` times
 __global__ __launch_bounds__(64) void k_bench_sweep(Params P, int head, int reps, int which) {
@@ -2610,19 +2650,25 @@ void launch_cforward(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_cforward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
 }
 void launch_qp_ipm(const Params& P, hipStream_t st) {
-    if (P.active_set && P.as_passes > 0) {
-        // level-synchronous active-set passes: as_passes launches of one solve each, the last one loops over
-        // the remaining solves in-wave; then commit, retries over a longer head, interior point for the rest
+    if (P.active_set && P.as_passes != 0) {
+        // as_passes > 0: level-synchronous active-set passes -- pairs (factor, forward) of one solve each, one
+        // launch loops over the remaining solves in-wave; as_passes < 0: every solve in one launch.  Then commit,
+        // retries over a longer head, interior point for the rest.
         const int G = imax_h(1, imin_h(P.as_grid, P.NW));
-        hipLaunchKernelGGL(k_asf_first, dim3(G), dim3(64), 0, st, P);
-        hipLaunchKernelGGL(k_asw_first, dim3(G), dim3(64), 0, st, P);
-        for (int p = 1; p < P.as_passes; p++) {
-            hipLaunchKernelGGL(k_asf, dim3(G), dim3(64), 0, st, P, p);
-            hipLaunchKernelGGL(k_asw, dim3(G), dim3(64), 0, st, P, p);
+        if (P.as_passes < 0) {
+            hipLaunchKernelGGL(k_asp_all, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
+        } else {
+            hipLaunchKernelGGL(k_asf_first, dim3(G), dim3(64), 0, st, P);
+            hipLaunchKernelGGL(k_asw_first, dim3(G), dim3(64), 0, st, P);
+            for (int p = 1; p < P.as_passes; p++) {
+                hipLaunchKernelGGL(k_asf, dim3(G), dim3(64), 0, st, P, p);
+                hipLaunchKernelGGL(k_asw, dim3(G), dim3(64), 0, st, P, p);
+            }
+            if (P.as_passes < AS_MAX_SOLVES)
+                hipLaunchKernelGGL(k_asp, dim3(imax_h(1, G / 2)), dim3(64), 0, st, P, P.as_passes, AS_MAX_SOLVES - P.as_passes);
         }
-        if (P.as_passes < AS_MAX_SOLVES)
-            hipLaunchKernelGGL(k_asp, dim3(imax_h(1, G / 2)), dim3(64), 0, st, P, P.as_passes, AS_MAX_SOLVES - P.as_passes);
-        hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
+        if (P.NW <= 2 * P.as_grid) hipLaunchKernelGGL(k_ascommit1, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
+        else hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_as_retry, dim3(P.NW), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_ipm_rest, dim3(P.NW), dim3(64), 0, st, P);
     } else if (P.active_set) {

@@ -111,14 +111,19 @@ typedef struct cfnmpc_opts {
                             kernels already run back to back (18 us of gaps per step at 4096 instances), the
                             graph saves about half of that.                          */
     int as_passes;       /* QP, active_set = 1: how the active-set solves of the constrained instances are scheduled.
-                            -1: one monolithic kernel (four instances per wavefront stay together until the slowest
-                            has settled, rolled out and been verified: shortest dependent chain, right for small
-                            fleets); p = 1..12: LEVEL-SYNCHRONOUS -- p launches of ONE solve each over the instances
-                            that have not settled yet (work lists re-binned by remaining sweep length between the
-                            launches, two wavefronts per SIMD), one launch for the remaining 12 - p solves, then a
-                            commit pass (new iterate = start solve's candidate + delta, tail inputs verified);
-                            0 (default): by batch size.  Same results to rounding (the solves themselves are
-                            identical; the roll-out adds the delta to the candidate instead of recomputing it). */
+                            -1: one monolithic kernel on a wave-blocked compact copy (four instances per wavefront stay
+                            together until the slowest has settled, been rolled out and verified);
+                            -2: every solve in one launch as well, but on the instance-contiguous compact store
+                            (gathered by the first backward sweep itself, every row restarts at its own stage),
+                            followed by a COMMIT pass: new iterate = the start solve's candidate + delta -- head stages
+                            element-wise, the tail through the closed loop of the unconstrained feedback law, whose
+                            inputs are verified against the box there;
+                            p = 1..12: LEVEL-SYNCHRONOUS -- p pairs of launches (factor, forward) of ONE solve each
+                            over the instances that have not settled yet (work lists re-binned by remaining sweep
+                            length between the launches, two wavefronts per SIMD), one launch for the remaining
+                            12 - p solves, then the commit pass;
+                            0 (default): by batch size.  Same solves and solve counts in every mode; results agree to
+                            rounding (the commit adds the delta to the candidate instead of recomputing the roll-out). */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);

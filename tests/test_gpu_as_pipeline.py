@@ -16,13 +16,14 @@ def _fleet(oracle, B, scale, seed, N=50):
     return x0, np.repeat(yr[None], B, 0).copy(), np.repeat(ye[None], B, 0).copy()
 
 
-@pytest.mark.parametrize("B,scale,passes", [(200, 1.0, 1), (200, 1.5, 3), (1027, 2.0, 4), (1027, 2.5, 12), (4099, 1.0, 2), (4099, 3.0, 6)])
-def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, passes):
+@pytest.mark.parametrize("B,scale,passes,ah", [(200, 1.0, 1, 1), (200, 1.5, 3, 0), (200, 1.5, -2, 1), (1027, 2.0, 4, 1), (1027, 2.0, 4, 0),
+                                                (1027, 2.5, 12, 1), (1027, 2.5, -2, 0), (4099, 1.0, 2, 1), (4099, 3.0, 6, 1)])
+def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, passes, ah):
     from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
     from crazyflie_nmpc_amd.solver import INIT_HOVER
-    x0, yref, yref_e = _fleet(oracle, B, scale, 77 + passes)
-    a = BatchSolver(B, default_opts(as_passes=-1))
-    b = BatchSolver(B, default_opts(as_passes=passes))
+    x0, yref, yref_e = _fleet(oracle, B, scale, 77 + abs(passes))
+    a = BatchSolver(B, default_opts(as_passes=-1, active_horizon=ah))
+    b = BatchSolver(B, default_opts(as_passes=passes, active_horizon=ah))
     for s in (a, b):
         s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
     x = x0.copy()
@@ -35,11 +36,20 @@ def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, pass
         assert np.array_equal(sa, sb), (t, np.nonzero(sa != sb)[0][:10], sa[sa != sb][:10], sb[sa != sb][:10])
         ok = sa == 0
         as_only = ok & (ia <= 12) & (ib <= 12)
-        assert np.array_equal(ia[as_only], ib[as_only]), (t, ia[as_only & (ia != ib)][:10], ib[as_only & (ia != ib)][:10])
-        # exact QP solutions on both sides: FP64-level agreement (kRPM / state units); instances that went
-        # through the interior point (tol 1e-8) agree at its accuracy
-        assert np.abs(ua[as_only] - ub[as_only]).max() < 1e-8 and np.abs(xa[as_only] - xb[as_only]).max() < 1e-8, (
-            t, np.abs(ua[as_only] - ub[as_only]).max(), np.abs(xa[as_only] - xb[as_only]).max())
+        if ah == 0:    # same head (the whole horizon) on both sides: the same solves, count by count
+            assert np.array_equal(ia[as_only], ib[as_only]), (t, ia[as_only & (ia != ib)][:10], ib[as_only & (ia != ib)][:10])
+        else:          # the monolithic kernel gives the four rows of a wave their largest head class, the passes each
+            #            row its own: a different (equivalent) QP may take a solve more or less
+            assert ((ia > 0) == (ib > 0))[ok].all()
+            assert (ia[as_only] != ib[as_only]).mean() < 0.02 and np.abs(ia[as_only] - ib[as_only]).max() <= 3
+        # exact QP solutions on both sides: FP64-level agreement (kRPM / state units).  The statistics do not tell
+        # an active-set solve from an interior-point fall-back that took <= 12 iterations (accuracy ~ sqrt(tol)):
+        # FP64 level for (nearly) all, the interior point's accuracy for every instance
+        du = np.abs(ua - ub).reshape(B, -1).max(1); dx = np.abs(xa - xb).reshape(B, -1).max(1)
+        close = (du < 1e-8) & (dx < 1e-8)
+        assert close[as_only].mean() > 0.99, (t, close[as_only].mean(), du[as_only].max())
+        if scale <= 1.5:
+            assert close[as_only].all(), (t, du[as_only].max(), dx[as_only].max())
         assert np.abs(ua[ok] - ub[ok]).max() < 5e-4 and np.abs(xa[ok] - xb[ok]).max() < 5e-4
         # (the monolithic kernel gives the four rows of a wave their largest head class, the passes each row
         #  its own: heads may differ, the unique QP solution does not)
@@ -86,7 +96,7 @@ def test_level_synchronous_passes_match_cpu_restatement(oracle, cref):
 
 def test_pipeline_option_validation():
     from crazyflie_nmpc_amd import BatchSolver, default_opts
-    for bad in (-2, 13):
+    for bad in (-3, 13):
         with pytest.raises(Exception):
             BatchSolver(8, default_opts(as_passes=bad))
     BatchSolver(8, default_opts(as_passes=12)).close()
