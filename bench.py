@@ -99,7 +99,8 @@ def _cpu_baseline_child(seed):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import cfnmpc_oracle as o
     import cref
-    cref.build()
+    cref.build()          # rebuilds when the library was compiled on another host (-march=native is the BUILD host's)
+    march = cref.march_native()
     N = N_HORIZON
     yr, ye = o.regulation_yref(N, (0.0, 0.0, 0.4))
     opts = cref.default_opts(active_set=1)          # same QP method as the engine's default
@@ -147,7 +148,8 @@ def _cpu_baseline_child(seed):
                        "steps": int(len(lat)), "budget_us": 15000.0, "bad_status": int(bad)},
         "mixed_horizon_steps_per_s": B * KICK_PERIOD / t_mix, "mixed_horizon_stage_steps_per_s": stage_steps / t_mix,
         "mean_qp_solves": best["iters"] / (B * KICK_PERIOD),
-        "sample": (f"oracle/cfnmpc_ref.c (CPU restatement, NOT acados; gcc -O3 -march=native -fopenmp, FP64, same QP method as the "
+        "march_native": march,
+        "sample": (f"oracle/cfnmpc_ref.c (CPU restatement, NOT acados; gcc -O3 -march=native [= {march} on this host, compiled here] -fopenmp, FP64, same QP method as the "
                    f"engine: active-set solves, interior point as fall-back). B-thr: first {B} instances of config C2 x {KICK_PERIOD} "
                    f"closed-loop RTI steps, one instance at a time per thread, {best['threads']} threads = the CPUs this process may use "
                    f"(affinity mask capped by the cgroup CPU quota; host has {cores}), best of 3. B-lat: 1 instance, {len(lat)} closed-loop steps on one core "
@@ -324,13 +326,14 @@ def timed_run(fleet, steps, warmup, barrier):
         fleet.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    ms_lin, ms_qp, n_prof = fleet.solver.get_profile()
+    kms, n_prof = fleet.solver.get_profile_kernels()   # linearise | factor | forward | compaction | active set | interior point
+    ms_lin, ms_qp = kms[0], sum(kms[1:])
     fleet.solver.set_profiling(False)
     # (n_prof == steps unless K exceeds the library's cap of timed steps: the average then covers the first 4096)
     st, it, _rs = fleet.solver.stats()
     heads = fleet.solver.heads()
     return elapsed, ms_lin, ms_qp, dict(ok=float((st == 0).sum()), bad=float((st != 0).sum()), solves=float(it.sum()),
-                                        constrained=float((it > 0).sum()), heads=float(heads.sum()))
+                                        constrained=float((it > 0).sum()), heads=float(heads.sum()), kms=kms)
 
 
 def main():
@@ -412,12 +415,13 @@ def main():
         fleet.close()
         del fleet
         torch.cuda.empty_cache()
-        sums = [st["ok"], st["bad"], st["solves"], st["constrained"], st["heads"], ms_lin, ms_qp, float(batch_rank)]
+        sums = [st["ok"], st["bad"], st["solves"], st["constrained"], st["heads"], ms_lin, ms_qp, float(batch_rank)] + list(st["kms"])
         elapsed, sums = parallel.aggregate_report(elapsed, sums, dist, red_dev)
         tot = sums[7]
         return dict(elapsed=elapsed, total=tot, value=tot * steps / elapsed, ms_per_step=elapsed / steps * 1e3,
                     ms_lin=sums[5] / world, ms_qp=sums[6] / world, ok_frac=sums[0] / tot, mean_qp_solves=sums[2] / tot,
-                    frac_constrained=sums[3] / tot, mean_head=sums[4] / tot, batch_rank=batch_rank)
+                    frac_constrained=sums[3] / tot, mean_head=sums[4] / tot, batch_rank=batch_rank,
+                    kms=[float(v) / world for v in sums[8:14]])
 
     if scaling == "strong":
         lo, hi = parallel.shard_range(args.batch, rank, world)
@@ -445,6 +449,10 @@ def main():
         extras["batch_8192 (one GPU's share of 65536 at 8 GPUs)"] = brief(measure(8192, 40, 40, seed_off=7))
         extras["config_C4_figure8_tracking"] = brief(measure(B_rank, 20, ws, workload="figure8", seed_off=8))
         extras["config_C5_mixed_horizons_30_50_100_delay_compensated"] = mixed_horizon_run(B_rank, dev, np.random.default_rng(seed + 9000), 20, ws)
+        extras["config_C5_mixed_horizons_30_50_100_delay_compensated"]["predictor"] = (
+            "x0 = RK4 prediction over the 60 ms delay THROUGH THE FOUR QUEUED INPUTS (oldest first); the reference's estimator holds the "
+            "LATEST input over the delay (acados_estimator.cpp:573-593) -- with raw motor speeds as plant inputs that closed loop diverges "
+            "(no onboard attitude loop in this plant), hence the departure")
 
     if rank == 0:
         r = main_run
@@ -495,6 +503,10 @@ def main():
                          "alg_bytes_per_launch": alg_bytes_step(N) * B_launch, "kernel_ms": ms_step,
                          "kernel_ms_within_step": kernel_time_consistent,
                          "linearise_ms": r["ms_lin"], "qp_ms": r["ms_qp"],
+                         # the same K timed steps per kernel group (seven HIP events per step on the launch stream)
+                         "kernels_ms": dict(zip(("k_linearise", "k_factor", "k_forward", "k_compact+k_scatter",
+                                                 "k_as (active-set solves, roll-out)", "k_ipm_rest (interior-point fall-back)"), r["kms"])),
+                         "traffic_over_alg": (traffic / (alg_bytes_step(N) * B_launch)) if traffic else None,
                          "qp_phase": {"kernels": "k_factor + k_forward + k_compact + k_scatter + k_as + k_ipm_rest",
                                       "alg_bytes_per_launch": alg_bytes_qp(N) * B_launch, "achieved": ach_qp / 1e9,
                                       "frac": ach_qp / HBM_PEAK, "traffic": traffic_qp},

@@ -131,10 +131,9 @@ int ocp_nlp_constraints_model_set(ocp_nlp_config*, ocp_nlp_dims*, ocp_nlp_in*, i
         return 0;
     }
     if (!std::strcmp(field, "lbu") || !std::strcmp(field, "ubu")) {
-        // stored per stage like acados does; the engine solves with ONE box for all inputs and
-        // stages, so acados_solve() applies the stored boxes if they are uniform and fails (status 1,
-        // nothing solved) if they are not -- e.g. the reference's FIXED_U0 pin of stage 0
-        // (acados_mpc.cpp:605-608, compiled out at :111)
+        // stored per stage like acados does; acados_solve() hands them to the engine: as ONE scalar box when
+        // they are uniform (the default path), as per-stage / per-input boxes otherwise -- e.g. the
+        // reference's FIXED_U0 pin of stage 0, lbu = ubu = u1 (acados_mpc.cpp:605-608, compiled out at :111)
         if (stage < 0 || stage >= N) return 1;
         for (int i = 0; i < NU; i++) if (!(v[i] == v[i])) return 1;
         std::memcpy(field[0] == 'l' ? g->lbu[stage] : g->ubu[stage], v, sizeof(double) * NU);
@@ -181,10 +180,17 @@ int acados_solve(void) {
     }
     if (g->box_dirty) {
         const double lo = g->lbu[0][0], hi = g->ubu[0][0];
+        bool uniform = true;
         for (int k = 0; k < N; k++)
             for (int i = 0; i < NU; i++)
-                if (g->lbu[k][i] != lo || g->ubu[k][i] != hi) return 1;   // per-stage boxes: not supported
-        if (cfnmpc_set_box(g->s, lo, hi) != CFNMPC_OK) return 1;          // (also rejects lo >= hi)
+                if (g->lbu[k][i] != lo || g->ubu[k][i] != hi) uniform = false;
+        if (uniform) {
+            if (cfnmpc_set_box(g->s, lo, hi) != CFNMPC_OK) return 1;          // (also rejects lo >= hi)
+            if (cfnmpc_set_box_stages(g->s, nullptr, nullptr, 0, nullptr) != CFNMPC_OK) return 1;
+        } else {
+            // [1][N][4] = the shim's own storage order (rejects lb > ub and NaN; lb = ub pins an input)
+            if (cfnmpc_set_box_stages(g->s, &g->lbu[0][0], &g->ubu[0][0], 0, nullptr) != CFNMPC_OK) return 1;
+        }
         g->box_dirty = false;
     }
     int status = 1, iters = 0;

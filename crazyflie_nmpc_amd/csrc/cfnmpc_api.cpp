@@ -28,7 +28,7 @@ struct cfnmpc_solver {
     unsigned long long bytes;
     // optional per-kernel timing with HIP events on the launch stream (cfnmpc_set_profiling)
     int profiling;
-    std::vector<hipEvent_t> ev;  // triples (start, between the two phases, end), one per RTI step
+    std::vector<hipEvent_t> ev;  // EV_PER_STEP events per timed RTI step: start | linearise | factor | forward | compaction | active set | end
     size_t ev_used;
     // preparation-phase overlap (cfnmpc_opts.overlap_linearise): the linearisation for the NEXT
     // step is written to the alternate (AR, BR, b) set while the interior-point kernel still
@@ -46,6 +46,7 @@ struct cfnmpc_solver {
     hipGraphExec_t gexec[2];
     bool gvalid[2];
     int parity;                  // which of the two argument sets the NEXT step uses
+    double *lbs_keep, *ubs_keep; // per-stage boxes (cfnmpc_set_box_stages), allocated at the first call
 };
 
 namespace {
@@ -75,6 +76,7 @@ struct DeviceGuard {
 };
 
 constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the count
+constexpr size_t EV_PER_STEP = 7;
 constexpr int FORWARD_RG_BELOW = 8192;        // measured cross-over of the two forward sweeps
 
 template <typename T>
@@ -140,7 +142,7 @@ bool weights_ok(const double* W, const double* WN) {
 
 extern "C" {
 
-const char* cfnmpc_version(void) { return "cfnmpc 0.6 (gfx950; row-group Riccati with fused DPP broadcast FMAs, lane-per-instance linearisation and matrix-free forward sweep, primal-dual active-set QP solves; options: partial condensing, small-fleet forward sweep; device output stage; multi-GPU shards)"; }
+const char* cfnmpc_version(void) { return "cfnmpc 0.7 (gfx950; row-group Riccati with fused DPP broadcast FMAs, lane-per-instance linearisation and matrix-free forward sweep, primal-dual active-set QP solves; options: partial condensing, small-fleet forward sweep; device output stage; multi-GPU shards)"; }
 
 void cfnmpc_default_opts(cfnmpc_opts* o) {
     // generate_c_code.py:41-42,63-84,109,133-134
@@ -205,6 +207,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     s->gexec[0] = s->gexec[1] = nullptr;
     s->gvalid[0] = s->gvalid[1] = false;
     s->parity = 0;
+    s->lbs_keep = s->ubs_keep = nullptr;
     // the shooting intervals of a 64-instance group are independent: spread them over enough
     // workgroups to fill the 1024 SIMDs when the batch alone does not (a single instance then
     // linearises its 50 intervals in parallel instead of one after the other)
@@ -361,6 +364,43 @@ int cfnmpc_set_box(cfnmpc_solver* s, double u_min, double u_max) {
     return CFNMPC_OK;
 }
 
+int cfnmpc_set_box_stages(cfnmpc_solver* s, const double* lb, const double* ub, int on_device, void* stream) {
+    if (!s || ((lb == nullptr) != (ub == nullptr))) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    cfn::Params& P = s->P;
+    if (!lb) {                       // back to the scalar box of cfnmpc_set_box
+        if (P.lbs) { s->lbs_keep = P.lbs; s->ubs_keep = P.ubs; }
+        P.lbs = P.ubs = nullptr;
+        invalidate_graphs(s);
+        return CFNMPC_OK;
+    }
+    if (P.cond_N2) return CFNMPC_EINVAL;   // the condensed path has no per-stage boxes
+    const size_t n = (size_t)P.B * P.N * 4;
+    if (!on_device)
+        for (size_t i = 0; i < n; i++) if (!(lb[i] <= ub[i])) return CFNMPC_EINVAL;   // (NaN fails too; lb = ub pins the input)
+    if (!s->lbs_keep) {
+        const size_t cnt = ((size_t)P.NW + 1) * 4 * P.N * 4;
+        int rc = dev_alloc(s, &s->lbs_keep, cnt);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->ubs_keep, cnt);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &P.clbs, cnt);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &P.cubs, cnt);
+        if (rc != CFNMPC_OK) return rc;
+        // rows of the spare block (parked rows of compacted waves): a wide finite box
+        std::vector<double> lo(4 * (size_t)P.N * 4, -1e30), hi(4 * (size_t)P.N * 4, 1e30);
+        HIP_TRY(hipMemcpy(s->lbs_keep + (size_t)P.NW * 4 * P.N * 4, lo.data(), lo.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(s->ubs_keep + (size_t)P.NW * 4 * P.N * 4, hi.data(), hi.size() * 8, hipMemcpyHostToDevice));
+    }
+    // instance-major [inst][stage][4] is the caller's AoS order: plain copies
+    hipStream_t st = (hipStream_t)stream;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIP_TRY(hipMemcpyAsync(s->lbs_keep, lb, n * sizeof(double), kind, st));
+    HIP_TRY(hipMemcpyAsync(s->ubs_keep, ub, n * sizeof(double), kind, st));
+    if (!on_device) HIP_TRY(hipStreamSynchronize(st));
+    P.lbs = s->lbs_keep; P.ubs = s->ubs_keep;
+    invalidate_graphs(s);
+    return CFNMPC_OK;
+}
+
 int cfnmpc_get_cmd(cfnmpc_solver* s, double* cmd_vel, int* motvel, int on_device, void* stream) {
     if (!s || !cmd_vel) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
@@ -415,14 +455,14 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     for (int it = 0; it < n_rti; it++) {
         hipEvent_t* e = nullptr;
-        if (s->profiling && s->ev_used < 3 * MAX_PROFILED_STEPS) {   // bounded: later steps go untimed
-            while (s->ev.size() < s->ev_used + 3) {
+        if (s->profiling && s->ev_used < EV_PER_STEP * MAX_PROFILED_STEPS) {   // bounded: later steps go untimed
+            while (s->ev.size() < s->ev_used + EV_PER_STEP) {
                 hipEvent_t ne;
                 HIP_TRY(hipEventCreate(&ne));
                 s->ev.push_back(ne);
             }
             e = &s->ev[s->ev_used];
-            s->ev_used += 3;
+            s->ev_used += EV_PER_STEP;
         }
         if (!s->overlap && s->use_graph && !e) {
             // the step's launches replayed from a captured graph (one per parity of the iterate buffers)
@@ -453,9 +493,13 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
             if (e) HIP_TRY(hipEventRecord(e[0], st));
             cfn::launch_linearise(s->P, s->chunks_all, st);
             if (e) HIP_TRY(hipEventRecord(e[1], st));
-            if (s->P.cond_N2) cfn::launch_qp_cond(s->P, st);   // pcond -> condensed Riccati -> expand (-> interior point)
-            else cfn::launch_qp(s->P, st);
-            if (e) HIP_TRY(hipEventRecord(e[2], st));
+            if (s->P.cond_N2) {
+                cfn::launch_qp_cond(s->P, st);   // pcond -> condensed Riccati -> expand (-> interior point)
+                if (e) for (int j = 2; j < 6; j++) HIP_TRY(hipEventRecord(e[j], st));   // (no per-kernel split on this path)
+            } else {
+                cfn::launch_qp(s->P, st, e ? e + 2 : nullptr);
+            }
+            if (e) HIP_TRY(hipEventRecord(e[6], st));
             std::swap(s->P.xit, s->P.xitn);   // the step's kernels wrote every instance's new iterate there
             std::swap(s->P.uit, s->P.uitn);
             s->parity ^= 1;
@@ -468,7 +512,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
         cfn::launch_qp_start(s->P, st);
         HIP_TRY(hipEventRecord(s->ev_start, st));
         cfn::launch_qp_ipm(s->P, st);
-        if (e) HIP_TRY(hipEventRecord(e[1], st));
+        if (e) { for (int j = 1; j < 6; j++) HIP_TRY(hipEventRecord(e[j], st)); }   // (phases only on the overlapped path)
         // ... and preparation of the next step into the alternate set: an early pass over ALL
         // instances runs beside the interior-point kernel (the instances still inside it are
         // linearised around a stale iterate there and redone by the list pass afterwards)
@@ -481,7 +525,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
         HIP_TRY(hipEventRecord(s->ev_aux, s->aux));
         HIP_TRY(hipStreamWaitEvent(st, s->ev_aux, 0));
         cfn::launch_linearise_list(Q, s->chunks_list, st);
-        if (e) HIP_TRY(hipEventRecord(e[2], st));
+        if (e) HIP_TRY(hipEventRecord(e[6], st));
         s->AR2 = s->P.AR; s->BR2 = s->P.BR; s->b2 = s->P.b;
         s->P.AR = Q.AR; s->P.BR = Q.BR; s->P.b = Q.b;
         s->lin_valid = true;
@@ -614,23 +658,35 @@ int cfnmpc_set_profiling(cfnmpc_solver* s, int enable) {
     return CFNMPC_OK;
 }
 
-int cfnmpc_get_profile(cfnmpc_solver* s, double* ms_linearise, double* ms_qp, int* n_steps) {
-    if (!s || !ms_linearise || !ms_qp || !n_steps) return CFNMPC_EINVAL;
+int cfnmpc_get_profile_kernels(cfnmpc_solver* s, double* ms, int* n_steps) {
+    if (!s || !ms || !n_steps) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
-    double a = 0.0, b = 0.0;
-    const size_t n = s->ev_used / 3;
+    double acc[EV_PER_STEP - 1] = {0, 0, 0, 0, 0, 0};
+    const size_t n = s->ev_used / EV_PER_STEP;
     for (size_t i = 0; i < n; i++) {
-        float t0 = 0.f, t1 = 0.f;
-        HIP_TRY(hipEventSynchronize(s->ev[3 * i + 2]));
-        HIP_TRY(hipEventElapsedTime(&t0, s->ev[3 * i], s->ev[3 * i + 1]));
-        HIP_TRY(hipEventElapsedTime(&t1, s->ev[3 * i + 1], s->ev[3 * i + 2]));
-        a += s->overlap ? t1 : t0;   // overlap: the QP phase comes first, then the exposed linearisation
-        b += s->overlap ? t0 : t1;
+        hipEvent_t* e = &s->ev[EV_PER_STEP * i];
+        HIP_TRY(hipEventSynchronize(e[EV_PER_STEP - 1]));
+        for (size_t j = 0; j + 1 < EV_PER_STEP; j++) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, e[j], e[j + 1]));
+            acc[j] += t;
+        }
     }
-    *ms_linearise = n ? a / n : 0.0;
-    *ms_qp = n ? b / n : 0.0;
+    for (size_t j = 0; j + 1 < EV_PER_STEP; j++) ms[j] = n ? acc[j] / n : 0.0;
     *n_steps = (int)n;
     s->ev_used = 0;
+    return CFNMPC_OK;
+}
+
+int cfnmpc_get_profile(cfnmpc_solver* s, double* ms_linearise, double* ms_qp, int* n_steps) {
+    if (!s || !ms_linearise || !ms_qp || !n_steps) return CFNMPC_EINVAL;
+    double ms[EV_PER_STEP - 1];
+    const int rc = cfnmpc_get_profile_kernels(s, ms, n_steps);
+    if (rc != CFNMPC_OK) return rc;
+    const double a = ms[0], b = ms[1] + ms[2] + ms[3] + ms[4] + ms[5];
+    // overlap: the QP phase comes first (events 0 -> 1..5), then the exposed linearisation (5 -> 6)
+    *ms_linearise = s->overlap ? ms[5] : a;
+    *ms_qp = s->overlap ? a : b;
     return CFNMPC_OK;
 }
 

@@ -150,6 +150,15 @@ __device__ __forceinline__ size_t i4(const Params& P, const Lane& t, int k, int 
     return ((size_t)t.inst * P.N + k) * 4 + a;
 }
 
+// Input box of element idx (instance-major 4-vector index in P's own indexing): the scalar box of cfnmpc_set_box,
+// or -- SBOX, kernels instantiated for cfnmpc_set_box_stages -- the per-stage, per-input arrays (acados' "lbu" /
+// "ubu" on individual stages, acados_mpc.cpp:605-608).
+template <bool SBOX>
+__device__ __forceinline__ void box_at(const Params& P, const size_t idx, double& lo, double& hi) {
+    if (SBOX) { lo = gm(P.lbs)[idx]; hi = gm(P.ubs)[idx]; }
+    else { lo = P.u_min; hi = P.u_max; }
+}
+
 // Loads are branch-free: every lane reads a valid (clamped) address and lanes outside the
 // stored range select 0 -- exec-masked loads would split the unrolled code into tiny blocks.
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
@@ -838,7 +847,10 @@ __device__ __forceinline__ void sweep_resolve(const Params& P, const Lane& t, co
 // Element state (instance-major 4-vectors of the compact slot): P.tl = c, P.tu = class (0 free,
 // 1 lower, 2 upper) as a double, P.dva = du.
 constexpr double AS_BIG = 1e30;
-constexpr int AS_MAX_SOLVES = 12;   // observed on the bench workload: 48 % settle after 1 solve, 99 % within 4, all within 8
+#ifndef CFN_AS_MAX
+#define CFN_AS_MAX 12
+#endif
+constexpr int AS_MAX_SOLVES = CFN_AS_MAX;   // observed on the bench workload: 48 % settle after 1 solve, 99 % within 4, all within 8
 __device__ __forceinline__ void load_stage_as(const Params& P, const Lane& t, const int k, StageIn<true>& in) {
     ld_ar_raw(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
     ld_rows4_raw(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
@@ -903,10 +915,11 @@ __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, 
 // on the way (stage-local: grad = R c + B'pi_{k+1} with B'pi_{k+1} = G dx_k + (B'PB) du_free + rho,
 // pi = P dx + p being the costate of the equality-constrained solve).  Returns the last stage of
 // the row in which an input changed its class (-1: none).
+template <bool SBOX = false>
 __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, const int head) {
     // kg: lanes 0..3 hold K[a][0..12], lanes 4..7 hold G[a][0..12] -- ONE chain of 13 broadcast FMAs
     // forms the feedback (lanes 0..3) and G dx (lanes 4..7) together
-    struct In { double kg[13], ar[10], br[4], d, sr[4], rho, c, cls, v0, uk; };
+    struct In { double kg[13], ar[10], br[4], d, sr[4], rho, c, cls, v0, uk, lo, hi; };
     const int a = t.L & 3;
     const bool lo4 = t.L < 4;
     auto load = [&](int k, In& in) {
@@ -922,6 +935,7 @@ __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, 
         in.d = gm(P.d)[idx];
         in.rho = gm(P.crho)[idx];
         in.c = gm(P.tl)[idx]; in.cls = gm(P.tu)[idx]; in.v0 = gm(P.v)[idx]; in.uk = gm(P.uit)[idx];
+        box_at<SBOX>(P, idx, in.lo, in.hi);
     };
     double x = 0.0;
     int jm = -1;
@@ -940,12 +954,13 @@ __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, 
         SFOR(c, 0, 4, { gd += cur.sr[c] * fr[c]; });     // + (B'PB)[a][free] du_free
         if (lo4) {
             const double grad = t.wu * cur.c + gd + cur.rho;   // multiplier of a fixed input
-            const double lb = P.u_min - cur.uk, ub = P.u_max - cur.uk;
+            const double lb = cur.lo - cur.uk, ub = cur.hi - cur.uk;
             const double vn = cur.v0 + dv;
             double nc;
             if (cur.cls == 0.0) nc = vn < lb ? 1.0 : (vn > ub ? 2.0 : 0.0);
             else if (cur.cls == 1.0) nc = grad > 0.0 ? 1.0 : 0.0;
             else nc = grad < 0.0 ? 2.0 : 0.0;
+            if (SBOX && !(cur.lo < cur.hi)) nc = 1.0;   // lb = ub: an equality, fixed whatever its multiplier's sign
             jm = nc != cur.cls ? k : jm;
             const size_t idx = i4(P, t, k, a);
             gm(P.tu)[idx] = nc;
@@ -1250,7 +1265,8 @@ __global__ __launch_bounds__(64) void k_cforward(Params P) {
 // (DESIGN.md section 5.4), so the choice is by batch size (cfnmpc_opts.forward_sweep).
 // The compaction ranks (per 64-instance group, as k_forward leaves them) come from k_rank.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_forward_rg(Params P) {
+template <bool SBOX>
+__device__ __forceinline__ void forward_rg_body(const Params& P) {
     const Lane t = lane_id(P);
     const int N = P.N;
     const double margin = P.ah_margin * (P.u_max - P.u_min);
@@ -1258,10 +1274,11 @@ __global__ __launch_bounds__(64) void k_forward_rg(Params P) {
     const bool lo4 = t.L < 4;
     // three rotating stage buffers: the loads of stage k+2 are issued before the arithmetic of stage k
     // (small fleets run about one wave per SIMD: memory-level parallelism has to come from the wave itself)
-    struct In { FwdIn<true> f; double u, xb; };
+    struct In { FwdIn<true> f; double u, xb, lo, hi; };
     auto load = [&](int k, In& in) {
         load_fwd<true>(P, t, k, in.f);
         in.u = gm(P.uit)[i4(P, t, k, a)];
+        box_at<SBOX>(P, i4(P, t, k, a), in.lo, in.hi);
         in.xb = ld13(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);
     };
     double xbcur = ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
@@ -1273,7 +1290,7 @@ __global__ __launch_bounds__(64) void k_forward_rg(Params P) {
         st13(blk(P.xitn, t, N + 1, k, SZ_V13), t, xbcur + x);
         const double v = feedback<true>(t, cur.f, x);      // lanes a < 4: du = -K dx - d
         if (lo4) {
-            const double lb = P.u_min - cur.u, ub = P.u_max - cur.u;
+            const double lb = cur.lo - cur.u, ub = cur.hi - cur.u;
             viol = fmax(viol, fmax(lb - v, v - ub));
             nviol += (v < lb || v > ub) ? 1 : 0;
             if (v < lb + margin || v > ub - margin) last_tight = k;
@@ -1325,6 +1342,8 @@ __global__ __launch_bounds__(64) void k_forward_rg(Params P) {
     }
     keep_row(P, t, bad);   // a failed row keeps its iterate: old -> new
 }
+__global__ __launch_bounds__(64) void k_forward_rg(Params P) { forward_rg_body<false>(P); }
+__global__ __launch_bounds__(64) void k_forward_rg_sbox(Params P) { forward_rg_body<true>(P); }
 // per 64-instance group: bin counts and ranks of the constrained instances (the second half of
 // k_forward's epilogue, for the row-group forward sweep)
 __global__ __launch_bounds__(64) void k_rank(Params P) {
@@ -1408,13 +1427,15 @@ struct Elem {
     double v, tl, tu, ll, lu, rg, lb, ub;
     double dva, dvc;   // predictor / corrector input steps (passes that need them)
 };
-template <int NSTEP>   // NSTEP = 0: state only, 1: + dva, 2: + dva, dvc
+template <int NSTEP, bool SBOX = false>   // NSTEP = 0: state only, 1: + dva, 2: + dva, dvc
 __device__ __forceinline__ Elem ld_elem(const Params& P, size_t idx) {
     Elem e;
     e.v = gm(P.v)[idx]; e.tl = gm(P.tl)[idx]; e.tu = gm(P.tu)[idx]; e.ll = gm(P.ll)[idx]; e.lu = gm(P.lu)[idx]; e.rg = gm(P.rg)[idx];
     const double uk = gm(P.uit)[idx];
-    e.lb = P.u_min - uk;
-    e.ub = P.u_max - uk;
+    double lo, hi;
+    box_at<SBOX>(P, idx, lo, hi);
+    e.lb = lo - uk;
+    e.ub = hi - uk;
     e.dva = NSTEP >= 1 ? gm(P.dva)[idx] : 0.0;
     e.dvc = NSTEP >= 2 ? gm(P.dvc)[idx] : 0.0;
     return e;
@@ -1422,11 +1443,11 @@ __device__ __forceinline__ Elem ld_elem(const Params& P, size_t idx) {
 // One pass over the n elements of a row, in batches of four per lane with all loads of a batch
 // issued before any arithmetic (these passes run with one wave per SIMD: a plain loop would pay
 // one memory round trip per element).
-template <int NSTEP, class BODY>
+template <int NSTEP, bool SBOX, class BODY>
 __device__ __forceinline__ void elem_pass(const Params& P, size_t base, int n, int L, BODY&& body) {
     for (int e0 = L; e0 < n; e0 += 64) {
         Elem d[4];
-        SFOR(j, 0, 4, { d[j] = ld_elem<NSTEP>(P, base + imin(e0 + 16 * j, n - 1)); });
+        SFOR(j, 0, 4, { d[j] = ld_elem<NSTEP, SBOX>(P, base + imin(e0 + 16 * j, n - 1)); });
         SFOR(j, 0, 4, { if (e0 + 16 * j < n) body(e0 + 16 * j, d[j]); });
     }
 }
@@ -1446,7 +1467,7 @@ __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave
 // others are left untouched for a MODE 2 launch; MODE 2: interior point for the rows without flag;
 // MODE 3: MODE 1 for the rows the level-synchronous pipeline's commit kernel flagged (P.done = 2: settled,
 // but a tail input left the box -- solve again over the longer head it wrote to P.head).
-template <int MODE>
+template <int MODE, bool SBOX = false>
 __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64]) {
 #ifdef CFN_PROF
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
@@ -1483,17 +1504,19 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     tc.wave = blockIdx.x; tc.q = t.row; tc.inst = blockIdx.x * 4 + t.row;
     Params Q = P;
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
+    Q.lbs = P.clbs; Q.ubs = P.cubs;
     const size_t cbase = (size_t)tc.inst * N * 4;  // compact 4-vectors of this row
     auto gather = [&](int hd, int ck) {
         // four stages per batch, loads first (the source lines are cold: one HBM round trip each)
         for (int k0 = 0; k0 < hd; k0 += 4) {
-            double ar[4][10], br[4][4], vv[4], uu[4];
+            double ar[4][10], br[4][4], vv[4], uu[4], blo[4], bhi[4];
             SFOR(j, 0, 4, {
                 const int k = imin(k0 + j, hd - 1);
                 ld_ar(blk(P.AR, t, N, k, SZ_A), t, ar[j]);
                 ld_rows4(blk(P.BR, t, N, k, SZ_B), t, br[j]);
                 vv[j] = gm(P.v)[i4(P, t, k, t.L & 3)];
                 uu[j] = gm(P.uit)[i4(P, t, k, t.L & 3)];
+                box_at<SBOX>(P, i4(P, t, k, t.L & 3), blo[j], bhi[j]);
             });
             SFOR(j, 0, 4, {
                 const int k = k0 + j;
@@ -1505,6 +1528,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                     if (t.L < 4) {
                         gm(Q.v)[i4(Q, tc, k, t.L)] = vv[j];
                         gm(Q.uit)[i4(Q, tc, k, t.L)] = uu[j];
+                        if (SBOX) { gm(Q.lbs)[i4(Q, tc, k, t.L)] = blo[j]; gm(Q.ubs)[i4(Q, tc, k, t.L)] = bhi[j]; }
                     }
                 }
             });
@@ -1530,17 +1554,19 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         if (MODE != 2 && P.active_set) {
             // initial classification from the unconstrained minimiser
             for (int e0 = t.L; e0 < head * 4; e0 += 64) {
-                double uk[4], vv[4];
+                double uk[4], vv[4], blo[4], bhi[4];
                 SFOR(j, 0, 4, {
                     const size_t idx = cbase + imin(e0 + 16 * j, head * 4 - 1);
                     uk[j] = gm(Q.uit)[idx];
                     vv[j] = gm(Q.v)[idx];
+                    box_at<SBOX>(Q, idx, blo[j], bhi[j]);
                 });
                 SFOR(j, 0, 4, {
                     const int e = e0 + 16 * j;
                     if (e < head * 4) {
-                        const double lb = P.u_min - uk[j], ub = P.u_max - uk[j];
-                        const double cls = vv[j] < lb ? 1.0 : (vv[j] > ub ? 2.0 : 0.0);
+                        const double lb = blo[j] - uk[j], ub = bhi[j] - uk[j];
+                        double cls = vv[j] < lb ? 1.0 : (vv[j] > ub ? 2.0 : 0.0);
+                        if (SBOX && !(blo[j] < bhi[j])) cls = 1.0;   // lb = ub: fixed from the start
                         gm(Q.tu)[cbase + e] = cls;
                         gm(Q.tl)[cbase + e] = cls == 1.0 ? lb - vv[j] : (cls == 2.0 ? ub - vv[j] : 0.0);
                     }
@@ -1553,7 +1579,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 as_ok = sweep_factor_as(Q, tc, head, chk, kstart, wt, sb) && as_ok;
                 PROF_T(2)
                 PROF_SOLVE(kstart + 1)
-                int jw = sweep_forward_as(Q, tc, head);
+                int jw = sweep_forward_as<SBOX>(Q, tc, head);
                 const bool changed = jw >= 0;
                 jw = max(jw, __shfl_xor(jw, 16));
                 jw = max(jw, __shfl_xor(jw, 32));
@@ -1582,18 +1608,19 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             const double mu0 = fmax(P.mu0_scale * viol, P.lam0_min);
             double mu = 0.0, res = 0.0;
             for (int e0 = t.L; e0 < head * 4; e0 += 64) {
-                double uk[4], vv[4];
+                double uk[4], vv[4], blo[4], bhi[4];
                 SFOR(j, 0, 4, {
                     const size_t idx = cbase + imin(e0 + 16 * j, head * 4 - 1);
                     uk[j] = gm(Q.uit)[idx];
                     vv[j] = gm(Q.v)[idx];
+                    box_at<SBOX>(Q, idx, blo[j], bhi[j]);
                 });
                 SFOR(j, 0, 4, {
                     const int e = e0 + 16 * j;
                     if (e < head * 4) {
                         const size_t idx = cbase + e;
                         const double v = vv[j];
-                        const double lb = P.u_min - uk[j], ub = P.u_max - uk[j];
+                        const double lb = blo[j] - uk[j], ub = bhi[j] - uk[j];
                         const double tl = fmax(v - lb, P.thr0), tu = fmax(ub - v, P.thr0);
                         const double itl = rcp_nr(tl), itu = rcp_nr(tu);
                         const double ll = mu0 * itl, lu = mu0 * itu, rg = -ll + lu;
@@ -1664,18 +1691,18 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 if (n <= 64) {
                     Elem d[4];
                     Aff f[4];
-                    SFOR(j, 0, 4, { d[j] = ld_elem<1>(Q, cbase + imin(t.L + 16 * j, n - 1)); });
+                    SFOR(j, 0, 4, { d[j] = ld_elem<1, SBOX>(Q, cbase + imin(t.L + 16 * j, n - 1)); });
                     SFOR(j, 0, 4, { f[j] = aff(d[j]); if (t.L + 16 * j < n) passA(d[j], f[j]); });
                     a = row_min(a);
                     SFOR(j, 0, 4, { if (t.L + 16 * j < n) passB(d[j], f[j]); });
                     centre();
                     SFOR(j, 0, 4, { if (t.L + 16 * j < n) passC(t.L + 16 * j, d[j], f[j]); });
                 } else {
-                    elem_pass<1>(Q, cbase, n, t.L, [&](int, const Elem& el) { passA(el, aff(el)); });
+                    elem_pass<1, SBOX>(Q, cbase, n, t.L, [&](int, const Elem& el) { passA(el, aff(el)); });
                     a = row_min(a);
-                    elem_pass<1>(Q, cbase, n, t.L, [&](int, const Elem& el) { passB(el, aff(el)); });
+                    elem_pass<1, SBOX>(Q, cbase, n, t.L, [&](int, const Elem& el) { passB(el, aff(el)); });
                     centre();
-                    elem_pass<1>(Q, cbase, n, t.L, [&](int e, const Elem& el) { passC(e, el, aff(el)); });
+                    elem_pass<1, SBOX>(Q, cbase, n, t.L, [&](int e, const Elem& el) { passC(e, el, aff(el)); });
                 }
             }
             // corrector: re-solve, forward
@@ -1722,14 +1749,14 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 if (n <= 64) {
                     Elem d[4];
                     Stp f[4];
-                    SFOR(j, 0, 4, { d[j] = ld_elem<2>(Q, cbase + imin(t.L + 16 * j, n - 1)); });
+                    SFOR(j, 0, 4, { d[j] = ld_elem<2, SBOX>(Q, cbase + imin(t.L + 16 * j, n - 1)); });
                     SFOR(j, 0, 4, { f[j] = stp(d[j]); if (t.L + 16 * j < n) passD(d[j], f[j]); });
                     a = fmin(1.0, P.tau * row_min(a));
                     SFOR(j, 0, 4, { if (t.L + 16 * j < n) passE(t.L + 16 * j, d[j], f[j]); });
                 } else {
-                    elem_pass<2>(Q, cbase, n, t.L, [&](int, const Elem& el) { passD(el, stp(el)); });
+                    elem_pass<2, SBOX>(Q, cbase, n, t.L, [&](int, const Elem& el) { passD(el, stp(el)); });
                     a = fmin(1.0, P.tau * row_min(a));
-                    elem_pass<2>(Q, cbase, n, t.L, [&](int e, const Elem& el) { passE(e, el, stp(el)); });
+                    elem_pass<2, SBOX>(Q, cbase, n, t.L, [&](int e, const Elem& el) { passE(e, el, stp(el)); });
                 }
                 mu = row_sum(mu) / (8.0 * head);
                 res = row_max(res);
@@ -1759,6 +1786,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 load_fwd<true>(P, t, kn, nxt);  // prefetch
                 vnxt = gm(Q.v)[i4(Q, tc, imin(kn, head - 1), t.L & 3)];
                 unxt = gm(P.uit)[i4(P, t, kn, t.L & 3)];
+                double blo, bhi;                       // box of stage k (only its tail check reads it)
+                box_at<SBOX>(P, i4(P, t, k, t.L & 3), blo, bhi);
                 xbnxt = ld13(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);
                 st13(blk(P.xitn, t, N + 1, k, SZ_V13), t, xbcur + x);
                 double v;
@@ -1766,7 +1795,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                     v = t.L < 4 ? vcur : 0.0;
                 } else {
                     v = feedback<true>(t, cur, x);
-                    if (t.L < 4 && !((v >= P.u_min - ucur) && (v <= P.u_max - ucur))) kviol = k;
+                    if (t.L < 4 && !((v >= blo - ucur) && (v <= bhi - ucur))) kviol = k;
                 }
                 // candidate inputs of the whole horizon (P.v keeps the unconstrained minimiser)
                 if (t.L < 4) gm(P.uitn)[i4(P, t, k, t.L)] = ucur + v;
@@ -1839,6 +1868,22 @@ __global__ __launch_bounds__(64) void k_ipm_rest(Params P) {  // interior point 
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
     qp_wave<2>(P, wtile, btile);
+}
+// the same three for per-stage input boxes (cfnmpc_set_box_stages)
+__global__ __launch_bounds__(64) void k_ipm_sbox(Params P) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<0, true>(P, wtile, btile);
+}
+__global__ __launch_bounds__(64) void k_as_sbox(Params P) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<1, true>(P, wtile, btile);
+}
+__global__ __launch_bounds__(64) void k_ipm_rest_sbox(Params P) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<2, true>(P, wtile, btile);
 }
 __global__ __launch_bounds__(64) void k_as_retry(Params P) {  // MODE 3: rows the commit kernel sent back
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
@@ -2635,22 +2680,39 @@ void launch_linearise(const Params& P, int chunks, hipStream_t st) {
 void launch_linearise_list(const Params& P, int chunks, hipStream_t st) {
     hipLaunchKernelGGL(k_linearise_list, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P);
 }
-void launch_qp_start(const Params& P, hipStream_t st) {
+// ev (optional, cfnmpc_set_profiling): events recorded after k_factor, after the forward sweep, after the compaction
+void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
-    if (P.forward_rg) {
+    if (ev) (void)hipEventRecord(ev[0], st);
+    if (P.lbs) {   // per-stage boxes: the row-group forward sweep carries them
+        hipLaunchKernelGGL(k_forward_rg_sbox, dim3(P.NW), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_rank, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+    } else if (P.forward_rg) {
         hipLaunchKernelGGL(k_forward_rg, dim3(P.NW), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_rank, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     } else {
         hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     }
+    if (ev) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_compact, dim3(N_BIN), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_scatter, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
+    if (ev) (void)hipEventRecord(ev[2], st);
 }
 void launch_cforward(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_cforward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
 }
-void launch_qp_ipm(const Params& P, hipStream_t st) {
-    if (P.active_set && P.as_passes != 0) {
+// ev (optional): event recorded after the active-set kernels (before the interior-point launch for what they left)
+void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
+    if (P.lbs) {   // per-stage boxes: monolithic kernels instantiated for them
+        if (P.active_set) {
+            hipLaunchKernelGGL(k_as_sbox, dim3(P.NW), dim3(64), 0, st, P);
+            if (ev) (void)hipEventRecord(ev[0], st);
+            hipLaunchKernelGGL(k_ipm_rest_sbox, dim3(P.NW), dim3(64), 0, st, P);
+        } else {
+            if (ev) (void)hipEventRecord(ev[0], st);
+            hipLaunchKernelGGL(k_ipm_sbox, dim3(P.NW), dim3(64), 0, st, P);
+        }
+    } else if (P.active_set && P.as_passes != 0) {
         // as_passes > 0: level-synchronous active-set passes -- pairs (factor, forward) of one solve each, one
         // launch loops over the remaining solves in-wave; as_passes < 0: every solve in one launch.  Then commit,
         // retries over a longer head, interior point for the rest.
@@ -2670,17 +2732,20 @@ void launch_qp_ipm(const Params& P, hipStream_t st) {
         if (P.NW <= 2 * P.as_grid) hipLaunchKernelGGL(k_ascommit1, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
         else hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_as_retry, dim3(P.NW), dim3(64), 0, st, P);
+        if (ev) (void)hipEventRecord(ev[0], st);
         hipLaunchKernelGGL(k_ipm_rest, dim3(P.NW), dim3(64), 0, st, P);
     } else if (P.active_set) {
         hipLaunchKernelGGL(k_as, dim3(P.NW), dim3(64), 0, st, P);
+        if (ev) (void)hipEventRecord(ev[0], st);
         hipLaunchKernelGGL(k_ipm_rest, dim3(P.NW), dim3(64), 0, st, P);
     } else {
+        if (ev) (void)hipEventRecord(ev[0], st);
         hipLaunchKernelGGL(k_ipm, dim3(P.NW), dim3(64), 0, st, P);
     }
 }
-void launch_qp(const Params& P, hipStream_t st) {
-    launch_qp_start(P, st);
-    launch_qp_ipm(P, st);
+void launch_qp(const Params& P, hipStream_t st, hipEvent_t* ev) {
+    launch_qp_start(P, st, ev);
+    launch_qp_ipm(P, st, ev ? ev + 3 : nullptr);
 }
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st) {
     hipLaunchKernelGGL(k_sim, dim3((B + 255) / 256), dim3(256), 0, st, B, x, u, T, steps, xn);

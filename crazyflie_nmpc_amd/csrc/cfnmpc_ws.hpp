@@ -101,6 +101,9 @@ struct Params {
     int *aslist, *ascnt;         // work lists [set 0..2][bin 0..6][compact slots], their lengths [set][bin]
     int *askst, *asst, *asok;    // per compact slot: restart stage of its next solve; 1 = settled (to be committed); last factorisation positive definite
     double *czdx;                // per compact slot: dx_k of its last solve, (N + 1) x 13
+    // per-stage, per-input input box (cfnmpc_set_box_stages; NULL: the scalar box u_min / u_max): instance-major
+    // [inst][stage][4] like uit, and the compact copies of the constrained-QP kernels
+    double *lbs, *ubs, *clbs, *cubs;
     int forward_rg;              // 1: forward sweep of the start solve on the stored blocks (k_forward_rg; small fleets)
     int cond_N2, cond_M, cond_rem;
     double *cb;                  // condensed blocks, [instance][block][cb_size(w_max)] (layout: cfnmpc_pcond.hip)
@@ -124,9 +127,10 @@ __host__ __device__ constexpr int cb_size(int mmax) { return cond_tri(cond_w(mma
 // (independent) shooting intervals of one 64-instance group are spread over
 void launch_linearise(const Params& P, int chunks, hipStream_t st);
 void launch_linearise_list(const Params& P, int chunks, hipStream_t st);
-void launch_qp(const Params& P, hipStream_t st);        // = launch_qp_start + launch_qp_ipm
-void launch_qp_start(const Params& P, hipStream_t st);  // factor, forward (+ full step of feasible rows), compact
-void launch_qp_ipm(const Params& P, hipStream_t st);    // interior-point instances (+ their full step)
+// ev (optional): four events recorded after k_factor / the forward sweep / the compaction / the active-set kernels
+void launch_qp(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr);        // = launch_qp_start + launch_qp_ipm
+void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr);  // factor, forward (+ full step of feasible rows), compact
+void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr);    // constrained instances (+ their full step)
 // partial condensing path (cfnmpc_pcond.hip): pcond -> condensed Riccati -> forward sweep with expand ->
 // interior point on the condensed QP for the constrained instances
 void launch_pcond(const Params& P, hipStream_t st);

@@ -126,6 +126,17 @@ class BatchSolver:
     def set_box(self, u_min, u_max):
         _check(self._L.cfnmpc_set_box(self._h, float(u_min), float(u_max)), "cfnmpc_set_box")
 
+    def set_box_stages(self, lb=None, ub=None):
+        """Per-stage, per-input box [B][N][4] (acados' "lbu" / "ubu" on individual stages); None, None: back to
+        the scalar box."""
+        if lb is None and ub is None:
+            _check(self._L.cfnmpc_set_box_stages(self._h, None, None, 0, None), "cfnmpc_set_box_stages")
+            return
+        p, dev, st, _k = _arg(lb, (self.B, self.N, NU))
+        pu, devu, _s, _k2 = _arg(ub, (self.B, self.N, NU))
+        assert dev == devu
+        _check(self._L.cfnmpc_set_box_stages(self._h, p, pu, dev, st), "cfnmpc_set_box_stages")
+
     def init_iterate(self, mode=INIT_ACADOS, stream=None):
         _check(self._L.cfnmpc_init_iterate(self._h, mode, C.c_void_p(stream or 0)), "cfnmpc_init_iterate")
 
@@ -161,6 +172,12 @@ class BatchSolver:
         a = C.c_double(0); b = C.c_double(0); n = C.c_int(0)
         _check(self._L.cfnmpc_get_profile(self._h, C.byref(a), C.byref(b), C.byref(n)), "cfnmpc_get_profile")
         return a.value, b.value, n.value
+
+    def get_profile_kernels(self):
+        """-> (ms[6], n_steps): linearise | factor | forward | compaction | active set | interior point (averages)."""
+        ms = (C.c_double * 6)(); n = C.c_int(0)
+        _check(self._L.cfnmpc_get_profile_kernels(self._h, ms, C.byref(n)), "cfnmpc_get_profile_kernels")
+        return [float(v) for v in ms], n.value
 
     def linearise_only(self, stream=None):
         _check(self._L.cfnmpc_debug_linearise(self._h, C.c_void_p(stream or 0)), "cfnmpc_debug_linearise")

@@ -162,6 +162,12 @@ int cfnmpc_set_weights(cfnmpc_solver *s, const double *W /*[17]*/, const double 
  * inputs, stages and instances (generate_c_code.py:133-134).  Takes effect at the next
  * cfnmpc_solve.  Per-stage boxes are not offered. */
 int cfnmpc_set_box(cfnmpc_solver *s, double u_min, double u_max);
+/* Per-stage, per-input box: lb, ub [B][N][4] (what "lbu" / "ubu" on INDIVIDUAL stages set in acados -- the reference's
+ * FIXED_U0 variant pins stage 0 to the input in flight, lbu = ubu = u1, acados_mpc.cpp:605-608).  lb[i] = ub[i] makes
+ * that input an equality (the active-set solves keep it fixed whatever its multiplier's sign; the interior-point
+ * fall-back needs lb < ub).  NULL, NULL returns to the scalar box of cfnmpc_set_box.  Steps with per-stage boxes run
+ * the row-group forward sweep and the monolithic QP kernels (instantiated for them); not with cond_N2. */
+int cfnmpc_set_box_stages(cfnmpc_solver *s, const double *lb, const double *ub, int on_device, void *stream);
 
 /* Iterate (the persistent nlp_out of acados_mpc.cpp:77): initial guess, save / restore. */
 int cfnmpc_init_iterate(cfnmpc_solver *s, int mode, void *stream);
@@ -208,6 +214,12 @@ int cfnmpc_get_cmd(cfnmpc_solver *s, double *cmd_vel /*[B][4]*/, int *motvel /*[
  * time it ADDS to the step (the part not hidden behind the interior-point kernel). */
 int cfnmpc_set_profiling(cfnmpc_solver *s, int enable);
 int cfnmpc_get_profile(cfnmpc_solver *s, double *ms_linearise, double *ms_qp, int *n_steps);
+/* The same timed steps split per kernel group (seven events per step): ms[6] = linearisation | start solve backward
+ * (k_factor) | start solve forward (k_forward / k_forward_rg + k_rank) | compaction (k_compact + k_scatter) |
+ * active-set kernels (k_as, or the passes + commit + retry) | interior point for what they left (k_ipm_rest / k_ipm).
+ * Partial-condensing and overlapped steps report their phases in ms[0] / ms[5] only.  Resets like cfnmpc_get_profile
+ * (call one of the two). */
+int cfnmpc_get_profile_kernels(cfnmpc_solver *s, double *ms, int *n_steps);
 
 /* crazyflie_acados_sim_solve() equivalent, batched (acados_estimator.cpp:573-593):
  * xn = RK4(x, u) over T seconds in `steps` sub-steps.  Stateless. */

@@ -586,7 +586,8 @@ def pdas_dense(qp: StageQP, max_solves=12):
     ub = qp.ub.reshape(-1)
     v0 = np.linalg.solve(H, -h)
     v = v0
-    lo, up = v0 < lb, v0 > ub
+    eq = ~(lb < ub)                      # lb = ub (per-stage boxes, cfnmpc_set_box_stages): an equality, fixed whatever
+    lo, up = (v0 < lb) | eq, (v0 > ub) & ~eq   # the sign of its multiplier
     solves, converged = 0, True
     if lo.any() or up.any():
         converged = False
@@ -598,8 +599,8 @@ def pdas_dense(qp: StageQP, max_solves=12):
             if free.any():
                 v[free] = np.linalg.solve(H[np.ix_(free, free)], -h[free] - H[np.ix_(free, act)] @ v[act])
             grad = H @ v + h
-            lo2 = (free & (v < lb)) | (lo & (grad > 0))
-            up2 = (free & (v > ub)) | (up & (grad < 0))
+            lo2 = (free & (v < lb)) | (lo & (grad > 0)) | eq
+            up2 = ((free & (v > ub)) | (up & (grad < 0))) & ~eq
             if np.array_equal(lo2, lo) and np.array_equal(up2, up):
                 converged = True
                 break

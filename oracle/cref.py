@@ -22,9 +22,46 @@ class Opts(C.Structure):
                 ("lam0_min", C.c_double), ("mu0_scale", C.c_double), ("active_set", C.c_int)]
 
 
+def _host_tag():
+    """What `-march=native` resolves to depends on the CPU the library is BUILT on: the tag (CPU model + ISA
+    flags) is stored beside the .so so that a library built on another host (the .so travels with the
+    repository snapshot) is rebuilt before it is loaded or timed here."""
+    model, flags = "", ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and not model:
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("flags") and not flags:
+                flags = ln.split(":", 1)[1].strip()
+            if model and flags:
+                break
+    except OSError:
+        pass
+    import hashlib
+    return model + " #" + hashlib.sha1(flags.encode()).hexdigest()[:12]
+
+
+def march_native():
+    """The -march the compiler resolves `native` to on this host (reported in bench.py's cpu_baseline.sample)."""
+    try:
+        out = subprocess.run(["gcc", "-march=native", "-Q", "--help=target"], capture_output=True, text=True, timeout=20).stdout
+        for ln in out.splitlines():
+            if ln.strip().startswith("-march="):
+                return ln.split("=", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "cfnmpc_ref.c")):
+    stamp = _SO + ".host"
+    tag = _host_tag()
+    stale = (not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "cfnmpc_ref.c"))
+             or not os.path.exists(stamp) or open(stamp).read() != tag)
+    if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+        with open(stamp, "w") as f:
+            f.write(tag)
     return _SO
 
 
@@ -34,8 +71,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build()
+        build()   # (no-op when the library is current AND was built on this host)
         _lib = C.CDLL(_SO)
         _lib.cfo_rti_step.restype = C.c_int
         _lib.cfo_closed_loop.restype = C.c_int

@@ -62,16 +62,19 @@ public:
     int N_STEPS, iter;
     PropellerSpeeds last_motvel;  // what would go to /crazyflie/acados_motvel
     Twist last_cmd_vel;           // what would go to /crazyflie/cmd_vel
+    bool fixed_u0;                // the reference's compile-time switch FIXED_U0 (acados_mpc.cpp:111), run-time here
 
     // acados_mpc.cpp:219-291
     explicit NMPC(const std::string& ref_traj) {
         const int status = acados_create();
         if (status) throw status;  // the reference exit(1)s (:227-230)
         for (int i = 0; i < NU; i++) acados_out.u0[i] = 0.0;
+        fixed_u0 = false;
         mq = 33e-3f;
         Ct = 3.25e-4f;
         uss = std::sqrt((mq * g0) / (4 * Ct));
         uss_row = uss;
+        for (int i = 0; i < NU; i++) acados_out.u1[i] = uss;   // (the reference leaves u1 uninitialised before the first solve)
         N_STEPS = ref_traj.empty() ? 0 : load_reference(ref_traj.c_str(), precomputed_traj);
         xq_des = 0; yq_des = 0; zq_des = 0.40;  // App. B4
         iter = 0;
@@ -162,6 +165,11 @@ public:
         for (int i = 0; i < NYN; i++) acados_in.yref_e[i] = yref_sign[N * NY + i];
         for (int ii = 0; ii < N; ii++) ocp_nlp_cost_model_set(nlp_config, nlp_dims, nlp_in, ii, "yref", acados_in.yref + ii * NY);
         ocp_nlp_cost_model_set(nlp_config, nlp_dims, nlp_in, N, "yref", acados_in.yref_e);
+        // --- set constraints (:605-608, FIXED_U0): stage 0 is pinned to the input in flight, u1 of the previous step
+        if (fixed_u0) {
+            ocp_nlp_constraints_model_set(nlp_config, nlp_dims, nlp_in, 0, "lbu", acados_out.u1);
+            ocp_nlp_constraints_model_set(nlp_config, nlp_dims, nlp_in, 0, "ubu", acados_out.u1);
+        }
         // --- call solver (:611-616)
         acados_status = acados_solve();
         acados_out.status = acados_status;

@@ -4,8 +4,10 @@
 // generated solver expects from its caller (acados_mpc.cpp:76-84) and drives NMPC::iteration().
 // The plant is the model itself, integrated by the sim solver (crazyflie_acados_sim_solve).
 //
-// usage: cf_nmpc_replay <regulation|tracking> <traj.txt|-> <steps> <x0.txt> <init 0|1> <out.csv> [uss]
+// usage: cf_nmpc_replay <regulation|tracking> <traj.txt|-> <steps> <x0.txt> <init 0|1> <out.csv> [uss [fixed_u0]]
 //   uss: steady-state propeller speed of the hold rows (default: the node's own float value)
+//   fixed_u0 = 1: the reference's FIXED_U0 variant (acados_mpc.cpp:605-608, 631-635): stage 0 pinned to the input in
+//   flight (lbu = ubu = u1 of the previous step), u1 is what goes to the motors
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +48,7 @@ int main(int argc, char** argv) {
 
     cf::NMPC nmpc(traj);
     if (argc > 7) nmpc.uss_row = std::atof(argv[7]);
+    if (argc > 8) { nmpc.fixed_u0 = std::atoi(argv[8]) != 0; for (double& v : nmpc.acados_out.u1) v = nmpc.uss_row; }
     if (nlp_out == nullptr || nlp_dims == nullptr || nlp_dims->N != cf::N) {
         std::fprintf(stderr, "acados_create() did not populate the caller's globals\n");
         return 3;
