@@ -22,7 +22,7 @@ SYMBOLS = [
     "cfnmpc_fleet_get_u", "cfnmpc_fleet_get_x", "cfnmpc_fleet_get_stats", "cfnmpc_fleet_set_box", "cfnmpc_fleet_get_cmd",
     "cfnmpc_multi_create", "cfnmpc_multi_free", "cfnmpc_multi_batch", "cfnmpc_multi_num_shards", "cfnmpc_multi_shard",
     "cfnmpc_multi_set_x0", "cfnmpc_multi_set_yref", "cfnmpc_multi_set_weights", "cfnmpc_multi_init_iterate", "cfnmpc_multi_solve",
-    "cfnmpc_multi_sync", "cfnmpc_multi_get_u", "cfnmpc_multi_get_x", "cfnmpc_multi_get_cmd", "cfnmpc_multi_get_stats",
+    "cfnmpc_multi_sync", "cfnmpc_multi_set_box", "cfnmpc_multi_set_box_stages", "cfnmpc_multi_get_u", "cfnmpc_multi_get_x", "cfnmpc_multi_get_cmd", "cfnmpc_multi_get_stats",
 ]
 
 
@@ -117,6 +117,8 @@ def lib():
     L.cfnmpc_multi_get_x.argtypes = [vp, i32, vp]
     L.cfnmpc_multi_get_cmd.argtypes = [vp, vp, vp]
     L.cfnmpc_multi_get_stats.argtypes = [vp, vp, vp, vp]
+    L.cfnmpc_multi_set_box.argtypes = [vp, dbl, dbl]
+    L.cfnmpc_multi_set_box_stages.argtypes = [vp, vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int or fn.restype is None or name in ("cfnmpc_version", "cfnmpc_workspace_bytes"):

@@ -44,6 +44,7 @@ struct cfnmpc_solver {
     int use_graph;
     hipStream_t cap;             // capture stream
     hipGraphExec_t gexec[2];
+    hipEvent_t glaunched[2];     // recorded behind the last launch of gexec[p]: waited for before that exec is destroyed
     bool gvalid[2];
     int parity;                  // which of the two argument sets the NEXT step uses
     double *lbs_keep, *ubs_keep; // per-stage boxes (cfnmpc_set_box_stages), allocated at the first call
@@ -79,6 +80,9 @@ constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the c
 constexpr size_t EV_PER_STEP = 7;
 constexpr int FORWARD_RG_BELOW = 8192;        // measured cross-over of the two forward sweeps
 
+// `on_device` argument: 0 host (synchronous), 2 host (enqueued only), anything else: device pointer
+inline bool is_host(int on_device) { return on_device == CFNMPC_ON_HOST || on_device == CFNMPC_ON_HOST_ASYNC; }
+
 template <typename T>
 int dev_alloc(cfnmpc_solver* s, T** p, size_t count) {
     void* q = nullptr;
@@ -96,14 +100,16 @@ int put_field(cfnmpc_solver* s, const double* src, int on_device, int S, int E, 
     const cfn::Params& P = s->P;
     const size_t n = (size_t)P.B * S * E;
     const double* dsrc = src;
-    if (!on_device) {
+    const bool host = is_host(on_device);
+    if (host) {
         if (n > s->stage_doubles) return CFNMPC_EINVAL;
         HIP_TRY(hipMemcpyAsync(s->stage_buf, src, n * sizeof(double), hipMemcpyHostToDevice, st));
         dsrc = s->stage_buf;
     }
     cfn::launch_put(P.B, S, E, perm13, dsrc, field, st);
     HIP_TRY(hipGetLastError());
-    if (!on_device) HIP_TRY(hipStreamSynchronize(st));  // staging buffer is reused
+    // the staging buffer is reused: wait, unless the caller orders the next use on the same stream itself
+    if (on_device == CFNMPC_ON_HOST) HIP_TRY(hipStreamSynchronize(st));
     return CFNMPC_OK;
 }
 
@@ -113,15 +119,16 @@ int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int pe
     const cfn::Params& P = s->P;
     const size_t n = (size_t)P.B * S * E;
     double* ddst = dst;
-    if (!on_device) {
+    const bool host = is_host(on_device);
+    if (host) {
         if (n > s->stage_doubles) return CFNMPC_EINVAL;
         ddst = s->stage_buf;
     }
     cfn::launch_get(P.B, S, E, perm13, s0, Stot, field, ddst, st);
     HIP_TRY(hipGetLastError());
-    if (!on_device) {
+    if (host) {
         HIP_TRY(hipMemcpyAsync(dst, ddst, n * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (on_device == CFNMPC_ON_HOST) HIP_TRY(hipStreamSynchronize(st));
     }
     return CFNMPC_OK;
 }
@@ -205,6 +212,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     s->use_graph = o.step_graph ? 1 : 0;
     s->cap = nullptr;
     s->gexec[0] = s->gexec[1] = nullptr;
+    s->glaunched[0] = s->glaunched[1] = nullptr;
     s->gvalid[0] = s->gvalid[1] = false;
     s->parity = 0;
     s->lbs_keep = s->ubs_keep = nullptr;
@@ -304,7 +312,10 @@ int cfnmpc_free(cfnmpc_solver* s) {
     if (!s) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
-    for (int p = 0; p < 2; p++) if (s->gexec[p]) (void)hipGraphExecDestroy(s->gexec[p]);
+    for (int p = 0; p < 2; p++) {
+        if (s->glaunched[p]) { (void)hipEventSynchronize(s->glaunched[p]); (void)hipEventDestroy(s->glaunched[p]); }
+        if (s->gexec[p]) (void)hipGraphExecDestroy(s->gexec[p]);
+    }
     if (s->cap) (void)hipStreamDestroy(s->cap);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_aux) (void)hipEventDestroy(s->ev_aux);
@@ -376,7 +387,7 @@ int cfnmpc_set_box_stages(cfnmpc_solver* s, const double* lb, const double* ub, 
     }
     if (P.cond_N2) return CFNMPC_EINVAL;   // the condensed path has no per-stage boxes
     const size_t n = (size_t)P.B * P.N * 4;
-    if (!on_device)
+    if (is_host(on_device))
         for (size_t i = 0; i < n; i++) if (!(lb[i] <= ub[i])) return CFNMPC_EINVAL;   // (NaN fails too; lb = ub pins the input)
     if (!s->lbs_keep) {
         const size_t cnt = ((size_t)P.NW + 1) * 4 * P.N * 4;
@@ -392,10 +403,10 @@ int cfnmpc_set_box_stages(cfnmpc_solver* s, const double* lb, const double* ub, 
     }
     // instance-major [inst][stage][4] is the caller's AoS order: plain copies
     hipStream_t st = (hipStream_t)stream;
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind kind = !is_host(on_device) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     HIP_TRY(hipMemcpyAsync(s->lbs_keep, lb, n * sizeof(double), kind, st));
     HIP_TRY(hipMemcpyAsync(s->ubs_keep, ub, n * sizeof(double), kind, st));
-    if (!on_device) HIP_TRY(hipStreamSynchronize(st));
+    if (on_device == CFNMPC_ON_HOST) HIP_TRY(hipStreamSynchronize(st));
     P.lbs = s->lbs_keep; P.ubs = s->ubs_keep;
     invalidate_graphs(s);
     return CFNMPC_OK;
@@ -406,7 +417,7 @@ int cfnmpc_get_cmd(cfnmpc_solver* s, double* cmd_vel, int* motvel, int on_device
     DeviceGuard dg(s);
     hipStream_t st = (hipStream_t)stream;
     const size_t B = s->P.B;
-    if (on_device) {
+    if (!is_host(on_device)) {
         cfn::launch_postproc(s->P, cmd_vel, motvel, st);
         HIP_TRY(hipGetLastError());
         return CFNMPC_OK;
@@ -419,7 +430,7 @@ int cfnmpc_get_cmd(cfnmpc_solver* s, double* cmd_vel, int* motvel, int on_device
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(cmd_vel, dc, B * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (motvel) HIP_TRY(hipMemcpyAsync(motvel, dm, B * 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (on_device == CFNMPC_ON_HOST) HIP_TRY(hipStreamSynchronize(st));
     return CFNMPC_OK;
 }
 
@@ -469,19 +480,38 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
             const int p = s->parity;
             if (!s->gvalid[p]) {
                 if (!s->cap) HIP_TRY(hipStreamCreateWithFlags(&s->cap, hipStreamNonBlocking));
-                if (s->gexec[p]) { (void)hipGraphExecDestroy(s->gexec[p]); s->gexec[p] = nullptr; }
+                if (!s->glaunched[p]) HIP_TRY(hipEventCreateWithFlags(&s->glaunched[p], hipEventDisableTiming));
+                if (s->gexec[p]) {   // a launch of the old exec may still be running (cfnmpc_solve is asynchronous)
+                    HIP_TRY(hipEventSynchronize(s->glaunched[p]));
+                    (void)hipGraphExecDestroy(s->gexec[p]);
+                    s->gexec[p] = nullptr;
+                }
                 hipGraph_t g = nullptr;
-                HIP_TRY(hipStreamBeginCapture(s->cap, hipStreamCaptureModeThreadLocal));
-                cfn::launch_linearise(s->P, s->chunks_all, s->cap);
-                if (s->P.cond_N2) cfn::launch_qp_cond(s->P, s->cap);
-                else cfn::launch_qp(s->P, s->cap);
-                HIP_TRY(hipStreamEndCapture(s->cap, &g));
-                const hipError_t ie = hipGraphInstantiate(&s->gexec[p], g, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(g);
-                if (ie != hipSuccess) return CFNMPC_EHIP;
+                bool ok = hipStreamBeginCapture(s->cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
+                if (ok) {
+                    cfn::launch_linearise(s->P, s->chunks_all, s->cap);
+                    if (s->P.cond_N2) cfn::launch_qp_cond(s->P, s->cap);
+                    else cfn::launch_qp(s->P, s->cap);
+                    ok = hipStreamEndCapture(s->cap, &g) == hipSuccess && g != nullptr;   // (always ends the capture)
+                }
+                if (ok) ok = hipGraphInstantiate(&s->gexec[p], g, nullptr, nullptr, 0) == hipSuccess;
+                if (g) (void)hipGraphDestroy(g);
+                if (!ok) {
+                    // capture / instantiation failed: drop the capture stream (it may be left in an invalid capture
+                    // state) and fall back to individual launches for good
+                    (void)hipGetLastError();
+                    (void)hipStreamDestroy(s->cap);
+                    s->cap = nullptr;
+                    s->gexec[p] = nullptr;
+                    s->use_graph = 0;
+                    std::fprintf(stderr, "cfnmpc: step_graph capture failed, launching the step's kernels individually\n");
+                    it--;          // redo this step on the plain path
+                    continue;
+                }
                 s->gvalid[p] = true;
             }
             HIP_TRY(hipGraphLaunch(s->gexec[p], st));
+            HIP_TRY(hipEventRecord(s->glaunched[p], st));
             std::swap(s->P.xit, s->P.xitn);
             std::swap(s->P.uit, s->P.uitn);
             s->parity ^= 1;
@@ -598,12 +628,12 @@ int cfnmpc_get_stats(cfnmpc_solver* s, int* status, int* qp_iter, double* res, i
     if (!s) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
     hipStream_t st = (hipStream_t)stream;
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const hipMemcpyKind kind = !is_host(on_device) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     const size_t B = s->P.B;
     if (status) HIP_TRY(hipMemcpyAsync(status, s->P.status, B * sizeof(int), kind, st));
     if (qp_iter) HIP_TRY(hipMemcpyAsync(qp_iter, s->P.iters, B * sizeof(int), kind, st));
     if (res) HIP_TRY(hipMemcpyAsync(res, s->P.res, B * sizeof(double), kind, st));
-    if (!on_device) HIP_TRY(hipStreamSynchronize(st));
+    if (on_device == CFNMPC_ON_HOST) HIP_TRY(hipStreamSynchronize(st));
     return CFNMPC_OK;
 }
 
@@ -611,20 +641,20 @@ int cfnmpc_sim(int batch, const double* x, const double* u, double T, int steps,
                void* stream) {
     if (batch <= 0 || !x || !u || !xn || steps < 1 || !(T > 0)) return CFNMPC_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    if (on_device) {
+    if (!is_host(on_device)) {
         cfn::launch_sim(batch, x, u, T, steps, xn, st);
         HIP_TRY(hipGetLastError());
         return CFNMPC_OK;
     }
     // host pointers: device scratch cached per device and grown on demand (the estimator calls this
     // at 66 Hz with batch 1, acados_estimator.cpp:589 -- no allocation per call); one caller at a time
-    static std::mutex mtx;
+    static std::mutex mtx[64];             // one caller at a time PER DEVICE (predictors on different GPUs run concurrently)
     static double* scratch[64] = {nullptr};
     static size_t cap[64] = {0};
-    std::lock_guard<std::mutex> lock(mtx);
     int devi = 0;
     HIP_TRY(hipGetDevice(&devi));
     if (devi < 0 || devi >= 64) return CFNMPC_EHIP;
+    std::lock_guard<std::mutex> lock(mtx[devi]);
     const size_t B = batch, need = B * 30;
     if (cap[devi] < need) {
         if (scratch[devi]) (void)hipFree(scratch[devi]);

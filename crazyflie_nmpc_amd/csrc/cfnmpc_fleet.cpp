@@ -111,6 +111,8 @@ int cfnmpc_fleet_create(cfnmpc_fleet** out, int batch, const int* N_per_instance
     *out = nullptr;
     cfnmpc_opts o;
     if (opts) o = *opts; else cfnmpc_default_opts(&o);
+    const int cond_N2_req = o.cond_N2;
+    if (cond_N2_req < 0) return CFNMPC_EINVAL;
     std::map<int, std::vector<int>> by_n;
     for (int i = 0; i < batch; i++) {
         if (N_per_instance[i] < 1) return CFNMPC_EINVAL;
@@ -130,6 +132,10 @@ int cfnmpc_fleet_create(cfnmpc_fleet** out, int batch, const int* N_per_instance
         b.count = (int)kv.second.size();
         b.idx = std::move(kv.second);
         o.N = b.N;
+        // partial condensing applies per bucket: a bucket with no more than cond_N2 stages has nothing to condense
+        // (cond_N2 >= N means "none", as for a single solver) instead of failing the whole fleet; a bucket whose
+        // blocks would exceed the supported length is still refused by cfnmpc_create
+        o.cond_N2 = (cond_N2_req > 0 && cond_N2_req < b.N) ? cond_N2_req : 0;
         rc = cfnmpc_create(&b.s, b.count, &o);
         if (rc != CFNMPC_OK) break;
         if (hipMalloc((void**)&b.d_idx, sizeof(int) * b.count) != hipSuccess ||

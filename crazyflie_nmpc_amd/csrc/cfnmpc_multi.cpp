@@ -92,17 +92,44 @@ int cfnmpc_multi_shard(const cfnmpc_multi* m, int shard, cfnmpc_solver** solver,
     return CFNMPC_OK;
 }
 
+// Host-array I/O of the whole fleet: every shard's transfer (+ layout kernel) is ENQUEUED on its own stream first
+// (CFNMPC_ON_HOST_ASYNC), then the shards are waited for -- the copies of different GPUs overlap instead of
+// running one after the other.
+static int sync_all(cfnmpc_multi* m) {
+    for (Shard& s : m->sh) {
+        Dev d(s.device);
+        if (hipStreamSynchronize(s.st) != hipSuccess) return CFNMPC_EHIP;
+    }
+    return CFNMPC_OK;
+}
+
 int cfnmpc_multi_set_x0(cfnmpc_multi* m, const double* x0) {
     if (!m || !x0) return CFNMPC_EINVAL;
-    for (Shard& s : m->sh) RC_TRY(cfnmpc_set_x0(s.s, x0 + (size_t)s.lo * 13, 0, s.st));
-    return CFNMPC_OK;
+    for (Shard& s : m->sh) RC_TRY(cfnmpc_set_x0(s.s, x0 + (size_t)s.lo * 13, CFNMPC_ON_HOST_ASYNC, s.st));
+    return sync_all(m);
 }
 
 int cfnmpc_multi_set_yref(cfnmpc_multi* m, const double* yref, const double* yref_e) {
     if (!m || !yref || !yref_e) return CFNMPC_EINVAL;
+    // (two arrays through ONE staging buffer per shard: the second put is ordered behind the first on the shard's stream)
     for (Shard& s : m->sh)
-        RC_TRY(cfnmpc_set_yref(s.s, yref + (size_t)s.lo * m->N * 17, yref_e + (size_t)s.lo * 13, 0, s.st));
+        RC_TRY(cfnmpc_set_yref(s.s, yref + (size_t)s.lo * m->N * 17, yref_e + (size_t)s.lo * 13, CFNMPC_ON_HOST_ASYNC, s.st));
+    return sync_all(m);
+}
+
+int cfnmpc_multi_set_box(cfnmpc_multi* m, double u_min, double u_max) {
+    if (!m) return CFNMPC_EINVAL;
+    for (Shard& s : m->sh) RC_TRY(cfnmpc_set_box(s.s, u_min, u_max));
     return CFNMPC_OK;
+}
+
+int cfnmpc_multi_set_box_stages(cfnmpc_multi* m, const double* lb, const double* ub) {
+    if (!m || ((lb == nullptr) != (ub == nullptr))) return CFNMPC_EINVAL;
+    for (Shard& s : m->sh) {
+        const size_t off = (size_t)s.lo * m->N * 4;
+        RC_TRY(cfnmpc_set_box_stages(s.s, lb ? lb + off : nullptr, ub ? ub + off : nullptr, CFNMPC_ON_HOST_ASYNC, s.st));
+    }
+    return sync_all(m);
 }
 
 int cfnmpc_multi_set_weights(cfnmpc_multi* m, const double* W, const double* WN) {
@@ -134,28 +161,29 @@ int cfnmpc_multi_sync(cfnmpc_multi* m) {
 
 int cfnmpc_multi_get_u(cfnmpc_multi* m, int stage, double* u) {
     if (!m || !u) return CFNMPC_EINVAL;
-    for (Shard& s : m->sh) RC_TRY(cfnmpc_get_u(s.s, stage, u + (size_t)s.lo * 4, 0, s.st));
-    return CFNMPC_OK;
+    for (Shard& s : m->sh) RC_TRY(cfnmpc_get_u(s.s, stage, u + (size_t)s.lo * 4, CFNMPC_ON_HOST_ASYNC, s.st));
+    return sync_all(m);
 }
 
 int cfnmpc_multi_get_x(cfnmpc_multi* m, int stage, double* x) {
     if (!m || !x) return CFNMPC_EINVAL;
-    for (Shard& s : m->sh) RC_TRY(cfnmpc_get_x(s.s, stage, x + (size_t)s.lo * 13, 0, s.st));
-    return CFNMPC_OK;
+    for (Shard& s : m->sh) RC_TRY(cfnmpc_get_x(s.s, stage, x + (size_t)s.lo * 13, CFNMPC_ON_HOST_ASYNC, s.st));
+    return sync_all(m);
 }
 
 int cfnmpc_multi_get_cmd(cfnmpc_multi* m, double* cmd_vel, int* motvel) {
     if (!m || !cmd_vel) return CFNMPC_EINVAL;
     for (Shard& s : m->sh)
-        RC_TRY(cfnmpc_get_cmd(s.s, cmd_vel + (size_t)s.lo * 4, motvel ? motvel + (size_t)s.lo * 4 : nullptr, 0, s.st));
-    return CFNMPC_OK;
+        RC_TRY(cfnmpc_get_cmd(s.s, cmd_vel + (size_t)s.lo * 4, motvel ? motvel + (size_t)s.lo * 4 : nullptr, CFNMPC_ON_HOST_ASYNC, s.st));
+    return sync_all(m);
 }
 
 int cfnmpc_multi_get_stats(cfnmpc_multi* m, int* status, int* qp_iter, double* res) {
     if (!m) return CFNMPC_EINVAL;
     for (Shard& s : m->sh)
-        RC_TRY(cfnmpc_get_stats(s.s, status ? status + s.lo : nullptr, qp_iter ? qp_iter + s.lo : nullptr, res ? res + s.lo : nullptr, 0, s.st));
-    return CFNMPC_OK;
+        RC_TRY(cfnmpc_get_stats(s.s, status ? status + s.lo : nullptr, qp_iter ? qp_iter + s.lo : nullptr, res ? res + s.lo : nullptr,
+                                CFNMPC_ON_HOST_ASYNC, s.st));
+    return sync_all(m);
 }
 
 }  // extern "C"

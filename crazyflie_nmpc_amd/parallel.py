@@ -103,6 +103,17 @@ class MultiGpuFleet:
         a, p = self._p(yref, (self.B, self.N, 17)); b, q = self._p(yref_e, (self.B, 13))
         self._check(self._L.cfnmpc_multi_set_yref(self._h, p, q), "cfnmpc_multi_set_yref")
 
+    def set_box(self, u_min, u_max):
+        assert self._L.cfnmpc_multi_set_box(self._h, float(u_min), float(u_max)) == 0
+
+    def set_box_stages(self, lb=None, ub=None):
+        """per-stage / per-input boxes [B][N][4] of the whole fleet; None, None: back to the scalar box"""
+        if lb is None and ub is None:
+            assert self._L.cfnmpc_multi_set_box_stages(self._h, None, None) == 0
+            return
+        a, p = self._p(lb, (self.B, self.N, 4)); b, q = self._p(ub, (self.B, self.N, 4))
+        assert self._L.cfnmpc_multi_set_box_stages(self._h, p, q) == 0
+
     def init_iterate(self, mode):
         self._check(self._L.cfnmpc_multi_init_iterate(self._h, int(mode)), "cfnmpc_multi_init_iterate")
 

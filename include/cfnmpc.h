@@ -13,8 +13,9 @@
  *       x  : [B][13]  = xq yq zq qw qx qy qz vbx vby vbz wx wy wz   (acados_mpc.cpp:117-131)
  *       u  : [B][4]   = w1..w4 [kRPM]                               (acados_mpc.cpp:133-138)
  *       yref   : [B][N][17], yref_e : [B][13]                        (acados_mpc.cpp:584-594)
- *   - `on_device` != 0: the pointer is device memory of the solver's GPU (no copy through the
- *     host); == 0: host memory, copied synchronously;
+ *   - `on_device`: 0 (CFNMPC_ON_HOST) host memory, copied synchronously; 2 (CFNMPC_ON_HOST_ASYNC) host memory,
+ *     transfer only enqueued on `stream`; any other value: device memory of the solver's GPU (no copy through
+ *     the host);
  *   - every call returns 0 on success, a negative CFNMPC_E* code otherwise; solver *status*
  *     per instance follows acados: 0 success, 2 max. iterations, 4 QP failure.
  *   - a solver (or fleet) lives on the HIP device that is current when it is created; later calls
@@ -37,6 +38,13 @@ extern "C" {
 #define CFNMPC_EINVAL (-1)  /* bad argument                              */
 #define CFNMPC_EHIP (-2)    /* HIP runtime error / no device             */
 #define CFNMPC_ENOMEM (-3)  /* device allocation failed                  */
+
+/* values of the `on_device` argument of the array setters / getters */
+#define CFNMPC_ON_HOST 0        /* host pointer; the call returns when the transfer is complete                       */
+#define CFNMPC_ON_DEVICE 1      /* device pointer of the solver's GPU (any non-zero value other than 2 historically)   */
+#define CFNMPC_ON_HOST_ASYNC 2  /* host pointer; the transfer is only ENQUEUED on `stream`: the caller keeps the array
+                                   alive and synchronises the stream before it reads (getters) or reuses (setters) it --
+                                   what cfnmpc_multi_* uses to overlap the I/O of its shards                            */
 
 #define CFNMPC_INIT_ACADOS 0 /* x_k = [0,0,0,1,0..], u_k = 0 (generate_c_code.py:135) */
 #define CFNMPC_INIT_HOVER 1  /* x_k = current x0, u_k = hover speed                                      */
@@ -307,6 +315,9 @@ int cfnmpc_multi_get_u(cfnmpc_multi *m, int stage, double *u /*[B][4] host*/);
 int cfnmpc_multi_get_x(cfnmpc_multi *m, int stage, double *x /*[B][13] host*/);
 int cfnmpc_multi_get_cmd(cfnmpc_multi *m, double *cmd_vel /*[B][4] host*/, int *motvel /*[B][4] host or NULL*/);
 int cfnmpc_multi_get_stats(cfnmpc_multi *m, int *status, int *qp_iter, double *res);
+/* cfnmpc_set_box / cfnmpc_set_box_stages (host arrays [B][N][4] of the whole fleet) for every shard */
+int cfnmpc_multi_set_box(cfnmpc_multi *m, double u_min, double u_max);
+int cfnmpc_multi_set_box_stages(cfnmpc_multi *m, const double *lb, const double *ub);
 
 const char *cfnmpc_version(void);
 

@@ -434,11 +434,20 @@ def test_acados_shim_setters_box_weights_and_predictor(oracle, cref):
         xr = np.repeat(x0[None, None, :], N + 1, 1).copy(); ur = np.full((1, N, 4), HOV)
         st_r, _, _, _ = cref.rti_step(opts, xr, ur, x0[None].copy(), yr[None].copy(), ye[None].copy(), nthreads=1)
         assert st_r[0] == 0 and np.abs(U - ur[0]).max() < 1e-8
-        # the reference's FIXED_U0 pattern: stage 0 pinned -> per-stage box -> solve refuses
+        # the reference's FIXED_U0 pattern (acados_mpc.cpp:605-608): stage 0 pinned -> per-stage box -> solved with
+        # u0 = the pin; an inverted box on one stage is refused without solving
         pin, ppin = dbl(U[1])
         assert L.ocp_nlp_constraints_model_set(None, None, None, 0, b"lbu", ppin) == 0
         assert L.ocp_nlp_constraints_model_set(None, None, None, 0, b"ubu", ppin) == 0
+        assert L.acados_solve() == 0
+        u0p = np.empty(4)
+        L.ocp_nlp_out_get(None, None, None, 0, b"u", u0p.ctypes.data_as(vp))
+        assert np.abs(u0p - pin).max() < 1e-12
+        assert L.ocp_nlp_constraints_model_set(None, None, None, 7, b"lbu", phi) == 0     # lb = 20 > ub = ... on stage 7
+        assert L.ocp_nlp_constraints_model_set(None, None, None, 7, b"ubu", plo) == 0
         assert L.acados_solve() == 1
+        assert L.ocp_nlp_constraints_model_set(None, None, None, 7, b"lbu", plo) == 0
+        assert L.ocp_nlp_constraints_model_set(None, None, None, 7, b"ubu", phi) == 0
         assert L.ocp_nlp_constraints_model_set(None, None, None, 0, b"lbu", plo) == 0
         assert L.ocp_nlp_constraints_model_set(None, None, None, 0, b"ubu", phi) == 0
         assert L.acados_solve() == 0
@@ -579,6 +588,20 @@ def test_multi_gpu_fleet_shards_match_single_solver(oracle):
         assert np.array_equal(c, c1) and np.array_equal(mv, mv1)
         x = sim(x, m.get_u(0), T=0.015, steps=1)
     assert seen > 0
+    # the boxes reach every shard: scalar, then per-stage with stage 0 pinned
+    lb = np.zeros((B, N, 4)); ub = np.full((B, N, 4), 22.0)
+    lb[:, 0] = ub[:, 0] = rng.uniform(13.0, 18.0, (B, 4))
+    for step in (0, 1):
+        for o in (m, s):
+            if step == 0:
+                o.set_box(1.0, 19.0)
+            else:
+                o.set_box_stages(lb, ub)
+            o.set_x0(x); o.solve(1)
+        m.sync()
+        assert np.array_equal(m.get_u(0), s.get_u(0)) and np.array_equal(m.get_x(4), s.get_x(4))
+        assert np.array_equal(m.stats()[1], s.stats()[1])
+    assert np.abs(m.get_u(0) - lb[:, 0]).max() < 1e-12
     if torch.cuda.device_count() > 1:       # a real second device, when the box has one
         m2 = parallel.MultiGpuFleet(B, [0, 1], opts)
         m2.set_x0(x); m2.set_yref(yref, yref_e); m2.init_iterate(INIT_HOVER); m2.solve(1); m2.sync()
@@ -651,6 +674,14 @@ def test_captured_step_graph_is_bit_identical(oracle, B):
         assert np.array_equal(xa, xb) and np.array_equal(ua, ub), t
         assert np.array_equal(a.stats()[1], b.stats()[1]) and (a.stats()[0] == 0).all()
         x = sim(x, ua[:, 0, :].copy(), T=0.015, steps=1)
+    # re-capture while launches of the old graphs may still be in flight (cfnmpc_solve is asynchronous: nothing
+    # waits between the solves and the setters here), per-stage boxes included
+    lb = np.zeros((B, 50, 4)); ub = np.full((B, 50, 4), 22.0); ub[:, 0:3, :] = 19.0
+    for s in (a, b):
+        s.set_x0(x); s.solve(3); s.set_box(1.0, 20.0); s.solve(2); s.set_box_stages(lb, ub); s.solve(2)
+        s.set_box_stages(None, None); s.solve(1)
+    (xa, ua), (xb, ub_) = a.get_iterate(), b.get_iterate()
+    assert np.array_equal(xa, xb) and np.array_equal(ua, ub_)
 
 
 @pytest.mark.parametrize("seed", list(range(12)))

@@ -138,6 +138,13 @@ def test_condensed_mixed_horizon_fleet(oracle):
     assert np.abs(u0c - u0p).max() < 1e-6 and np.abs(u1c - u1p).max() < 1e-6 and np.abs(x4c - x4p).max() < 1e-6
     with pytest.raises(CfnmpcError):
         MixedHorizonFleet(hz, cond_N2=5)          # N = 100 would need 20-stage blocks
+    # a bucket with no more stages than cond_N2 simply runs uncondensed (cond_N2 >= N means "none")
+    hz2 = rng.choice([8, 30, 50], size=B)
+    f = MixedHorizonFleet(hz2, cond_N2=10)
+    f.set_regulation(np.tile([0.0, 0.0, 0.4], (B, 1)), HOV)
+    f.set_x0(x0); f.init_iterate(INIT_HOVER); f.solve(1)
+    assert (f.stats()[0] == 0).all()
+    f.close()
 
 
 @pytest.mark.parametrize("seed", list(range(8)))
