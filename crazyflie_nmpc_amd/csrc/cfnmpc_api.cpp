@@ -78,6 +78,7 @@ struct DeviceGuard {
 
 constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the count
 constexpr size_t EV_PER_STEP = 7;
+constexpr int AS_COMMIT_BELOW = 16384;        // below: the active-set kernel leaves the roll-out to k_ascommit
 constexpr int FORWARD_RG_BELOW = 8192;        // measured cross-over of the two forward sweeps
 
 // `on_device` argument: 0 host (synchronous), 2 host (enqueued only), anything else: device pointer
@@ -247,12 +248,14 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.active_set = o.active_set ? 1 : 0;
     if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
     P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && batch < FORWARD_RG_BELOW) ? 1 : 0;
-    if (o.as_passes < -2 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
-    // internal: 0 = monolithic k_as, -1 = every solve in one launch on the compact z store + commit, p > 0 = p single-solve passes
-    P.as_passes = o.as_passes > 0 ? o.as_passes : (o.as_passes == -2 ? -1 : 0);
+    if (o.as_passes < -3 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
+    // internal: 0 = monolithic k_as, -1 = every solve in one launch on the compact z store + commit, -2 = the monolithic
+    // kernel's solves + commit, p > 0 = p single-solve passes
+    P.as_passes = o.as_passes > 0 ? o.as_passes : (o.as_passes == -2 ? -1 : (o.as_passes == -3 ? -2 : 0));
+    if (o.as_passes == 0 && batch < AS_COMMIT_BELOW) P.as_passes = -2;   // small fleets: solves + commit kernel (measured)
     if (const char* e = std::getenv("CFNMPC_AS_PASSES")) {   // development aid (internal encoding)
         const int v = std::atoi(e);
-        if (v >= -1 && v <= 12) P.as_passes = v;
+        if (v >= -2 && v <= 12) P.as_passes = v;
     }
     {   // pass launches: two wavefronts per SIMD of this device
         hipDeviceProp_t prop;

@@ -915,7 +915,8 @@ __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, 
 // on the way (stage-local: grad = R c + B'pi_{k+1} with B'pi_{k+1} = G dx_k + (B'PB) du_free + rho,
 // pi = P dx + p being the costate of the equality-constrained solve).  Returns the last stage of
 // the row in which an input changed its class (-1: none).
-template <bool SBOX = false>
+// ZDX: dx_{k+1} of the solve goes to P.czdx[slot] (read by the commit kernel when the roll-out is not done in-wave)
+template <bool SBOX = false, bool ZDX = false>
 __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, const int head) {
     // kg: lanes 0..3 hold K[a][0..12], lanes 4..7 hold G[a][0..12] -- ONE chain of 13 broadcast FMAs
     // forms the feedback (lanes 0..3) and G dx (lanes 4..7) together
@@ -970,6 +971,7 @@ __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, 
         dotbc<10, 3>(xn, cur.ar, x);
         SFOR(c, 0, 4, { xn += cur.br[c] * vr[c]; });
         x = xn;
+        if (ZDX && t.L < 13) gm(P.czdx)[((size_t)t.inst * (P.N + 1) + k + 1) * 13 + t.L] = x;
     };
     In b0, b1;
     load(0, b0);
@@ -1265,15 +1267,18 @@ __global__ __launch_bounds__(64) void k_cforward(Params P) {
 // (DESIGN.md section 5.4), so the choice is by batch size (cfnmpc_opts.forward_sweep).
 // The compaction ranks (per 64-instance group, as k_forward leaves them) come from k_rank.
 // ---------------------------------------------------------------------------------------------
-template <bool SBOX>
+template <bool SBOX, int DEPTH = 3>
 __device__ __forceinline__ void forward_rg_body(const Params& P) {
     const Lane t = lane_id(P);
     const int N = P.N;
     const double margin = P.ah_margin * (P.u_max - P.u_min);
     const int a = t.L & 3;
     const bool lo4 = t.L < 4;
-    // three rotating stage buffers: the loads of stage k+2 are issued before the arithmetic of stage k
-    // (small fleets run about one wave per SIMD: memory-level parallelism has to come from the wave itself)
+    // DEPTH rotating stage buffers: the loads of stage k + DEPTH - 1 are issued before the arithmetic of stage k
+    // (small fleets run about one wave per SIMD: memory-level parallelism has to come from the wave itself;
+    // measured on fleets of 1024 / 2048 / 4096 instances, one wave per SIMD: DEPTH 3: 40 / 51 / 106 us, 4: 42 / 55 / 108,
+    // 5: 47 / 60 / 112, 6: 50 / 62 / 114 -- the buffers beyond the VGPR file are parked in AGPRs, and the copy waits
+    // for the load; at 4096 instances the sweep moves 370 MB in 106 us = 3.5 TB/s: no longer a latency chain)
     struct In { FwdIn<true> f; double u, xb, lo, hi; };
     auto load = [&](int k, In& in) {
         load_fwd<true>(P, t, k, in.f);
@@ -1303,21 +1308,18 @@ __device__ __forceinline__ void forward_rg_body(const Params& P) {
         x = propagate<true>(t, cur.f, x, vr);
         xbcur = cur.xb;
     };
-    {
-        In b0, b1, b2;
-        load(0, b0);
-        load(imin(1, N - 1), b1);
+    {   // DEPTH rotating stage buffers (compile-time indices: registers)
+        In b[DEPTH];
+        SFOR(j, 0, DEPTH - 1, { load(imin(j, N - 1), b[j]); });
         int k = 0;
         while (k < N) {
-            load(imin(k + 2, N - 1), b2);
-            body(b0, k);
-            if (++k >= N) break;
-            load(imin(k + 2, N - 1), b0);
-            body(b1, k);
-            if (++k >= N) break;
-            load(imin(k + 2, N - 1), b1);
-            body(b2, k);
-            ++k;
+            SFOR(j, 0, DEPTH, {
+                if (k < N) {
+                    load(imin(k + DEPTH - 1, N - 1), b[(j + DEPTH - 1) % DEPTH]);
+                    body(b[j], k);
+                    ++k;
+                }
+            });
         }
     }
     st13(blk(P.xitn, t, N + 1, N, SZ_V13), t, xbcur + x);
@@ -1465,8 +1467,10 @@ __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave
 // P.active_set, then the interior point for the rows that did not settle); MODE 1: active-set
 // solves only -- rows that settle and pass the tail check are finished and flagged in P.done, the
 // others are left untouched for a MODE 2 launch; MODE 2: interior point for the rows without flag;
-// MODE 3: MODE 1 for the rows the level-synchronous pipeline's commit kernel flagged (P.done = 2: settled,
-// but a tail input left the box -- solve again over the longer head it wrote to P.head).
+// MODE 3: MODE 1 for the rows the commit kernel flagged (P.done = 2: settled, but a tail input left the box --
+// solve again over the longer head it wrote to P.head); MODE 4: the active-set solves of MODE 1 only -- no
+// roll-out: k_ascommit adds the delta to the start solve's candidate in a kernel of its own (deeper prefetch
+// than this kernel's registers allow: for small fleets, where the roll-out is a latency chain).
 template <int MODE, bool SBOX = false>
 __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64]) {
 #ifdef CFN_PROF
@@ -1479,7 +1483,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     if (blockIdx.x * 4 >= nipm) return;  // wave-uniform: no work for this wave
     bool has = slot < nipm;
     const int inst0 = has ? gm(P.ilist)[imin(slot, nipm - 1)] : 0;
-    constexpr bool AS_ONLY = MODE == 1 || MODE == 3;
+    constexpr bool AS_ONLY = MODE == 1 || MODE == 3 || MODE == 4;
+    constexpr bool NO_ROLL = MODE == 4;   // solves only: roll-out, tail check and publication are left to k_ascommit
     if (MODE == 2 || MODE == 3) {   // MODE 2: rows left for the interior point (done = 0); MODE 3: rows the
         has = has && gm(P.done)[inst0] == (MODE == 2 ? 0 : 2);   // commit kernel sent back for a longer head (done = 2)
         if (!__any(has)) return;
@@ -1579,7 +1584,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 as_ok = sweep_factor_as(Q, tc, head, chk, kstart, wt, sb) && as_ok;
                 PROF_T(2)
                 PROF_SOLVE(kstart + 1)
-                int jw = sweep_forward_as<SBOX>(Q, tc, head);
+                int jw = sweep_forward_as<SBOX, NO_ROLL>(Q, tc, head);
                 const bool changed = jw >= 0;
                 jw = max(jw, __shfl_xor(jw, 16));
                 jw = max(jw, __shfl_xor(jw, 32));
@@ -1588,6 +1593,14 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 const bool fine = row_min(as_ok ? 1.0 : 0.0) > 0.0;
                 if (infeasible && !as_done && !changed && fine) { as_done = true; as_iters = it; }
                 if (!__any(infeasible && !as_done && fine)) break;
+            }
+            if (NO_ROLL) {   // hand over to the commit kernel: settled flag, solve count, the head the solves covered
+                if (t.L == 0 && t.valid) {
+                    gm(P.asst)[tc.inst] = as_done ? 1 : 0;
+                    gm(P.head)[t.inst] = head;
+                    if (as_done) gm(P.iters)[t.inst] = as_iters;
+                }
+                return;
             }
             if (as_done) {   // accepted: inputs of the head = v0 + du
                 for (int e0 = t.L; e0 < head * 4; e0 += 64) {
@@ -1884,6 +1897,11 @@ __global__ __launch_bounds__(64) void k_ipm_rest_sbox(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
     qp_wave<2, true>(P, wtile, btile);
+}
+__global__ __launch_bounds__(64) void k_as_solves(Params P) {  // MODE 4: active-set solves, no roll-out
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<4>(P, wtile, btile);
 }
 __global__ __launch_bounds__(64) void k_as_retry(Params P) {  // MODE 3: rows the commit kernel sent back
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
@@ -2717,7 +2735,9 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         // launch loops over the remaining solves in-wave; as_passes < 0: every solve in one launch.  Then commit,
         // retries over a longer head, interior point for the rest.
         const int G = imax_h(1, imin_h(P.as_grid, P.NW));
-        if (P.as_passes < 0) {
+        if (P.as_passes == -2) {
+            hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, P);
+        } else if (P.as_passes < 0) {
             hipLaunchKernelGGL(k_asp_all, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
         } else {
             hipLaunchKernelGGL(k_asf_first, dim3(G), dim3(64), 0, st, P);

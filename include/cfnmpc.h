@@ -120,18 +120,21 @@ typedef struct cfnmpc_opts {
                             graph saves about half of that.                          */
     int as_passes;       /* QP, active_set = 1: how the active-set solves of the constrained instances are scheduled.
                             -1: one monolithic kernel on a wave-blocked compact copy (four instances per wavefront stay
-                            together until the slowest has settled, been rolled out and verified);
-                            -2: every solve in one launch as well, but on the instance-contiguous compact store
-                            (gathered by the first backward sweep itself, every row restarts at its own stage),
-                            followed by a COMMIT pass: new iterate = the start solve's candidate + delta -- head stages
-                            element-wise, the tail through the closed loop of the unconstrained feedback law, whose
-                            inputs are verified against the box there;
+                            together until the slowest has settled, been rolled out and verified in-wave);
+                            -3: the same kernel's solves only, followed by a COMMIT kernel: new iterate = the start
+                            solve's candidate + delta -- head stages element-wise from the solve's own du / dx, the tail
+                            through the closed loop of the unconstrained feedback law, whose inputs are verified against
+                            the box there (rows whose tail leaves it are solved again over a longer head);
+                            -2: every solve in one launch on the INSTANCE-CONTIGUOUS compact store (gathered by the first
+                            backward sweep itself, every row restarts at its own stage), then the commit kernel;
                             p = 1..12: LEVEL-SYNCHRONOUS -- p pairs of launches (factor, forward) of ONE solve each
                             over the instances that have not settled yet (work lists re-binned by remaining sweep
                             length between the launches, two wavefronts per SIMD), one launch for the remaining
-                            12 - p solves, then the commit pass;
-                            0 (default): by batch size.  Same solves and solve counts in every mode; results agree to
-                            rounding (the commit adds the delta to the candidate instead of recomputing the roll-out). */
+                            12 - p solves, then the commit kernel;
+                            0 (default): -3 below 16 384 instances (+1 .. 2.5 % there), -1 from there on -- measured on
+                            MI355X, DESIGN.md section 5.5: the phase is bound by the bytes of the home blocks and by
+                            the hardest instance's chain of solves, not by occupancy, and -2 / p > 0 are slower at
+                            every fleet size; kept as options.  Same solves in every mode; results agree to rounding. */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);

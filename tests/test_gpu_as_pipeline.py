@@ -17,7 +17,7 @@ def _fleet(oracle, B, scale, seed, N=50):
 
 
 @pytest.mark.parametrize("B,scale,passes,ah", [(200, 1.0, 1, 1), (200, 1.5, 3, 0), (200, 1.5, -2, 1), (1027, 2.0, 4, 1), (1027, 2.0, 4, 0),
-                                                (1027, 2.5, 12, 1), (1027, 2.5, -2, 0), (4099, 1.0, 2, 1), (4099, 3.0, 6, 1)])
+                                                (1027, 2.5, 12, 1), (1027, 2.5, -2, 0), (200, 1.5, -3, 1), (1027, 2.5, -3, 0), (4099, 1.0, -3, 1), (4099, 1.0, 2, 1), (4099, 3.0, 6, 1)])
 def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, passes, ah):
     from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
     from crazyflie_nmpc_amd.solver import INIT_HOVER
@@ -96,7 +96,7 @@ def test_level_synchronous_passes_match_cpu_restatement(oracle, cref):
 
 def test_pipeline_option_validation():
     from crazyflie_nmpc_amd import BatchSolver, default_opts
-    for bad in (-3, 13):
+    for bad in (-4, 13):
         with pytest.raises(Exception):
             BatchSolver(8, default_opts(as_passes=bad))
     BatchSolver(8, default_opts(as_passes=12)).close()
