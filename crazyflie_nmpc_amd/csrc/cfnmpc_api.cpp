@@ -732,6 +732,69 @@ float cfnmpc_debug_bench_sweep(cfnmpc_solver* s, int waves, int head, int reps, 
 int cfnmpc_debug_prof(unsigned long long* out, int reset) { (void)hipDeviceSynchronize(); cfn::debug_prof_read(out, reset); return 0; }
 #endif
 
+// EXPERIMENT: linearisation + backward factorisation of the start solve, either as the two
+// kernels of the product (chunk = 0) or alternating in chunks of `chunk` stages going backward -- linearise stages
+// [k, k + chunk), then factorise them (cost-to-go parked between the launches) -- so that the stage blocks might be
+// consumed from the L2 / MALL.  `reps` repetitions; *ms = average duration of one pair (HIP events).  Same numbers
+// either way (bitwise: the same arithmetic).  Leaves the solver ready for cfnmpc_solve.
+int cfnmpc_debug_chunked_pair(cfnmpc_solver* s, int chunk, int reps, double* ms, void* stream) {
+    if (!s || chunk < 0 || reps < 1 || !ms) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    hipStream_t st = (hipStream_t)stream;
+    cfn::Params P = s->P;
+    if (chunk > 0 && !P.Ppark) {
+        int rc = dev_alloc(s, &s->P.Ppark, ((size_t)P.NW + 1) * 13 * 64);
+        if (rc != CFNMPC_OK) return rc;
+        P.Ppark = s->P.Ppark;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; r++) {
+        if (chunk == 0) {
+            cfn::launch_linearise(P, s->chunks_all, st);
+            cfn::launch_factor_only(P, st);
+        } else {
+            for (int hi = P.N; hi > 0; hi -= chunk) {
+                const int lo = hi - chunk > 0 ? hi - chunk : 0;
+                cfn::Params Q = P;
+                Q.lin_k0 = lo; Q.lin_k1 = hi; Q.fk_lo = lo; Q.fk_hi = hi;
+                // the chunk's intervals spread over as many workgroups as the whole horizon gets normally
+                int c = s->chunks_all < hi - lo ? s->chunks_all : hi - lo;
+                cfn::launch_linearise(Q, c < 1 ? 1 : c, st);
+                cfn::launch_factor_chunk(Q, st);
+            }
+        }
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms = t / reps;
+    HIP_TRY(hipGetLastError());
+    return CFNMPC_OK;
+}
+
+// sums of the start solve's gains, feed-forward terms and Riccati checkpoints (host side, exact order: equal sums for
+// bitwise-equal arrays) -- checker of the chunked experiment
+int cfnmpc_debug_checksum(cfnmpc_solver* s, double* out3) {
+    if (!s || !out3) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    const cfn::Params& P = s->P;
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n[3] = {(size_t)P.NW * P.N * cfn::SZ_K, (size_t)P.NW * 4 * P.N * 4, (size_t)P.NW * cfn::N_CHK * cfn::SZ_P};
+    const double* src[3] = {P.KR, P.d, P.Pchk};
+    for (int f = 0; f < 3; f++) {
+        std::vector<double> h(n[f]);
+        HIP_TRY(hipMemcpy(h.data(), src[f], n[f] * 8, hipMemcpyDeviceToHost));
+        double acc = 0.0;
+        for (size_t i = 0; i < n[f]; i++) acc += h[i] * (double)(1 + (i % 7));
+        out3[f] = acc;
+    }
+    return CFNMPC_OK;
+}
+
 int cfnmpc_debug_linearise(cfnmpc_solver* s, void* stream) {
     if (!s) return CFNMPC_EINVAL;
     DeviceGuard dg(s);

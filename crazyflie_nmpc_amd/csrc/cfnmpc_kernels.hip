@@ -261,8 +261,10 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     }
     __syncthreads();
     const int inst = sinst[tid];
-    const int per = (N + gridDim.y - 1) / gridDim.y;
-    const int k0 = blockIdx.y * per, k1 = imin(N, k0 + per);
+    // (P.lin_k1 > 0: only the shooting intervals [lin_k0, lin_k1) -- the stage-chunked hand-over experiment)
+    const int ka = P.lin_k1 > 0 ? P.lin_k0 : 0, kb = P.lin_k1 > 0 ? P.lin_k1 : N;
+    const int per = (kb - ka + gridDim.y - 1) / gridDim.y;
+    const int k0 = ka + blockIdx.y * per, k1 = imin(kb, k0 + per);
     if (k0 >= k1) return;
 
     // address of element (local instance li, lane i) of a field with `stages` stages per block, SZ
@@ -639,11 +641,16 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
 // Backward factorisation over stages [0, head), next stage prefetched while the current one is
 // computed.  chk >= 0: start from a stored checkpoint of the unconstrained tail (P.Pchk, affine
 // row zero), else from the terminal cost.
+// klo / park / from_park: only the stages [klo, head) of the sweep, cost-to-go taken from / left in `park`
+// ([wave][13][64 lanes]) -- the stage-chunked hand-over experiment (k_factor_chunk); the defaults fold away.
 template <bool ABSOLUTE>
 __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, const int head, const int chk,
-                                             double* wt, double* sb) {
+                                             double* wt, double* sb, const int klo = 0, gdouble* park = nullptr,
+                                             const bool from_park = false) {
     double Pa[13];
-    if (ABSOLUTE || chk < 0) {
+    if (from_park) {
+        SFOR(j, 0, 13, { Pa[j] = park[j * 64 + threadIdx.x]; });
+    } else if (ABSOLUTE || chk < 0) {
         const double xN = ABSOLUTE ? ld13(blk(P.xit, t, P.N + 1, P.N, SZ_V13), t) : 0.0;
         const double yN = ABSOLUTE ? ld13(blk(P.yref_e, t, 1, 0, SZ_V13), t) : 0.0;
         double qv = 0.0;
@@ -680,17 +687,18 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
     StageIn<ABSOLUTE> bufA, bufB;
     load_stage<ABSOLUTE>(P, t, head - 1, wq, bufA);
     int k = head - 1;
-    while (k >= 0) {
+    while (k >= klo) {
         load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufB);
         ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufA, wq, is13, wt, sb) && ok;
         after(k);
         k--;
-        if (k < 0) break;
+        if (k < klo) break;
         load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufA);
         ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufB, wq, is13, wt, sb) && ok;
         after(k);
         k--;
     }
+    if (park) SFOR(j, 0, 13, { park[j * 64 + threadIdx.x] = Pa[j]; });
     return ok;
 }
 
@@ -870,12 +878,25 @@ __device__ __forceinline__ void load_stage_as(const Params& P, const Lane& t, co
 // of the unconstrained tail; kstart < head - 1 (later solves: no input of a stage > kstart changed
 // its class, so P_{kstart+1} and everything stored for the stages behind it are still valid): from
 // the cost-to-go this sweep saved at stage kstart + 1 during an earlier solve.
-constexpr int AS_PSAVE = 32;   // stages 1 .. AS_PSAVE-1 keep their cost-to-go (P.cPs)
+constexpr int AS_PSAVE = 32;   // saved cost-to-go matrices per compact row (P.cPs)
+// Every AS_PGRAN_MONO-th stage keeps its cost-to-go (182 of the ~470 doubles a factor stage moves): a later
+// factorisation restarts at the first such stage behind the last change, i.e. repeats up to AS_PGRAN_MONO - 1
+// stages more than necessary (identical arithmetic, identical results).  Measured (k_as, 1 / 2 / 4): 65 536 instances
+// 0.686 / 0.688 / 0.690 ms, 4096 instances 0.281 / 0.291 / 0.299 ms (the repeated stages lengthen the hardest wave's
+// chain), kicks x 2 7.54 / 7.22 / 7.09 ms (there the bytes count): 1 stays the default.
+#ifndef CFN_PGRAN_MONO
+#define CFN_PGRAN_MONO 1
+#endif
+constexpr int AS_PGRAN_MONO = CFN_PGRAN_MONO;
+__device__ __forceinline__ int as_restart_mono(int jm, int head) {   // jm = last stage whose class changed
+    const int jr = ((jm + AS_PGRAN_MONO) / AS_PGRAN_MONO) * AS_PGRAN_MONO - 1;
+    return (jr + 1 < head && (jr + 1) / AS_PGRAN_MONO < AS_PSAVE) ? jr : head - 1;
+}
 __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, const int head, const int chk,
                                                 const int kstart, double* wt, double* sb) {
     double Pa[13];
     if (kstart + 1 < head) {
-        const gdouble* ps = blk(P.cPs, t, AS_PSAVE, kstart + 1, SZ_PA) + t.q * 14 + imin(t.L, 13);
+        const gdouble* ps = blk(P.cPs, t, AS_PSAVE, (kstart + 1) / AS_PGRAN_MONO, SZ_PA) + t.q * 14 + imin(t.L, 13);
         SFOR(j, 0, 13, { Pa[j] = ps[j * 56]; });
     } else if (chk < 0) {
         SFOR(j, 0, 13, { Pa[j] = (t.L == j) ? P.WN[ext_of(j)] : 0.0; });
@@ -891,8 +912,8 @@ __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, 
     SFOR(j, 0, 13, { if (t.L == j) wq = P.W[ext_of(j)]; });
     const double is13 = t.L == 13 ? 1.0 : 0.0;
     auto keep = [&](int k) {
-        if (k > 0 && k < AS_PSAVE && t.L < 14) {
-            gdouble* ps = blk(P.cPs, t, AS_PSAVE, k, SZ_PA) + t.q * 14 + t.L;
+        if (k > 0 && k % AS_PGRAN_MONO == 0 && k / AS_PGRAN_MONO < AS_PSAVE && t.L < 14) {
+            gdouble* ps = blk(P.cPs, t, AS_PSAVE, k / AS_PGRAN_MONO, SZ_PA) + t.q * 14 + t.L;
             SFOR(j, 0, 13, { ps[j * 56] = Pa[j]; });
         }
     };
@@ -997,6 +1018,23 @@ __global__ __launch_bounds__(64, 2) void k_factor(Params P) {
     bool ok = sweep_factor<true>(P, t, P.N, -1, wtile[t.row], btile[t.row]);
     ok = row_min(ok ? 1.0 : 0.0) > 0.0;
     if (t.L == 0 && t.valid) gm(P.status)[t.inst] = ok ? 0 : 4;
+}
+
+// Stage-chunked hand-over experiment (cfnmpc_debug_chunked_pair): the stages [fk_lo, fk_hi) of
+// the start solve's backward sweep, cost-to-go parked in P.Ppark between the launches, so that k_linearise can produce
+// the same stages right before (its output then being read from the L2 / MALL instead of HBM -- or not: measured).
+__global__ __launch_bounds__(64, 2) void k_factor_chunk(Params P) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    const Lane t = lane_id(P);
+    const bool first = P.fk_hi >= P.N;
+    gdouble* park = gm(P.Ppark) + (size_t)blockIdx.x * 13 * 64;
+    bool ok = sweep_factor<true>(P, t, P.fk_hi, -1, wtile[t.row], btile[t.row], P.fk_lo, park, !first);
+    ok = row_min(ok ? 1.0 : 0.0) > 0.0;
+    if (t.L == 0 && t.valid) {
+        if (first) gm(P.status)[t.inst] = ok ? 0 : 4;
+        else if (!ok) gm(P.status)[t.inst] = 4;
+    }
 }
 
 // a row whose QP failed keeps its iterate: old -> new buffers (`keep` is row-uniform; rare)
@@ -1588,7 +1626,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 const bool changed = jw >= 0;
                 jw = max(jw, __shfl_xor(jw, 16));
                 jw = max(jw, __shfl_xor(jw, 32));
-                kstart = (jw >= 0 && jw + 1 < AS_PSAVE) ? jw : head - 1;   // restart point of the next factorisation (wave-uniform)
+                kstart = jw >= 0 ? as_restart_mono(jw, head) : head - 1;   // restart point of the next factorisation (wave-uniform)
                 PROF_T(3)
                 const bool fine = row_min(as_ok ? 1.0 : 0.0) > 0.0;
                 if (infeasible && !as_done && !changed && fine) { as_done = true; as_iters = it; }
@@ -2715,6 +2753,12 @@ void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev) {
     hipLaunchKernelGGL(k_compact, dim3(N_BIN), dim3(256), 0, st, P);
     hipLaunchKernelGGL(k_scatter, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
     if (ev) (void)hipEventRecord(ev[2], st);
+}
+void launch_factor_chunk(const Params& P, hipStream_t st) {
+    hipLaunchKernelGGL(k_factor_chunk, dim3(P.NW), dim3(64), 0, st, P);
+}
+void launch_factor_only(const Params& P, hipStream_t st) {
+    hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
 }
 void launch_cforward(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_cforward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);

@@ -104,6 +104,9 @@ struct Params {
     // per-stage, per-input input box (cfnmpc_set_box_stages; NULL: the scalar box u_min / u_max): instance-major
     // [inst][stage][4] like uit, and the compact copies of the constrained-QP kernels
     double *lbs, *ubs, *clbs, *cubs;
+    // stage-chunked hand-over experiment (cfnmpc_debug_chunked_pair): stage ranges of k_linearise / k_factor_chunk
+    int lin_k0, lin_k1, fk_lo, fk_hi;
+    double *Ppark;               // cost-to-go between the chunks, [wave][13][64]
     int forward_rg;              // 1: forward sweep of the start solve on the stored blocks (k_forward_rg; small fleets)
     int cond_N2, cond_M, cond_rem;
     double *cb;                  // condensed blocks, [instance][block][cb_size(w_max)] (layout: cfnmpc_pcond.hip)
@@ -135,6 +138,8 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr);  
 // interior point on the condensed QP for the constrained instances
 void launch_pcond(const Params& P, hipStream_t st);
 void launch_cfactor(const Params& P, hipStream_t st);
+void launch_factor_chunk(const Params& P, hipStream_t st);   // experiment: stages [P.fk_lo, P.fk_hi) of the start solve
+void launch_factor_only(const Params& P, hipStream_t st);
 void launch_cforward(const Params& P, hipStream_t st);   // (in cfnmpc_kernels.hip: k_forward with condensed gains)
 void launch_cipm(const Params& P, hipStream_t st);
 void launch_qp_cond(const Params& P, hipStream_t st);    // = the four above

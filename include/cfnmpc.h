@@ -252,6 +252,10 @@ int cfnmpc_estimate(int batch, const double *meas, double *filt, const double *u
  * order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13] (host pointers). */
 int cfnmpc_debug_get_linearisation(cfnmpc_solver *s, double *A, double *Bm, double *b);
 /* runs only the linearisation kernel */
+/* experiment: linearisation + start-solve factorisation alternating in chunks of `chunk` stages
+ * (0: the product's two kernels); *ms = average duration of one pair over `reps` repetitions */
+int cfnmpc_debug_chunked_pair(cfnmpc_solver *s, int chunk, int reps, double *ms, void *stream);
+int cfnmpc_debug_checksum(cfnmpc_solver *s, double *out3);
 int cfnmpc_debug_linearise(cfnmpc_solver *s, void *stream);
 /* partial condensing (cond_N2 > 0): runs linearisation + pcond and copies condensed block `block`
  * of every instance to the host as dense arrays in the reference's state order, with
