@@ -177,6 +177,8 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->cond_N2 = 0;
     o->step_graph = 0;
     o->as_passes = 0;
+    o->ipm_clip_viol = 2.0;
+    o->ipm_clip_margin = 0.05;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
@@ -187,7 +189,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
         !(o.ah_margin >= 0.0 && o.ah_margin < 0.5) || o.ah_extra < 0) return CFNMPC_EINVAL;
     // QP parameters that would otherwise only show up as NaN / status 4 at run time
     if (!(o.tol > 0.0) || !(o.tau > 0.0 && o.tau < 1.0) || !(o.thr0 > 0.0) || !(o.lam0_min > 0.0) ||
-        !(o.mu0_scale >= 0.0)) return CFNMPC_EINVAL;
+        !(o.mu0_scale >= 0.0) || !(o.ipm_clip_viol >= 0.0) || !(o.ipm_clip_margin > 0.0 && o.ipm_clip_margin < 0.5)) return CFNMPC_EINVAL;
     if (!weights_ok(o.W, o.WN)) return CFNMPC_EINVAL;
     // partial condensing: cond_N2 blocks of at most COND_MMAX stages; not combined with the overlapped preparation
     if (o.cond_N2 < 0 || o.cond_N2 > o.N) return CFNMPC_EINVAL;
@@ -242,6 +244,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     for (int i = 0; i < 13; i++) P.WN[i] = o.WN[i];
     P.u_min = o.u_min; P.u_max = o.u_max; P.tol = o.tol; P.tau = o.tau; P.thr0 = o.thr0;
     P.lam0_min = o.lam0_min; P.mu0_scale = o.mu0_scale; P.max_iter = o.max_iter;
+    P.clip_viol = o.ipm_clip_viol; P.clip_margin = o.ipm_clip_margin;
     P.active_horizon = o.active_horizon ? 1 : 0;
     P.ah_margin = o.ah_margin;
     P.ah_extra = o.ah_extra;
@@ -287,7 +290,8 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(ilist, NW * 4); ALLOC(nipm, 64);
     ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * 32); ALLOC(rank, NW * 4); ALLOC(done, NW * 4);
     ALLOC(ascnt, 32); ALLOC(askst, NW * 4); ALLOC(asst, NW * 4); ALLOC(asok, NW * 4);
-    if (P.as_passes != 0) { ALLOC(aslist, (size_t)3 * 7 * NW * 4); ALLOC(czdx, NW * 4 * (N + 1) * 13); }
+    ALLOC(czdx, NW * 4 * (N + 1) * 13);
+    if (P.as_passes != 0) ALLOC(aslist, (size_t)3 * 7 * NW * 4);
     if (cond_N2) ALLOC(cb, NW * 4 * (size_t)cond_N2 * cfn::cb_size(cfn::cond_mmax(P)));
     if (s->overlap) {
         if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->AR2, NW * N * cfn::SZ_A);

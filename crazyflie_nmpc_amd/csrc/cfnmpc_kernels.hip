@@ -1492,6 +1492,103 @@ __device__ __forceinline__ void elem_pass(const Params& P, size_t base, int n, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Clipped start of the interior point (cfnmpc_opts.ipm_clip_viol; riccati_ipm in oracle/cfnmpc_oracle.py): gradient
+// of the condensed head QP at v0 + dv, g = H dv, by one forward sweep (dx_k -> P.czdx of the compact slot) and one
+// backward costate sweep (pi_head = P_head dx_head; g_k = R dv_k + B'pi_{k+1}; pi_k = Q dx_k + A'pi_{k+1}, the costate
+// carried replicated as in sweep_resolve).  dv is read from Q.dva, g is left in Q.g.  Rows with dv = 0 get g = 0.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sweep_clip_gradient(const Params& P, const Params& Q, const Lane& tc, const int head, const int chk) {
+    const int N = P.N;
+    const int a = tc.L & 3;
+    const bool lo4 = tc.L < 4;
+    gdouble* zx = gm(P.czdx) + (size_t)tc.inst * (N + 1) * 13;
+    {   // forward: dx_0 = 0, dx_{k+1} = A dx_k + B dv_k
+        struct In { double ar[10], br[4], dv; };
+        auto load = [&](int k, In& in) {
+            ld_ar(blk(Q.AR, tc, N, k, SZ_A), tc, in.ar);
+            ld_rows4(blk(Q.BR, tc, N, k, SZ_B), tc, in.br);
+            in.dv = gm(Q.dva)[i4(Q, tc, k, a)];
+        };
+        double x = 0.0;
+        if (tc.L < 13) zx[tc.L] = 0.0;
+        auto body = [&](const In& cur, int k) {
+            const double dvl = lo4 ? cur.dv : 0.0;
+            double vr[4];
+            SFOR(c, 0, 4, { vr[c] = bc<c>(dvl); });
+            double xn = tc.L < 3 ? x : 0.0;
+            dotbc<10, 3>(xn, cur.ar, x);
+            SFOR(c, 0, 4, { xn += cur.br[c] * vr[c]; });
+            x = xn;
+            if (tc.L < 13) zx[(size_t)(k + 1) * 13 + tc.L] = x;
+        };
+        In b0, b1;
+        load(0, b0);
+        int k = 0;
+        while (k < head) {
+            load(imin(k + 1, head - 1), b1);
+            body(b0, k);
+            if (++k >= head) break;
+            load(imin(k + 1, head - 1), b0);
+            body(b1, k);
+            ++k;
+        }
+    }
+    // backward: costate replicated in every lane
+    double p[13];
+    {
+        double xh[13];
+        SFOR(j, 0, 13, { xh[j] = zx[(size_t)head * 13 + j]; });
+        if (chk < 0) {
+            SFOR(j, 0, 13, { p[j] = P.WN[ext_of(j)] * xh[j]; });
+        } else {   // pi = P_head dx_head, P_head row-distributed (lane i holds row i)
+            const gdouble* pc = gm(Q.Pchk) + ((size_t)tc.wave * N_CHK + chk) * SZ_P;
+            double pd = 0.0;
+            SFOR(j, 0, 13, { pd += pc[(j * 4 + tc.q) * 13 + imin(tc.L, 12)] * xh[j]; });
+            SFOR(j, 0, 13, { p[j] = bc<j>(pd); });
+        }
+    }
+    struct Bk { double ar[10], br[4], dv, xk[13]; };
+    auto loadb = [&](int k, Bk& in) {
+        ld_ar_raw(blk(Q.AR, tc, N, k, SZ_A), tc, in.ar);
+        ld_rows4_raw(blk(Q.BR, tc, N, k, SZ_B), tc, in.br);
+        in.dv = gm(Q.dva)[i4(Q, tc, k, a)];
+        SFOR(j, 0, 13, { in.xk[j] = zx[(size_t)k * 13 + j]; });
+    };
+    auto bodyb = [&](const Bk& cur, int k) {
+        const double(&ar)[10] = cur.ar;
+        const double(&br)[4] = cur.br;
+        double glane = lo4 ? tc.wu * cur.dv : 0.0;
+        double rr[4];
+        SFOR(c, 0, 4, { rr[c] = bc<c>(glane); });
+        dot2bc<13, 0>(rr[0], rr[1], p, br[0], br[1]);
+        dot2bc<13, 0>(rr[2], rr[3], p, br[2], br[3]);
+        const double gv = a == 0 ? rr[0] : (a == 1 ? rr[1] : (a == 2 ? rr[2] : rr[3]));
+        if (lo4) gm(Q.g)[i4(Q, tc, k, a)] = gv;
+        double pn[13];
+        SFOR(j, 0, 3, { pn[j] = p[j]; });
+        SFOR(j, 3, 13, { pn[j] = 0.0; });
+        dot2bc<6, 0>(pn[3], pn[4], p, ar[0], ar[1]);
+        dotbc<6, 0>(pn[5], p, ar[2]);
+        dot2bc<10, 0>(pn[6], pn[7], p, ar[3], ar[4]);
+        dot2bc<10, 0>(pn[8], pn[9], p, ar[5], ar[6]);
+        dot2bc<13, 0>(pn[10], pn[11], p, ar[7], ar[8]);
+        dotbc<13, 0>(pn[12], p, ar[9]);
+        SFOR(j, 0, 13, { p[j] = pn[j] + P.W[ext_of(j)] * cur.xk[j]; });
+    };
+    Bk c0, c1;
+    loadb(head - 1, c0);
+    int k = head - 1;
+    while (k >= 0) {
+        loadb(imax(k - 1, 0), c1);
+        bodyb(c0, k);
+        if (--k < 0) break;
+        loadb(imax(k - 1, 0), c0);
+        bodyb(c1, k);
+        --k;
+    }
+}
+
 // -DCFN_PROF (development builds only, tools/ipm_phase_prof.py): phase timers of the longest wave
 #ifdef CFN_PROF
 __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave, [8] its total, [9] sum of totals, [10] waves, [16..23] phase sums
@@ -1654,11 +1751,13 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         }
         if (as_done) { R.status = 0; R.iters = as_iters; }
         if constexpr (!AS_ONLY) {
-        if (infeasible && !as_done) {
-            // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
-            const double mu0 = fmax(P.mu0_scale * viol, P.lam0_min);
-            double mu = 0.0, res = 0.0;
-            for (int e0 = t.L; e0 < head * 4; e0 += 64) {
+        const bool start_ipm = infeasible && !as_done;
+        // Clipped start for rows whose unconstrained minimiser lies more than clip_viol box widths outside the box
+        // (vehicles far from their iterate's trajectory: the infeasible start below spends 30 - 60 iterations there)
+        const bool clip = start_ipm && P.clip_viol > 0.0 && viol > P.clip_viol * (P.u_max - P.u_min);
+        double mu0c = P.lam0_min;
+        if (__any(clip)) {
+            for (int e0 = t.L; e0 < head * 4; e0 += 64) {   // v <- clipped into the box, dv -> Q.dva (0 for the other rows)
                 double uk[4], vv[4], blo[4], bhi[4];
                 SFOR(j, 0, 4, {
                     const size_t idx = cbase + imin(e0 + 16 * j, head * 4 - 1);
@@ -1669,12 +1768,54 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 SFOR(j, 0, 4, {
                     const int e = e0 + 16 * j;
                     if (e < head * 4) {
+                        const double lb = blo[j] - uk[j], ub = bhi[j] - uk[j], w = ub - lb;
+                        const double vc = fmin(fmax(vv[j], lb + P.clip_margin * w), ub - P.clip_margin * w);
+                        gm(Q.dva)[cbase + e] = clip ? vc - vv[j] : 0.0;
+                        if (clip) gm(Q.v)[cbase + e] = vc;
+                    }
+                });
+            }
+            sweep_clip_gradient(P, Q, tc, head, chk);
+            double acc = 0.0;
+            for (int e0 = t.L; e0 < head * 4; e0 += 64) {
+                double uk[4], vv[4], gg[4], blo[4], bhi[4];
+                SFOR(j, 0, 4, {
+                    const size_t idx = cbase + imin(e0 + 16 * j, head * 4 - 1);
+                    uk[j] = gm(Q.uit)[idx];
+                    vv[j] = gm(Q.v)[idx];
+                    gg[j] = gm(Q.g)[idx];
+                    box_at<SBOX>(Q, idx, blo[j], bhi[j]);
+                });
+                SFOR(j, 0, 4, {
+                    if (e0 + 16 * j < head * 4) acc += fabs(gg[j]) * fmin(vv[j] - (blo[j] - uk[j]), (bhi[j] - uk[j]) - vv[j]);
+                });
+            }
+            mu0c = fmax(P.lam0_min, P.mu0_scale * row_sum(acc) / (4.0 * head));
+        }
+        if (start_ipm) {
+            // ---- shift slacks / multipliers positive; residuals of the start; first R^, g
+            const double mu0 = clip ? mu0c : fmax(P.mu0_scale * viol, P.lam0_min);
+            double mu = 0.0, res = 0.0;
+            for (int e0 = t.L; e0 < head * 4; e0 += 64) {
+                double uk[4], vv[4], gg[4], blo[4], bhi[4];
+                SFOR(j, 0, 4, {
+                    const size_t idx = cbase + imin(e0 + 16 * j, head * 4 - 1);
+                    uk[j] = gm(Q.uit)[idx];
+                    vv[j] = gm(Q.v)[idx];
+                    gg[j] = clip ? gm(Q.g)[idx] : 0.0;
+                    box_at<SBOX>(Q, idx, blo[j], bhi[j]);
+                });
+                SFOR(j, 0, 4, {
+                    const int e = e0 + 16 * j;
+                    if (e < head * 4) {
                         const size_t idx = cbase + e;
                         const double v = vv[j];
                         const double lb = blo[j] - uk[j], ub = bhi[j] - uk[j];
-                        const double tl = fmax(v - lb, P.thr0), tu = fmax(ub - v, P.thr0);
+                        // clipped rows: exact slacks, multipliers absorb the gradient; others: slacks floored at thr0
+                        const double tl = clip ? v - lb : fmax(v - lb, P.thr0), tu = clip ? ub - v : fmax(ub - v, P.thr0);
                         const double itl = rcp_nr(tl), itu = rcp_nr(tu);
-                        const double ll = mu0 * itl, lu = mu0 * itu, rg = -ll + lu;
+                        const double ll = fmax(gg[j], 0.0) + mu0 * itl, lu = fmax(-gg[j], 0.0) + mu0 * itu;
+                        const double rg = gg[j] - ll + lu;
                         gm(Q.tl)[idx] = tl; gm(Q.tu)[idx] = tu; gm(Q.ll)[idx] = ll; gm(Q.lu)[idx] = lu; gm(Q.rg)[idx] = rg;
                         const double rl = v - lb - tl, ru = ub - v - tu;
                         const double Dl = ll * itl, Du = lu * itu;

@@ -135,6 +135,15 @@ typedef struct cfnmpc_opts {
                             MI355X, DESIGN.md section 5.5: the phase is bound by the bytes of the home blocks and by
                             the hardest instance's chain of solves, not by occupancy, and -2 / p > 0 are slower at
                             every fleet size; kept as options.  Same solves in every mode; results agree to rounding. */
+    double ipm_clip_viol; /* QP, interior point: CLIPPED START when the unconstrained minimiser leaves the box by more than
+                            this many box widths (2.0; 0 = never).  From such a point (vehicles far from their iterate's
+                            trajectory: ~100 kRPM outside and more) the infeasible start spends 30 - 60 iterations at tiny
+                            step lengths; instead the iteration starts inside the box -- inputs clipped to a margin of
+                            ipm_clip_margin of the width -- with multipliers that absorb the gradient of the condensed QP
+                            there (one forward + one backward costate sweep) and a complementarity floor scaled by it.
+                            Captured fall-back QPs: 63 -> 22 iterations, none at the cap any more; ordinary QPs are
+                            better served by the infeasible start (5 against 8 iterations), hence the threshold.          */
+    double ipm_clip_margin; /* ... 0.05                                                                                   */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);

@@ -423,7 +423,7 @@ def kkt_residual(qp: StageQP, dx, du, lam_l, lam_u):
 # Stage-wise Riccati interior point (the algorithm the HIP kernels implement; plays the role
 # of HPIPM d_ocp_qp_ipm_solve selected at generate_c_code.py:140).  See DESIGN.md section 4.
 # ----------------------------------------------------------------------------------------
-IPM_DEFAULTS = dict(tol=1e-8, max_iter=50, tau=0.995, thr0=1.0, lam0_min=1e-2, mu0_scale=0.1)
+IPM_DEFAULTS = dict(tol=1e-8, max_iter=50, tau=0.995, thr0=1.0, lam0_min=1e-2, mu0_scale=0.1, clip_viol=2.0, clip_margin=0.05)
 
 
 def _riccati_factor(qp, Rhat, rhat, absolute=True):
@@ -509,13 +509,40 @@ def riccati_ipm(qp: StageQP, **opts):
     if np.all(v >= lb) and np.all(v <= ub):
         z = np.zeros_like(v)
         return dict(dx=xs, du=v, lam_l=z, lam_u=z.copy(), **info)
-    tl = np.maximum(v - lb, o["thr0"])
-    tu = np.maximum(ub - v, o["thr0"])
     viol = max(float(np.maximum(lb - v, 0).max()), float(np.maximum(v - ub, 0).max()))
-    mu0 = max(o["lam0_min"], o["mu0_scale"] * viol)
-    ll = mu0 / tl
-    lu = mu0 / tu
-    rg = -ll + lu  # R v + r + B'pi = 0 at the unconstrained start
+    if o["clip_viol"] > 0 and viol > o["clip_viol"] * float((ub - lb).max()):
+        # CLIPPED START (cfnmpc_opts.ipm_clip_viol): the unconstrained minimiser lies more than clip_viol box
+        # widths outside the box (vehicles far from the iterate's trajectory: ~100 kRPM and more).  From there the
+        # infeasible start above spends 30-60 iterations at tiny step lengths; instead the iteration starts INSIDE the
+        # box -- v clipped to a margin of clip_margin of the width -- with multipliers that absorb the gradient of the
+        # condensed QP there, g = H (v - v0) (one forward sweep for dx, one backward costate sweep), and a complementarity
+        # floor scaled by it: lam_l = max(g, 0) + mu0 / t_l, lam_u = max(-g, 0) + mu0 / t_u, mu0 = max(lam0_min, mu0_scale *
+        # mean(|g| min(t_l, t_u))); slacks are exact (rho = 0), r_g = g - lam_l + lam_u.  (numpy: 63 -> 22 iterations on
+        # captured fall-back QPs, none at the cap; 5 -> 8 on ordinary ones -- hence the threshold.)
+        w = ub - lb
+        vc = np.clip(v, lb + o["clip_margin"] * w, ub - o["clip_margin"] * w)
+        dvc = vc - v
+        dxs = np.zeros((N + 1, NX))
+        for k in range(N):
+            dxs[k + 1] = qp.A[k] @ dxs[k] + qp.B[k] @ dvc[k]
+        pi = qp.QNd * dxs[N]
+        g = np.zeros_like(v)
+        for k in range(N - 1, -1, -1):
+            g[k] = Rd[k] * dvc[k] + qp.B[k].T @ pi
+            pi = qp.Qd * dxs[k] + qp.A[k].T @ pi
+        v = vc
+        tl, tu = v - lb, ub - v
+        mu0 = max(o["lam0_min"], o["mu0_scale"] * float((np.abs(g) * np.minimum(tl, tu)).sum()) / (NU * N))
+        ll = np.maximum(g, 0.0) + mu0 / tl
+        lu = np.maximum(-g, 0.0) + mu0 / tu
+        rg = g - ll + lu
+    else:
+        tl = np.maximum(v - lb, o["thr0"])
+        tu = np.maximum(ub - v, o["thr0"])
+        mu0 = max(o["lam0_min"], o["mu0_scale"] * viol)
+        ll = mu0 / tl
+        lu = mu0 / tu
+        rg = -ll + lu  # R v + r + B'pi = 0 at the unconstrained start
     status = 2
     it = 0
     while True:

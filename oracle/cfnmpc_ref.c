@@ -49,6 +49,9 @@ typedef struct {
     int active_set;   /* 1: primal-dual active-set solves first (the engine's cfnmpc_opts.active_set;
                          numpy twin pdas_dense), interior point only if the set does not settle in
                          12 solves; 0 (default): interior point only                              */
+    double clip_viol; /* IPM: clipped start when the unconstrained minimiser leaves the box by more than this
+                         many box widths (cfnmpc_opts.ipm_clip_viol; 0: never)                   */
+    double clip_margin; /* ... clipped to this fraction of the box width inside the bounds       */
 } cfo_opts;
 
 void cfo_default_opts(cfo_opts *o) {
@@ -67,6 +70,8 @@ void cfo_default_opts(cfo_opts *o) {
     o->lam0_min = 1e-2;
     o->mu0_scale = 0.1;
     o->active_set = 0;
+    o->clip_viol = 2.0;
+    o->clip_margin = 0.05;
 }
 
 /* ---------------------------------------------------------------- dynamics */
@@ -515,7 +520,57 @@ static int ipm_solve(qp_t *qp, const cfo_opts *o, int *iters_out, double *res_ou
             return 0;
         }
     }
-    {
+    if (o->clip_viol > 0.0 && viol > o->clip_viol * (o->u_max - o->u_min)) {
+        /* clipped start (riccati_ipm in cfnmpc_oracle.py): v inside the box, multipliers absorb the gradient
+         * g = H (v - v0) of the condensed QP there (forward sweep for dx, backward costate sweep) */
+        double *dxs = (double *)calloc((size_t)(N + 1) * NX, sizeof(double));
+        double *dvc = dva, *gr = qp->dvc;   /* (both free before the first iteration) */
+        for (int i = 0; i < n; i++) {
+            const double w = qp->ub[i] - qp->lb[i];
+            const double lo = qp->lb[i] + o->clip_margin * w, hi = qp->ub[i] - o->clip_margin * w;
+            const double vc = v[i] < lo ? lo : (v[i] > hi ? hi : v[i]);
+            dvc[i] = vc - v[i];
+            v[i] = vc;
+        }
+        for (int k = 0; k < N; k++) {
+            const double *A = qp->A + (size_t)k * 169, *B = qp->B + (size_t)k * 52;
+            for (int i = 0; i < NX; i++) {
+                double s = 0.0;
+                for (int l = 0; l < NX; l++) s += A[i * NX + l] * dxs[(size_t)k * NX + l];
+                for (int a = 0; a < NU; a++) s += B[i * NU + a] * dvc[k * 4 + a];
+                dxs[(size_t)(k + 1) * NX + i] = s;
+            }
+        }
+        double pi[NX], pn[NX];
+        for (int i = 0; i < NX; i++) pi[i] = qp->QNd[i] * dxs[(size_t)N * NX + i];
+        for (int k = N - 1; k >= 0; k--) {
+            const double *A = qp->A + (size_t)k * 169, *B = qp->B + (size_t)k * 52;
+            for (int a = 0; a < NU; a++) {
+                double s = qp->Rd[a] * dvc[k * 4 + a];
+                for (int l = 0; l < NX; l++) s += B[l * NU + a] * pi[l];
+                gr[k * 4 + a] = s;
+            }
+            for (int i = 0; i < NX; i++) {
+                double s = qp->Qd[i] * dxs[(size_t)k * NX + i];
+                for (int l = 0; l < NX; l++) s += A[l * NX + i] * pi[l];
+                pn[i] = s;
+            }
+            memcpy(pi, pn, sizeof pi);
+        }
+        double acc = 0.0;
+        for (int i = 0; i < n; i++) {
+            tl[i] = v[i] - qp->lb[i];
+            tu[i] = qp->ub[i] - v[i];
+            acc += fabs(gr[i]) * fmin(tl[i], tu[i]);
+        }
+        const double mu0 = fmax(o->lam0_min, o->mu0_scale * acc / n);
+        for (int i = 0; i < n; i++) {
+            ll[i] = fmax(gr[i], 0.0) + mu0 / tl[i];
+            lu[i] = fmax(-gr[i], 0.0) + mu0 / tu[i];
+            rg[i] = gr[i] - ll[i] + lu[i];
+        }
+        free(dxs);
+    } else {
         const double mu0 = fmax(o->mu0_scale * viol, o->lam0_min);
         for (int i = 0; i < n; i++) {
             tl[i] = fmax(v[i] - qp->lb[i], o->thr0);

@@ -19,7 +19,8 @@ class Opts(C.Structure):
     _fields_ = [("N", C.c_int), ("dt", C.c_double), ("W", C.c_double * NY), ("WN", C.c_double * NX),
                 ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
-                ("lam0_min", C.c_double), ("mu0_scale", C.c_double), ("active_set", C.c_int)]
+                ("lam0_min", C.c_double), ("mu0_scale", C.c_double), ("active_set", C.c_int),
+                ("clip_viol", C.c_double), ("clip_margin", C.c_double)]
 
 
 def _host_tag():
