@@ -179,6 +179,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->as_passes = 0;
     o->ipm_clip_viol = 2.0;
     o->ipm_clip_margin = 0.05;
+    o->as_skip_viol = 4.0;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
@@ -189,7 +190,8 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
         !(o.ah_margin >= 0.0 && o.ah_margin < 0.5) || o.ah_extra < 0) return CFNMPC_EINVAL;
     // QP parameters that would otherwise only show up as NaN / status 4 at run time
     if (!(o.tol > 0.0) || !(o.tau > 0.0 && o.tau < 1.0) || !(o.thr0 > 0.0) || !(o.lam0_min > 0.0) ||
-        !(o.mu0_scale >= 0.0) || !(o.ipm_clip_viol >= 0.0) || !(o.ipm_clip_margin > 0.0 && o.ipm_clip_margin < 0.5)) return CFNMPC_EINVAL;
+        !(o.mu0_scale >= 0.0) || !(o.ipm_clip_viol >= 0.0) || !(o.ipm_clip_margin > 0.0 && o.ipm_clip_margin < 0.5) ||
+        !(o.as_skip_viol >= 0.0)) return CFNMPC_EINVAL;
     if (!weights_ok(o.W, o.WN)) return CFNMPC_EINVAL;
     // partial condensing: cond_N2 blocks of at most COND_MMAX stages; not combined with the overlapped preparation
     if (o.cond_N2 < 0 || o.cond_N2 > o.N) return CFNMPC_EINVAL;
@@ -244,7 +246,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     for (int i = 0; i < 13; i++) P.WN[i] = o.WN[i];
     P.u_min = o.u_min; P.u_max = o.u_max; P.tol = o.tol; P.tau = o.tau; P.thr0 = o.thr0;
     P.lam0_min = o.lam0_min; P.mu0_scale = o.mu0_scale; P.max_iter = o.max_iter;
-    P.clip_viol = o.ipm_clip_viol; P.clip_margin = o.ipm_clip_margin;
+    P.clip_viol = o.ipm_clip_viol; P.clip_margin = o.ipm_clip_margin; P.as_skip_viol = o.as_skip_viol;
     P.active_horizon = o.active_horizon ? 1 : 0;
     P.ah_margin = o.ah_margin;
     P.ah_extra = o.ah_extra;
@@ -873,6 +875,14 @@ int cfnmpc_debug_get_condensed(cfnmpc_solver* s, int block, double* H, double* D
             for (int c = 0; c < w; c++) Di[cfn::ext_of(r) * w + zext(c)] = d[r * w + c];
     }
     if (m_out) *m_out = m;
+    return CFNMPC_OK;
+}
+
+int cfnmpc_debug_get_viol(cfnmpc_solver* s, double* viol) {   // largest bound violation of the unconstrained minimiser (0: feasible)
+    if (!s || !viol) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(viol, s->P.viol, (size_t)s->P.B * sizeof(double), hipMemcpyDeviceToHost));
     return CFNMPC_OK;
 }
 

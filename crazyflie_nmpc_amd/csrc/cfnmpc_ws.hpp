@@ -57,6 +57,7 @@ struct Params {
     double W[17], WN[13];  // external order, as in cfnmpc_opts
     double u_min, u_max, tol, tau, thr0, lam0_min, mu0_scale;
     double clip_viol, clip_margin;   // interior point: clipped start (cfnmpc_opts.ipm_clip_viol / ipm_clip_margin)
+    double as_skip_viol;             // rows beyond this many box widths skip the active-set iteration (cfnmpc_opts.as_skip_viol)
     int max_iter;
     int active_horizon;  // 1: interior-point sweeps only over the stages that can saturate
     double ah_margin;    // ... 'tight' = within this fraction of the box width of a bound

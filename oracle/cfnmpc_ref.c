@@ -52,6 +52,8 @@ typedef struct {
     double clip_viol; /* IPM: clipped start when the unconstrained minimiser leaves the box by more than this
                          many box widths (cfnmpc_opts.ipm_clip_viol; 0: never)                   */
     double clip_margin; /* ... clipped to this fraction of the box width inside the bounds       */
+    double as_skip_viol; /* active_set: beyond this many box widths the active-set solves are skipped
+                         (cfnmpc_opts.as_skip_viol; 0: never)                                    */
 } cfo_opts;
 
 void cfo_default_opts(cfo_opts *o) {
@@ -72,6 +74,7 @@ void cfo_default_opts(cfo_opts *o) {
     o->active_set = 0;
     o->clip_viol = 2.0;
     o->clip_margin = 0.05;
+    o->as_skip_viol = 4.0;
 }
 
 /* ---------------------------------------------------------------- dynamics */
@@ -510,7 +513,7 @@ static int ipm_solve(qp_t *qp, const cfo_opts *o, int *iters_out, double *res_ou
     }
     if (feas) { free(Rhat); *res_out = 0.0; return 0; }
     if (!(viol == viol)) { free(Rhat); *res_out = NAN; return 4; }
-    if (o->active_set) {
+    if (o->active_set && !(o->as_skip_viol > 0.0 && viol > o->as_skip_viol * (o->u_max - o->u_min))) {
         const int solves = as_solve(qp);
         if (solves > 0) {
             rollout(qp, v, qp->x);

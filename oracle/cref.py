@@ -20,7 +20,7 @@ class Opts(C.Structure):
                 ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
                 ("lam0_min", C.c_double), ("mu0_scale", C.c_double), ("active_set", C.c_int),
-                ("clip_viol", C.c_double), ("clip_margin", C.c_double)]
+                ("clip_viol", C.c_double), ("clip_margin", C.c_double), ("as_skip_viol", C.c_double)]
 
 
 def _host_tag():

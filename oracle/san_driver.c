@@ -9,7 +9,7 @@ typedef struct {
     int N; double dt; double W[17]; double WN[13]; double u_min, u_max; double tol; int max_iter;
     double tau, thr0, lam0_min, mu0_scale;
     int active_set;
-    double clip_viol, clip_margin;
+    double clip_viol, clip_margin, as_skip_viol;
 } cfo_opts;
 void cfo_default_opts(cfo_opts *o);
 int cfo_rti_step(const cfo_opts *o, int B, double *x_it, double *u_it, const double *x0, const double *yref,
