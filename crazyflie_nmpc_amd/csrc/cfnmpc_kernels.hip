@@ -879,24 +879,23 @@ __device__ __forceinline__ void load_stage_as(const Params& P, const Lane& t, co
 // its class, so P_{kstart+1} and everything stored for the stages behind it are still valid): from
 // the cost-to-go this sweep saved at stage kstart + 1 during an earlier solve.
 constexpr int AS_PSAVE = 32;   // saved cost-to-go matrices per compact row (P.cPs)
-// Every AS_PGRAN_MONO-th stage keeps its cost-to-go (182 of the ~470 doubles a factor stage moves): a later
-// factorisation restarts at the first such stage behind the last change, i.e. repeats up to AS_PGRAN_MONO - 1
-// stages more than necessary (identical arithmetic, identical results).  Measured (k_as, 1 / 2 / 4): 65 536 instances
-// 0.686 / 0.688 / 0.690 ms, 4096 instances 0.281 / 0.291 / 0.299 ms (the repeated stages lengthen the hardest wave's
-// chain), kicks x 2 7.54 / 7.22 / 7.09 ms (there the bytes count): 1 stays the default.
-#ifndef CFN_PGRAN_MONO
-#define CFN_PGRAN_MONO 1
-#endif
-constexpr int AS_PGRAN_MONO = CFN_PGRAN_MONO;
-__device__ __forceinline__ int as_restart_mono(int jm, int head) {   // jm = last stage whose class changed
-    const int jr = ((jm + AS_PGRAN_MONO) / AS_PGRAN_MONO) * AS_PGRAN_MONO - 1;
-    return (jr + 1 < head && (jr + 1) / AS_PGRAN_MONO < AS_PSAVE) ? jr : head - 1;
+// The cost-to-go is kept at every stage for short heads and at every 4th stage for heads of 24 stages and more
+// (pg_shift = 0 / 2; it is 182 of the ~470 doubles a factor stage moves): a later factorisation restarts at the first
+// kept stage behind the last change, i.e. repeats up to three stages (identical arithmetic, identical results).
+// Measured with one granularity for all heads (k_as, every stage / 2nd / 4th): 65 536 instances 0.686 / 0.688 / 0.690 ms,
+// 4096 instances 0.281 / 0.291 / 0.299 ms (the repeated stages lengthen the hardest wave's chain of short heads), kicks x 2
+// 7.54 / 7.22 / 7.09 ms (long heads: the bytes count) -- hence by head.
+__device__ __forceinline__ int as_pg_shift(int head) { return head >= 24 ? 2 : 0; }
+__device__ __forceinline__ int as_restart_mono(int jm, int head, int sh) {   // jm = last stage whose class changed
+    const int jr = (((jm >> sh) + 1) << sh) - 1;
+    return (jr + 1 < head && ((jr + 1) >> sh) < AS_PSAVE) ? jr : head - 1;
 }
 __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, const int head, const int chk,
                                                 const int kstart, double* wt, double* sb) {
+    const int sh = as_pg_shift(head);
     double Pa[13];
     if (kstart + 1 < head) {
-        const gdouble* ps = blk(P.cPs, t, AS_PSAVE, (kstart + 1) / AS_PGRAN_MONO, SZ_PA) + t.q * 14 + imin(t.L, 13);
+        const gdouble* ps = blk(P.cPs, t, AS_PSAVE, (kstart + 1) >> sh, SZ_PA) + t.q * 14 + imin(t.L, 13);
         SFOR(j, 0, 13, { Pa[j] = ps[j * 56]; });
     } else if (chk < 0) {
         SFOR(j, 0, 13, { Pa[j] = (t.L == j) ? P.WN[ext_of(j)] : 0.0; });
@@ -912,8 +911,8 @@ __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, 
     SFOR(j, 0, 13, { if (t.L == j) wq = P.W[ext_of(j)]; });
     const double is13 = t.L == 13 ? 1.0 : 0.0;
     auto keep = [&](int k) {
-        if (k > 0 && k % AS_PGRAN_MONO == 0 && k / AS_PGRAN_MONO < AS_PSAVE && t.L < 14) {
-            gdouble* ps = blk(P.cPs, t, AS_PSAVE, k / AS_PGRAN_MONO, SZ_PA) + t.q * 14 + t.L;
+        if (k > 0 && (k & ((1 << sh) - 1)) == 0 && (k >> sh) < AS_PSAVE && t.L < 14) {
+            gdouble* ps = blk(P.cPs, t, AS_PSAVE, k >> sh, SZ_PA) + t.q * 14 + t.L;
             SFOR(j, 0, 13, { ps[j * 56] = Pa[j]; });
         }
     };
@@ -1727,7 +1726,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 const bool changed = jw >= 0;
                 jw = max(jw, __shfl_xor(jw, 16));
                 jw = max(jw, __shfl_xor(jw, 32));
-                kstart = jw >= 0 ? as_restart_mono(jw, head) : head - 1;   // restart point of the next factorisation (wave-uniform)
+                kstart = jw >= 0 ? as_restart_mono(jw, head, as_pg_shift(head)) : head - 1;   // restart point of the next factorisation (wave-uniform)
                 PROF_T(3)
                 const bool fine = row_min(as_ok ? 1.0 : 0.0) > 0.0;
                 if (try_as && !as_done && !changed && fine) { as_done = true; as_iters = it; }
