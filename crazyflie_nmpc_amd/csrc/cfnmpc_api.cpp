@@ -289,7 +289,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(cS, NW * N * cfn::SZ_S4); ALLOC(crho, NW * 4 * N * 4);
     ALLOC(cPs, NW * 32 * cfn::SZ_PA);
     ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4); ALLOC(viol, NW * 4);
-    ALLOC(ilist, NW * 4); ALLOC(nipm, 64);
+    ALLOC(ilist, NW * 4); ALLOC(ilist2, NW * 4); ALLOC(nipm, 64);
     ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * 32); ALLOC(rank, NW * 4); ALLOC(done, NW * 4);
     ALLOC(ascnt, 32); ALLOC(askst, NW * 4); ALLOC(asst, NW * 4); ALLOC(asok, NW * 4);
     ALLOC(czdx, NW * 4 * (N + 1) * 13);

@@ -1605,18 +1605,22 @@ __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave
 // solve again over the longer head it wrote to P.head); MODE 4: the active-set solves of MODE 1 only -- no
 // roll-out: k_ascommit adds the delta to the start solve's candidate in a kernel of its own (deeper prefetch
 // than this kernel's registers allow: for small fleets, where the roll-out is a latency chain).
+// vb: index of the compact block (group of four list slots) this call works on -- the workgroup index, or the running
+// index of a grid-stride loop (k_ipm_rest: a small fixed grid instead of one mostly idle workgroup per four instances)
 template <int MODE, bool SBOX = false>
-__device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64]) {
+__device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64], const int vb) {
 #ifdef CFN_PROF
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
     const unsigned long long pstart = plast;
     unsigned long long psolves = 0, pstages = 0;
 #endif
-    const int nipm = gm(P.nipm)[0];
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (blockIdx.x * 4 >= nipm) return;  // wave-uniform: no work for this wave
+    // MODE 2 works on the list k_ipm_list compacted from the rows the active-set kernels left (P.ilist2, count in
+    // P.nipm[40]): four fall-back rows per wave instead of one row in each of the waves they were scattered over
+    const int nipm = gm(P.nipm)[MODE == 2 ? 40 : 0];
+    const int slot = vb * 4 + (threadIdx.x >> 4);
+    if (vb * 4 >= nipm) return;  // wave-uniform: no work for this wave
     bool has = slot < nipm;
-    const int inst0 = has ? gm(P.ilist)[imin(slot, nipm - 1)] : 0;
+    const int inst0 = has ? gm(MODE == 2 ? P.ilist2 : P.ilist)[imin(slot, nipm - 1)] : 0;
     constexpr bool AS_ONLY = MODE == 1 || MODE == 3 || MODE == 4;
     constexpr bool NO_ROLL = MODE == 4;   // solves only: roll-out, tail check and publication are left to k_ascommit
     if (MODE == 2 || MODE == 3) {   // MODE 2: rows left for the interior point (done = 0); MODE 3: rows the
@@ -1643,7 +1647,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     // unrelated instances, which would waste 3/4 of every cache line on every sweep of every
     // iteration.  The start solve's gains / inputs in P stay untouched until the QP is accepted.
     Lane tc = t;
-    tc.wave = blockIdx.x; tc.q = t.row; tc.inst = blockIdx.x * 4 + t.row;
+    tc.wave = vb; tc.q = t.row; tc.inst = vb * 4 + t.row;
     Params Q = P;
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
     Q.lbs = P.clbs; Q.ubs = P.cubs;
@@ -2035,7 +2039,10 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     keep_row(P, t, !AS_ONLY && infeasible && !(accepted && R.status != 4));
 #ifdef CFN_PROF
     PROF_T(7)
-    if (threadIdx.x == 0) {
+#ifndef CFN_PROF_MODE
+#define CFN_PROF_MODE MODE
+#endif
+    if (threadIdx.x == 0 && MODE == CFN_PROF_MODE) {   // (-DCFN_PROF_MODE=2: only the interior-point kernel reports)
         const unsigned long long tot = plast - pstart;
         const unsigned long long old = atomicMax(&g_prof[8], tot);
         if (tot > old) {   // (racy, development aid) phases of the longest wave
@@ -2049,46 +2056,94 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     }
 #endif
 }
+// List of the rows the active-set kernels left for the interior point (P.done = 0), in slot order (deterministic):
+// one workgroup, every thread scans a run of consecutive slots.
+__global__ __launch_bounds__(1024) void k_ipm_list(Params P) {
+    __shared__ int cnt[1024];
+    const int tid = threadIdx.x;
+    const int n = gm(P.nipm)[0];
+    const int chunk = (n + 1023) / 1024;
+    const int lo = tid * chunk, hi = min(lo + chunk, n);
+    int c = 0;
+    // batches of eight slots with all loads of a batch in flight together (two memory round trips per batch, not 16);
+    // the usual list (a few thousand rows) is one batch, kept in registers for the second pass
+    int inst[8];
+    bool left[8];
+    for (int i0 = lo; i0 < hi; i0 += 8) {
+        SFOR(j, 0, 8, { inst[j] = gm(P.ilist)[imin(i0 + j, n - 1)]; });
+        SFOR(j, 0, 8, { left[j] = (i0 + j < hi) && gm(P.done)[inst[j]] == 0; });
+        SFOR(j, 0, 8, { c += left[j] ? 1 : 0; });
+    }
+    // inclusive scan over the 1024 threads: shuffles inside the wave, the 16 wave totals through LDS (two barriers)
+    int incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if ((tid & 63) >= off) incl += v;
+    }
+    if ((tid & 63) == 63) cnt[tid >> 6] = incl;
+    __syncthreads();
+    if (tid < 64) {
+        int w = tid < 16 ? cnt[tid] : 0;
+        for (int off = 1; off < 16; off <<= 1) {
+            const int v = __shfl_up(w, off);
+            if (tid >= off) w += v;
+        }
+        if (tid < 16) cnt[16 + tid] = w;     // inclusive totals of the waves
+    }
+    __syncthreads();
+    const int wbase = (tid >> 6) > 0 ? cnt[16 + (tid >> 6) - 1] : 0;
+    if (tid == 1023) gm(P.nipm)[40] = wbase + incl;
+    int pos = wbase + incl - c;
+    if (c == 0) return;
+    if (chunk <= 8) {
+        SFOR(j, 0, 8, { if (left[j]) gm(P.ilist2)[pos++] = inst[j]; });
+    } else {
+        for (int i = lo; i < hi; i++) {
+            const int in = gm(P.ilist)[i];
+            if (gm(P.done)[in] == 0) gm(P.ilist2)[pos++] = in;
+        }
+    }
+}
 __global__ __launch_bounds__(64) void k_ipm(Params P) {       // MODE 0: used when active_set = 0
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<0>(P, wtile, btile);
+    qp_wave<0>(P, wtile, btile, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void k_as(Params P) {        // active-set solves
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<1>(P, wtile, btile);
+    qp_wave<1>(P, wtile, btile, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void k_ipm_rest(Params P) {  // interior point for what k_as left
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<2>(P, wtile, btile);
+    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[40]; vb += gridDim.x) qp_wave<2>(P, wtile, btile, vb);
 }
 // the same three for per-stage input boxes (cfnmpc_set_box_stages)
 __global__ __launch_bounds__(64) void k_ipm_sbox(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<0, true>(P, wtile, btile);
+    qp_wave<0, true>(P, wtile, btile, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void k_as_sbox(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<1, true>(P, wtile, btile);
+    qp_wave<1, true>(P, wtile, btile, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void k_ipm_rest_sbox(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<2, true>(P, wtile, btile);
+    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[40]; vb += gridDim.x) qp_wave<2, true>(P, wtile, btile, vb);
 }
 __global__ __launch_bounds__(64) void k_as_solves(Params P) {  // MODE 4: active-set solves, no roll-out
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<4>(P, wtile, btile);
+    qp_wave<4>(P, wtile, btile, blockIdx.x);
 }
 __global__ __launch_bounds__(64) void k_as_retry(Params P) {  // MODE 3: rows the commit kernel sent back
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<3>(P, wtile, btile);
+    qp_wave<3>(P, wtile, btile, blockIdx.x);
 }
 
 // =============================================================================================
@@ -2920,7 +2975,8 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         if (P.active_set) {
             hipLaunchKernelGGL(k_as_sbox, dim3(P.NW), dim3(64), 0, st, P);
             if (ev) (void)hipEventRecord(ev[0], st);
-            hipLaunchKernelGGL(k_ipm_rest_sbox, dim3(P.NW), dim3(64), 0, st, P);
+            hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
+            hipLaunchKernelGGL(k_ipm_rest_sbox, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
         } else {
             if (ev) (void)hipEventRecord(ev[0], st);
             hipLaunchKernelGGL(k_ipm_sbox, dim3(P.NW), dim3(64), 0, st, P);
@@ -2948,11 +3004,13 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         else hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_as_retry, dim3(P.NW), dim3(64), 0, st, P);
         if (ev) (void)hipEventRecord(ev[0], st);
-        hipLaunchKernelGGL(k_ipm_rest, dim3(P.NW), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
+        hipLaunchKernelGGL(k_ipm_rest, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
     } else if (P.active_set) {
         hipLaunchKernelGGL(k_as, dim3(P.NW), dim3(64), 0, st, P);
         if (ev) (void)hipEventRecord(ev[0], st);
-        hipLaunchKernelGGL(k_ipm_rest, dim3(P.NW), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
+        hipLaunchKernelGGL(k_ipm_rest, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
     } else {
         if (ev) (void)hipEventRecord(ev[0], st);
         hipLaunchKernelGGL(k_ipm, dim3(P.NW), dim3(64), 0, st, P);

@@ -90,6 +90,7 @@ struct Params {
     int active_set;  // 1: try the primal-dual active-set solve before the interior-point iteration
     int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
     double *res, *viol;          // per instance
+    int *ilist2;                 // the rows of ilist the active-set kernels left for the interior point (k_ipm_list; count in nipm[40])
     int *ilist;                  // compacted list of the instances that need the interior-point method
     int *nipm;                   // [0] its length, [1 + bin] instances per compaction bin
     int *blkcnt;                 // per 64-instance group of k_forward: instances per compaction bin [group][32]

@@ -13,12 +13,13 @@ L = _lib.lib()
 B, N, KP = int(os.environ.get("BATCH", "65536")), 50, 20
 rng = np.random.default_rng(20200103)
 dev = torch.device("cuda", 0)
-x = torch.from_numpy(sample_hover_x0(rng, B)).to(dev)
+SC = float(os.environ.get("KICK", "1"))
+x = torch.from_numpy(sample_hover_x0(rng, B, scale=SC)).to(dev)
 row = regulation_row()
 s = BatchSolver(B, default_opts(overlap_linearise=int(os.environ.get("OV", "0"))))
 s.set_x0(x); s.set_yref(torch.from_numpy(np.tile(row, (B, N, 1))).to(dev), torch.from_numpy(np.tile(row[:13], (B, 1))).to(dev)); s.init_iterate(INIT_HOVER)
 cohort = B // KP
-kicks = torch.from_numpy(sample_hover_x0(rng, cohort * KP).reshape(KP, cohort, 13)).to(dev)
+kicks = torch.from_numpy(sample_hover_x0(rng, cohort * KP, scale=SC).reshape(KP, cohort, 13)).to(dev)
 u0 = torch.empty((B, 4), dtype=torch.float64, device=dev); xn = torch.empty_like(x)
 names = ["gather", "elem(init,loop ctl)", "factor", "forward x2", "elem passes", "resolve", "rollout", "publish+commit"]
 out = (C.c_ulonglong * 32)()
