@@ -1977,12 +1977,23 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             // is not accepted is overwritten again (retry / interior-point launch) or restored (keep_row)
             double xbcur = ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t), xbnxt;
             double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - xbcur;
+            // head stages take A, B from the wave's compact copy (the home blocks are interleaved with the three wave-mates:
+            // three quarters of every cache line foreign) and need no gain; b and the tail come from the home blocks
+            auto load_roll = [&](int k, FwdIn<true>& in) {
+                if (k < head) {
+                    ld_ar(blk(Q.AR, tc, N, k, SZ_A), tc, in.ar);
+                    ld_rows4(blk(Q.BR, tc, N, k, SZ_B), tc, in.br);
+                    in.bv = ld13(blk(P.b, t, N, k, SZ_V13), t);
+                } else {
+                    load_fwd<true>(P, t, k, in);
+                }
+            };
             FwdIn<true> cur, nxt;
-            load_fwd<true>(P, t, 0, cur);
+            load_roll(0, cur);
             double vcur = gm(Q.v)[i4(Q, tc, 0, t.L & 3)], ucur = gm(P.uit)[i4(P, t, 0, t.L & 3)], vnxt, unxt;
             for (int k = 0; k < N; k++) {
                 const int kn = imin(k + 1, N - 1);
-                load_fwd<true>(P, t, kn, nxt);  // prefetch
+                load_roll(kn, nxt);  // prefetch
                 vnxt = gm(Q.v)[i4(Q, tc, imin(kn, head - 1), t.L & 3)];
                 unxt = gm(P.uit)[i4(P, t, kn, t.L & 3)];
                 double blo, bhi;                       // box of stage k (only its tail check reads it)
