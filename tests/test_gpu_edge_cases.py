@@ -727,3 +727,42 @@ def test_randomised_options_match_restatement(oracle, cref, seed):
         assert np.abs(ug - ur)[ok].max() < tol and np.abs(xg - xr)[ok].max() < tol, (seed, N, B, active_set)
         assert (ug[ok] >= u_min - 1e-7).all() and (ug[ok] <= u_max + 1e-7).all()   # (interior point: primal residual <= tol)
         x = xg[:, 1, :].copy()
+
+
+def test_profile_kernels_and_chunked_pair_experiment(oracle):
+    """cfnmpc_get_profile_kernels: six per-kernel-group durations of the timed steps that add up to cfnmpc_get_profile's two
+    phases; cfnmpc_debug_chunked_pair (the stage-chunked linearise / factor hand-over experiment of DESIGN.md section 5.9)
+    leaves bitwise the gains, feed-forward terms and checkpoints of the plain kernel pair."""
+    import ctypes as C
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 1500, 50
+    x0 = oracle.sample_hover_x0(np.random.default_rng(9), B, scale=1.5)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+
+    def make():
+        s = BatchSolver(B, default_opts())
+        s.set_x0(x0); s.set_yref(np.repeat(yr[None], B, 0).copy(), np.repeat(ye[None], B, 0).copy()); s.init_iterate(INIT_HOVER)
+        s.solve(2)
+        return s
+    s = make()
+    s.set_profiling(True)
+    s.solve(3)
+    ms, n = s.get_profile_kernels()
+    assert n == 3 and len(ms) == 6 and all(v >= 0.0 for v in ms) and ms[0] > 0 and ms[1] > 0 and ms[2] > 0 and ms[4] > 0
+    s.solve(2)
+    lin, qp, n2 = s.get_profile()
+    assert n2 == 2 and lin > 0 and qp > lin * 0.5
+    s.set_profiling(False)
+    sums = []
+    for chunk in (0, 7, 1, 50):
+        q = make()
+        t = C.c_double(0)
+        assert q._L.cfnmpc_debug_chunked_pair(q._h, chunk, 2, C.byref(t), None) == 0 and t.value > 0
+        k = np.empty(3)
+        assert q._L.cfnmpc_debug_checksum(q._h, k.ctypes.data_as(C.c_void_p)) == 0
+        sums.append(k)
+        q.solve(1)                      # the solver stays usable
+        assert (q.stats()[0] == 0).all()
+    for k in sums[1:]:
+        assert np.array_equal(k, sums[0]), (k, sums[0])
