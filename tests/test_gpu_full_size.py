@@ -217,3 +217,57 @@ def test_maximum_sizes(oracle, cref):
     # (the difference lives in the weakly weighted, slowly decaying modes -- W = 1e-5 / 1e-3 on rates and
     #  attitude -- and is gone at the far end: 1e-4 at stage 0, 1e-11 at stage 4000)
     assert np.abs(ug[:, -64:] - ur[:, -64:]).max() < 1e-9
+
+
+def test_full_size_heavy_disturbances_fallback_paths_and_determinism(oracle, cref):
+    """65 536 instances kicked at TWICE the bench's disturbance level (half of the fleet constrained, a few hundred
+    instances per step in the interior-point fall-back): the paths built for that regime at full size -- rows that skip
+    the active-set attempt (as_skip_viol), the clipped interior-point start (ipm_clip_viol), the compacted fall-back list
+    (k_ipm_list) -- keep the step's properties (x0 pinned, box respected by every accepted instance, no vehicle at the
+    iteration cap), agree with the CPU restatement on a sample that contains fall-back rows, and are DETERMINISTIC: a
+    second solver fed the same inputs returns bitwise the same iterate and statistics."""
+    from crazyflie_nmpc_amd import BatchSolver, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    x0, yref, yref_e = _fleet(oracle, seed=404, scale=2.0)
+    a, b = BatchSolver(B), BatchSolver(B)
+    for s in (a, b):
+        s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    x = x0.copy()
+    rng = np.random.default_rng(5)
+    kicks = oracle.sample_hover_x0(rng, B, scale=3.0)
+    n_fb = 0
+    for t in range(8):
+        if t > 0:                       # re-kick a quarter of the fleet: saturated iterates meet new states
+            sel = rng.choice(B, B // 4, replace=False)
+            x[sel] = kicks[sel]
+        xa0, ua0 = a.get_iterate()
+        for s in (a, b):
+            s.set_x0(x); s.solve(1)
+        st, it, rs = a.stats(); st2, it2, rs2 = b.stats()
+        xg, ug = a.get_iterate(); xg2, ug2 = b.get_iterate()
+        assert np.array_equal(st, st2) and np.array_equal(it, it2) and np.array_equal(xg, xg2) and np.array_equal(ug, ug2), t
+        ok = st == 0
+        assert ok.mean() > 0.99, (t, np.bincount(st))
+        assert (st != 2).all() or (it[st == 2] >= 50).all()          # status 2 only AT the cap (and the clipped start avoids it)
+        assert np.abs(xg[ok, 0, :] - x[ok]).max() < 1e-13
+        assert ug[ok].min() >= -1e-7 and ug[ok].max() <= 22.0 + 1e-7
+        fb = ok & (it > 12)
+        n_fb += int(fb.sum())
+        # spot parity: up to 24 fall-back rows + 40 others, restatement started from the engine's previous iterate
+        idx = np.concatenate([np.nonzero(fb)[0][:24], rng.choice(B, 40, replace=False)])
+        xr, ur = xa0[idx].copy(), ua0[idx].copy()
+        st_r, it_r, _, _ = cref.rti_step(cref.default_opts(active_set=1), xr, ur, x[idx].copy(), yref[idx].copy(), yref_e[idx].copy(), nthreads=0)
+        both = (st[idx] == 0) & (st_r == 0)
+        assert both.mean() > 0.9
+        as_rows = both & (it[idx] <= 12) & (it_r <= 12)
+        assert np.abs(ug[idx][as_rows] - ur[as_rows]).max() < 1e-7            # exact active-set solutions on both sides
+        # interior-point rows: same algorithm at tol 1e-8 on QPs of condition up to 1e11 -- objective-level agreement
+        assert np.abs(ug[idx][both] - ur[both]).max() < 0.2
+        # (a row may settle by active-set solves on one side and fall back on the other: the engine's active horizon
+        #  poses an equivalent QP over a shorter head)
+        ip = both & (it[idx] > 12) & (it_r > 12)
+        if ip.any():
+            assert np.abs(it[idx][ip] - it_r[ip]).max() <= 3, (it[idx][ip], it_r[ip])
+        x = sim(x, ug[:, 0, :].copy(), T=0.015, steps=1)
+        x[~ok] = kicks[~ok]            # lost vehicles restart
+    assert n_fb > 50                   # the fall-back paths were exercised
