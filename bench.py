@@ -355,6 +355,8 @@ def main():
     ap.add_argument("--kick-scale", type=float, default=1.0)
     ap.add_argument("--step-graph", type=int, default=None, help="cfnmpc_opts.step_graph (captured hipGraph per RTI step)")
     ap.add_argument("--forward-sweep", type=int, default=None, help="cfnmpc_opts.forward_sweep (0 auto, 1 matrix-free, 2 row groups)")
+    ap.add_argument("--as-passes", type=int, default=None, help="cfnmpc_opts.as_passes (scheduling of the active-set solves: 0 auto, -1 monolithic, "
+                                                                "-3 solves + commit kernel, -2 / 1..12 instance-contiguous store / level-synchronous passes)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (default); gloo only for functional checks of the N > 1 path on "
                          "a box with fewer GPUs than ranks (ranks then share devices)")
@@ -397,7 +399,7 @@ def main():
     seed = parallel.shard_seed(rank)
     opt_kw = dict(active_horizon=args.active_horizon, active_set=args.active_set)
     for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2),
-                 ("step_graph", args.step_graph), ("forward_sweep", args.forward_sweep)):
+                 ("step_graph", args.step_graph), ("forward_sweep", args.forward_sweep), ("as_passes", args.as_passes)):
         if v is not None:
             opt_kw[k] = v
 
@@ -435,7 +437,7 @@ def main():
 
     extras = {}
     if world == 1 and not args.no_extras and args.batch == TOTAL_BATCH and args.workload == "hover" and args.kick_scale == 1.0 \
-            and args.active_set == 1 and args.cond_n2 is None:
+            and args.active_set == 1 and args.cond_n2 is None and args.as_passes is None:
         ws = min(args.warmup, 20)
 
         def brief(r):

@@ -19,7 +19,7 @@ SYMBOLS = [
     "cfnmpc_fleet_create", "cfnmpc_fleet_free", "cfnmpc_fleet_batch", "cfnmpc_fleet_min_horizon", "cfnmpc_fleet_max_horizon",
     "cfnmpc_fleet_num_buckets", "cfnmpc_fleet_bucket", "cfnmpc_fleet_workspace_bytes", "cfnmpc_fleet_set_x0",
     "cfnmpc_fleet_set_yref", "cfnmpc_fleet_set_weights", "cfnmpc_fleet_init_iterate", "cfnmpc_fleet_solve",
-    "cfnmpc_fleet_get_u", "cfnmpc_fleet_get_x", "cfnmpc_fleet_get_stats", "cfnmpc_fleet_set_box", "cfnmpc_fleet_get_cmd",
+    "cfnmpc_fleet_get_u", "cfnmpc_fleet_get_x", "cfnmpc_fleet_get_stats", "cfnmpc_fleet_set_box", "cfnmpc_fleet_set_box_stages", "cfnmpc_fleet_get_cmd",
     "cfnmpc_multi_create", "cfnmpc_multi_free", "cfnmpc_multi_batch", "cfnmpc_multi_num_shards", "cfnmpc_multi_shard",
     "cfnmpc_multi_set_x0", "cfnmpc_multi_set_yref", "cfnmpc_multi_set_weights", "cfnmpc_multi_init_iterate", "cfnmpc_multi_solve",
     "cfnmpc_multi_sync", "cfnmpc_multi_set_box", "cfnmpc_multi_set_box_stages", "cfnmpc_multi_get_u", "cfnmpc_multi_get_x", "cfnmpc_multi_get_cmd", "cfnmpc_multi_get_stats",
@@ -100,6 +100,7 @@ def lib():
     L.cfnmpc_fleet_set_yref.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_fleet_set_weights.argtypes = [vp, vp, vp]
     L.cfnmpc_fleet_set_box.argtypes = [vp, dbl, dbl]
+    L.cfnmpc_fleet_set_box_stages.argtypes = [vp, vp, vp]
     L.cfnmpc_fleet_get_cmd.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_fleet_init_iterate.argtypes = [vp, i32, vp]
     L.cfnmpc_fleet_solve.argtypes = [vp, i32, vp]

@@ -240,6 +240,25 @@ int cfnmpc_fleet_set_box(cfnmpc_fleet* f, double u_min, double u_max) {
     return CFNMPC_OK;
 }
 
+// per-stage / per-input boxes for a fleet: host arrays [B][Nmax][4] in the fleet's vehicle order (rows behind a vehicle's
+// own horizon are ignored); NULL, NULL returns every bucket to the scalar box
+int cfnmpc_fleet_set_box_stages(cfnmpc_fleet* f, const double* lb, const double* ub) {
+    if (!f || ((lb == nullptr) != (ub == nullptr))) return CFNMPC_EINVAL;
+    FleetDevice fd(f);
+    std::vector<double> hl, hu;
+    for (Bucket& b : f->bk) {
+        if (!lb) { RC_TRY(cfnmpc_set_box_stages(b.s, nullptr, nullptr, 0, nullptr)); continue; }
+        const size_t row = (size_t)b.N * 4, frow = (size_t)f->Nmax * 4;
+        hl.resize((size_t)b.count * row); hu.resize((size_t)b.count * row);
+        for (int r = 0; r < b.count; r++) {
+            std::copy_n(lb + (size_t)b.idx[r] * frow, row, hl.data() + (size_t)r * row);
+            std::copy_n(ub + (size_t)b.idx[r] * frow, row, hu.data() + (size_t)r * row);
+        }
+        RC_TRY(cfnmpc_set_box_stages(b.s, hl.data(), hu.data(), 0, nullptr));
+    }
+    return CFNMPC_OK;
+}
+
 int cfnmpc_fleet_init_iterate(cfnmpc_fleet* f, int mode, void* stream) {
     if (!f) return CFNMPC_EINVAL;
     FleetDevice fd(f);

@@ -82,6 +82,15 @@ class MixedHorizonFleet:
     def set_box(self, u_min, u_max):
         _check(self._L.cfnmpc_fleet_set_box(self._h, float(u_min), float(u_max)), "cfnmpc_fleet_set_box")
 
+    def set_box_stages(self, lb=None, ub=None):
+        """per-stage / per-input boxes, host arrays [B][Nmax][4] (vehicle i uses rows 0..N_i-1); None, None: scalar box"""
+        if lb is None and ub is None:
+            _check(self._L.cfnmpc_fleet_set_box_stages(self._h, None, None), "cfnmpc_fleet_set_box_stages")
+            return
+        lb = np.ascontiguousarray(lb, dtype=np.float64); ub = np.ascontiguousarray(ub, dtype=np.float64)
+        assert lb.shape == (self.B, self.Nmax, 4) and ub.shape == lb.shape
+        _check(self._L.cfnmpc_fleet_set_box_stages(self._h, lb.ctypes.data_as(C.c_void_p), ub.ctypes.data_as(C.c_void_p)), "cfnmpc_fleet_set_box_stages")
+
     def get_cmd(self, cmd_vel=None, motvel=None):
         """Output stage of the reference node for the whole fleet (cfnmpc_fleet_get_cmd)."""
         if cmd_vel is None:

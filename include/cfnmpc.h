@@ -305,6 +305,9 @@ int cfnmpc_fleet_set_x0(cfnmpc_fleet *f, const double *x0, int on_device, void *
 int cfnmpc_fleet_set_yref(cfnmpc_fleet *f, const double *yref, const double *yref_e, int on_device, void *stream);
 int cfnmpc_fleet_set_weights(cfnmpc_fleet *f, const double *W /*[17]*/, const double *WN /*[13]*/);
 int cfnmpc_fleet_set_box(cfnmpc_fleet *f, double u_min, double u_max);
+/* cfnmpc_set_box_stages for a fleet: HOST arrays [B][Nmax][4] in the fleet's vehicle order (rows behind a vehicle's own
+ * horizon are ignored); NULL, NULL: back to the scalar box */
+int cfnmpc_fleet_set_box_stages(cfnmpc_fleet *f, const double *lb, const double *ub);
 int cfnmpc_fleet_init_iterate(cfnmpc_fleet *f, int mode, void *stream);
 int cfnmpc_fleet_solve(cfnmpc_fleet *f, int n_rti, void *stream);
 int cfnmpc_fleet_get_u(cfnmpc_fleet *f, int stage, double *u /*[B][4]*/, int on_device, void *stream);

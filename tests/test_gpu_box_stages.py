@@ -109,3 +109,38 @@ def test_dropin_fixed_u0_variant_matches_batch_api(tmp_path, oracle):
             assert ref["converged"] and np.abs(ug[0] - ubar[0] - ref["du"]).max() < 1e-8
         u1 = ug[0, 1].copy()
         x = sim(x, ug[:, 0], T=0.015, steps=1)
+
+
+def test_fleet_per_stage_boxes_reach_every_bucket(oracle):
+    """cfnmpc_fleet_set_box_stages: a mixed-horizon fleet with stage 0 pinned per vehicle equals one BatchSolver per
+    horizon with the same boxes (bitwise: the bucket IS such a solver), and u0 is the pin."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(17)
+    Bf = 45
+    hz = rng.choice([30, 50, 100], size=Bf)
+    x0 = oracle.sample_hover_x0(rng, Bf, scale=1.3)
+    f = MixedHorizonFleet(hz)
+    f.set_regulation(np.tile([0.0, 0.0, 0.4], (Bf, 1)), HOV)
+    lb = np.zeros((Bf, 100, 4)); ub = np.full((Bf, 100, 4), 22.0)
+    pin = rng.uniform(12.0, 19.0, (Bf, 4))
+    lb[:, 0] = pin; ub[:, 0] = pin
+    f.set_box_stages(lb, ub)
+    f.set_x0(x0); f.init_iterate(INIT_HOVER); f.solve(1)
+    st, it, _ = f.stats()
+    u0 = f.get_u(0); u1 = f.get_u(1)
+    assert (st == 0).all() and np.abs(u0 - pin).max() < 1e-12
+    for n in (30, 50, 100):
+        idx = np.nonzero(hz == n)[0]
+        yr, ye = oracle.regulation_yref(int(n), (0.0, 0.0, 0.4), uss=HOV)
+        s = BatchSolver(len(idx), default_opts(N=int(n)))
+        s.set_yref(np.repeat(yr[None], len(idx), 0).copy(), np.repeat(ye[None], len(idx), 0).copy())
+        s.set_x0(x0[idx]); s.init_iterate(INIT_HOVER)
+        s.set_box_stages(lb[idx, :n].copy(), ub[idx, :n].copy())
+        s.solve(1)
+        assert np.array_equal(s.get_u(0), u0[idx]) and np.array_equal(s.get_u(1), u1[idx])
+    f.set_box_stages(None, None)
+    f.set_x0(x0); f.init_iterate(INIT_HOVER); f.solve(1)
+    assert np.abs(f.get_u(0) - pin).max() > 0.1          # the pin is gone
+    f.close()
