@@ -446,6 +446,10 @@ def main():
         extras["interior_point_only (active_set=0)"] = brief(measure(B_rank, 20, ws, active_set=0, seed_off=2))
         extras["kick_scale_x2"] = brief(measure(B_rank, 20, ws, kick_scale=2.0, seed_off=3))
         extras["kick_scale_x3"] = brief(measure(B_rank, 20, ws, kick_scale=3.0, seed_off=4))
+        # cfnmpc_opts.reinit_failed: vehicles whose QP failed (status 4) restart from their current state instead of keeping
+        # the iterate that failed -- NOT the reference's behaviour (its node ignores the status), reported beside it
+        extras["kick_scale_x2 + reinit_failed"] = brief(measure(B_rank, 20, ws, kick_scale=2.0, seed_off=3, reinit_failed=1))
+        extras["kick_scale_x3 + reinit_failed"] = brief(measure(B_rank, 20, ws, kick_scale=3.0, seed_off=4, reinit_failed=1))
         extras["full_horizon_sweeps (active_horizon=0)"] = brief(measure(B_rank, 20, ws, active_horizon=0, seed_off=5))
         extras["config_C2_batch_4096"] = brief(measure(4096, 40, 40, seed_off=6))
         extras["batch_8192 (one GPU's share of 65536 at 8 GPUs)"] = brief(measure(8192, 40, 40, seed_off=7))

@@ -47,6 +47,7 @@ struct cfnmpc_solver {
     hipEvent_t glaunched[2];     // recorded behind the last launch of gexec[p]: waited for before that exec is destroyed
     bool gvalid[2];
     int parity;                  // which of the two argument sets the NEXT step uses
+    int reinit_failed;           // cfnmpc_opts.reinit_failed
     double *lbs_keep, *ubs_keep; // per-stage boxes (cfnmpc_set_box_stages), allocated at the first call
 };
 
@@ -180,6 +181,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->ipm_clip_viol = 2.0;
     o->ipm_clip_margin = 0.05;
     o->as_skip_viol = 4.0;
+    o->reinit_failed = 0;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
@@ -221,6 +223,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     s->gvalid[0] = s->gvalid[1] = false;
     s->parity = 0;
     s->lbs_keep = s->ubs_keep = nullptr;
+    s->reinit_failed = o.reinit_failed ? 1 : 0;
     // the shooting intervals of a 64-instance group are independent: spread them over enough
     // workgroups to fill the 1024 SIMDs when the batch alone does not (a single instance then
     // linearises its 50 intervals in parallel instead of one after the other)
@@ -251,7 +254,8 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.ah_margin = o.ah_margin;
     P.ah_extra = o.ah_extra;
     P.active_set = o.active_set ? 1 : 0;
-    if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
+    if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise) ||
+        (o.reinit_failed && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
     P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && batch < FORWARD_RG_BELOW) ? 1 : 0;
     if (o.as_passes < -3 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
     // internal: 0 = monolithic k_as, -1 = every solve in one launch on the compact z store + commit, -2 = the monolithic
@@ -484,6 +488,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
             e = &s->ev[s->ev_used];
             s->ev_used += EV_PER_STEP;
         }
+        if (s->reinit_failed) { cfn::launch_reinit_failed(s->P, st); s->lin_valid = false; }
         if (!s->overlap && s->use_graph && !e) {
             // the step's launches replayed from a captured graph (one per parity of the iterate buffers)
             const int p = s->parity;

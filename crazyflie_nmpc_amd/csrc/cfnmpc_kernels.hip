@@ -2942,6 +2942,18 @@ __global__ void k_init_iterate(Params P, int mode) {
         for (int e = 0; e < 4; e++) P.uit[blk_index(i, k, e, P.N, 4)] = (mode == 1) ? hov : 0.0;
 }
 
+// cfnmpc_opts.reinit_failed: an instance whose last step ended in status 4 (factorisation not positive definite / not
+// finite: its iterate has left the region where the Gauss-Newton QP is solvable, and re-linearising around the same iterate
+// fails the same way step after step) restarts from x_k = its current x0, u_k = the input reference of its stage.
+__global__ void k_reinit_failed(Params P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.B || P.status[i] != 4) return;
+    for (int k = 0; k <= P.N; k++)
+        for (int e = 0; e < 13; e++) P.xit[blk_index(i, k, e, P.N + 1, 13)] = P.x0[blk_index(i, 0, e, 1, 13)];
+    for (int k = 0; k < P.N; k++)
+        for (int e = 0; e < 4; e++) P.uit[blk_index(i, k, e, P.N, 4)] = P.yref[blk_index(i, k, 13 + e, P.N, 17)];
+}
+
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -3057,6 +3069,9 @@ void launch_windows(const Params& P, const double* traj, int n_rows, int* mode, 
 }
 void launch_postproc(const Params& P, double* cmd_vel, int* motvel, hipStream_t st) {
     hipLaunchKernelGGL(k_postproc, dim3((P.B + 255) / 256), dim3(256), 0, st, P, cmd_vel, motvel);
+}
+void launch_reinit_failed(const Params& P, hipStream_t st) {
+    hipLaunchKernelGGL(k_reinit_failed, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
 }
 void launch_init_iterate(const Params& P, int mode, hipStream_t st) {
     hipLaunchKernelGGL(k_init_iterate, dim3((P.B + 255) / 256), dim3(256), 0, st, P, mode);

@@ -156,6 +156,7 @@ void launch_get(int B, int S, int E, int perm13, int s0, int Stot, const double*
 void launch_windows(const Params& P, const double* traj, int n_rows, int* mode, int* iter, const double* des,
                     double uss, hipStream_t st);
 void launch_init_iterate(const Params& P, int mode, hipStream_t st);
+void launch_reinit_failed(const Params& P, hipStream_t st);   // cfnmpc_opts.reinit_failed
 // output stage of the reference node for the fleet (cmd_vel [B][4] doubles, motvel [B][4] int32 or NULL)
 void launch_postproc(const Params& P, double* cmd_vel, int* motvel, hipStream_t st);
 

@@ -149,6 +149,11 @@ typedef struct cfnmpc_opts {
                             Measured on the engine's closed loops at 2x / 3x the bench's disturbances: the iteration settles
                             for 68 - 71 % of the instances between 2 and 4 widths, 14 - 15 % between 4 and 8, 1 - 2 % beyond --
                             twelve futile solves per instance otherwise.                                                 */
+    int reinit_failed;   /* 1: an instance whose previous RTI step ended in status 4 (QP failure: the factorisation around its
+                            iterate is not positive definite / not finite) restarts the next step from x_k = its current x0,
+                            u_k = the input reference of its stage, instead of re-linearising around the same iterate and failing
+                            the same way for good.  0 (default): the reference's behaviour -- the node ignores the status and keeps
+                            the iterate (acados_mpc.cpp:611-616).                                                        */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);

@@ -766,3 +766,40 @@ def test_profile_kernels_and_chunked_pair_experiment(oracle):
         assert (q.stats()[0] == 0).all()
     for k in sums[1:]:
         assert np.array_equal(k, sums[0]), (k, sums[0])
+
+
+def test_reinit_failed_option_recovers_a_lost_instance(oracle):
+    """cfnmpc_opts.reinit_failed: an instance whose step ended in status 4 (here: an iterate poisoned with NaN) restarts
+    the next step from x_k = x0, u_k = the stage's input reference -- and then equals a solver freshly initialised that way;
+    without the option it stays lost (the reference's behaviour: status ignored, iterate kept); the other instances are
+    not touched (bitwise)."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 9, 50
+    x0 = oracle.sample_hover_x0(np.random.default_rng(13), B, scale=1.2)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4), uss=HOV)
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    on, off = BatchSolver(B, default_opts(reinit_failed=1)), BatchSolver(B, default_opts())
+    for s in (on, off):
+        s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER); s.solve(1)
+        x, u = s.get_iterate()
+        x[4] = np.nan; u[4] = np.nan
+        s.set_iterate(x, u)
+        s.solve(1)
+        assert s.stats()[0][4] == 4 and (np.delete(s.stats()[0], 4) == 0).all()
+    x1 = x0 + 0.01
+    for s in (on, off):
+        s.set_x0(x1); s.solve(1)
+    st_on, st_off = on.stats()[0], off.stats()[0]
+    assert st_off[4] == 4 and st_on[4] == 0 and (np.delete(st_on, 4) == 0).all()
+    (xa, ua), (xb, ub) = on.get_iterate(), off.get_iterate()
+    keep = np.arange(B) != 4
+    assert np.array_equal(xa[keep], xb[keep]) and np.array_equal(ua[keep], ub[keep])
+    fresh = BatchSolver(1)
+    fresh.set_x0(x1[4:5]); fresh.set_yref(yref[4:5], yref_e[4:5])
+    fresh.set_iterate(np.repeat(x1[4:5, None, :], N + 1, 1).copy(), np.full((1, N, 4), HOV))
+    fresh.solve(1)
+    xf, uf = fresh.get_iterate()
+    assert np.abs(xa[4] - xf[0]).max() < 1e-9 and np.abs(ua[4] - uf[0]).max() < 1e-9
+    with pytest.raises(Exception):
+        BatchSolver(4, default_opts(reinit_failed=1, overlap_linearise=1))

@@ -15,7 +15,7 @@ rng = np.random.default_rng(99)
 dev = torch.device("cuda", 0)
 x = torch.from_numpy(sample_hover_x0(rng, B)).to(dev)
 row = regulation_row()
-s = BatchSolver(B, default_opts(active_set=int(os.environ.get('SOAK_AS', 1)), active_horizon=int(os.environ.get('SOAK_AH', 1))))
+s = BatchSolver(B, default_opts(active_set=int(os.environ.get('SOAK_AS', 1)), active_horizon=int(os.environ.get('SOAK_AH', 1)), reinit_failed=int(os.environ.get('SOAK_REINIT', 0))))
 s.set_x0(x); s.set_yref(torch.from_numpy(np.tile(row, (B, N, 1))).to(dev), torch.from_numpy(np.tile(row[:13], (B, 1))).to(dev)); s.init_iterate(INIT_HOVER)
 cohort = B // KP
 u0 = torch.empty((B, 4), dtype=torch.float64, device=dev); xn = torch.empty_like(x)
