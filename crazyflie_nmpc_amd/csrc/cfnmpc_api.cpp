@@ -271,6 +271,9 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
         P.as_grid = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? 8 * prop.multiProcessorCount : 2048;
         if (const char* e = std::getenv("CFNMPC_AS_GRID")) { const int v = std::atoi(e); if (v > 0) P.as_grid = v; }
     }
+    // one fall-back row per wave is as fast as four while those waves fit one per SIMD (1024 rows: 1.6 % of 65 536 instances,
+    // 2.5 % fall back at three times the bench's disturbances): only large fleets pay the compaction's extra launch
+    P.ipm_listed = batch >= AS_COMMIT_BELOW ? 1 : 0;
     P.cond_N2 = cond_N2;
     P.cond_M = cond_N2 ? o.N / cond_N2 : 0;
     P.cond_rem = cond_N2 ? o.N % cond_N2 : 0;

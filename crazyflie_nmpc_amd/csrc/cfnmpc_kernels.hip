@@ -1616,11 +1616,12 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
 #endif
     // MODE 2 works on the list k_ipm_list compacted from the rows the active-set kernels left (P.ilist2, count in
     // P.nipm[40]): four fall-back rows per wave instead of one row in each of the waves they were scattered over
-    const int nipm = gm(P.nipm)[MODE == 2 ? 40 : 0];
+    const bool listed = MODE == 2 && P.ipm_listed;   // (small fleets skip k_ipm_list: the rows stay where k_as had them)
+    const int nipm = gm(P.nipm)[listed ? 40 : 0];
     const int slot = vb * 4 + (threadIdx.x >> 4);
     if (vb * 4 >= nipm) return;  // wave-uniform: no work for this wave
     bool has = slot < nipm;
-    const int inst0 = has ? gm(MODE == 2 ? P.ilist2 : P.ilist)[imin(slot, nipm - 1)] : 0;
+    const int inst0 = has ? gm(listed ? P.ilist2 : P.ilist)[imin(slot, nipm - 1)] : 0;
     constexpr bool AS_ONLY = MODE == 1 || MODE == 3 || MODE == 4;
     constexpr bool NO_ROLL = MODE == 4;   // solves only: roll-out, tail check and publication are left to k_ascommit
     if (MODE == 2 || MODE == 3) {   // MODE 2: rows left for the interior point (done = 0); MODE 3: rows the
@@ -2128,7 +2129,7 @@ __global__ __launch_bounds__(64) void k_as(Params P) {        // active-set solv
 __global__ __launch_bounds__(64) void k_ipm_rest(Params P) {  // interior point for what k_as left
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[40]; vb += gridDim.x) qp_wave<2>(P, wtile, btile, vb);
+    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[P.ipm_listed ? 40 : 0]; vb += gridDim.x) qp_wave<2>(P, wtile, btile, vb);
 }
 // the same three for per-stage input boxes (cfnmpc_set_box_stages)
 __global__ __launch_bounds__(64) void k_ipm_sbox(Params P) {
@@ -2144,7 +2145,7 @@ __global__ __launch_bounds__(64) void k_as_sbox(Params P) {
 __global__ __launch_bounds__(64) void k_ipm_rest_sbox(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[40]; vb += gridDim.x) qp_wave<2, true>(P, wtile, btile, vb);
+    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[P.ipm_listed ? 40 : 0]; vb += gridDim.x) qp_wave<2, true>(P, wtile, btile, vb);
 }
 __global__ __launch_bounds__(64) void k_as_solves(Params P) {  // MODE 4: active-set solves, no roll-out
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
@@ -2998,7 +2999,7 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         if (P.active_set) {
             hipLaunchKernelGGL(k_as_sbox, dim3(P.NW), dim3(64), 0, st, P);
             if (ev) (void)hipEventRecord(ev[0], st);
-            hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
+            if (P.ipm_listed) hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
             hipLaunchKernelGGL(k_ipm_rest_sbox, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
         } else {
             if (ev) (void)hipEventRecord(ev[0], st);
@@ -3027,12 +3028,12 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         else hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_as_retry, dim3(P.NW), dim3(64), 0, st, P);
         if (ev) (void)hipEventRecord(ev[0], st);
-        hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
+        if (P.ipm_listed) hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
         hipLaunchKernelGGL(k_ipm_rest, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
     } else if (P.active_set) {
         hipLaunchKernelGGL(k_as, dim3(P.NW), dim3(64), 0, st, P);
         if (ev) (void)hipEventRecord(ev[0], st);
-        hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
+        if (P.ipm_listed) hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
         hipLaunchKernelGGL(k_ipm_rest, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
     } else {
         if (ev) (void)hipEventRecord(ev[0], st);

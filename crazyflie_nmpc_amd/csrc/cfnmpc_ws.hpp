@@ -90,6 +90,7 @@ struct Params {
     int active_set;  // 1: try the primal-dual active-set solve before the interior-point iteration
     int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
     double *res, *viol;          // per instance
+    int ipm_listed;              // 1: k_ipm_rest works on ilist2 (fleets whose fall-back rows may exceed one wave per SIMD); 0: on ilist, filtered
     int *ilist2;                 // the rows of ilist the active-set kernels left for the interior point (k_ipm_list; count in nipm[40])
     int *ilist;                  // compacted list of the instances that need the interior-point method
     int *nipm;                   // [0] its length, [1 + bin] instances per compaction bin
