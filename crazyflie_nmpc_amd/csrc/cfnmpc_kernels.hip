@@ -8,7 +8,7 @@
 //     through LDS tiles -- for the kernels that carry at most a 13-vector (k_linearise, k_forward).
 // One wavefront per workgroup; instances never communicate.
 //
-// Kernels, one RTI step = seven launches on one stream:
+// Kernels, one RTI step = eight launches on one stream (large fleets; small ones: see launch_qp_*):
 //   k_linearise : RK4 + forward sensitivities per shooting interval (the role of acados sim_erk +
 //                 CasADi forw_vde, acados_mpc.cpp:84), written in the row-distributed A / B form.
 //   k_factor    : start solve, backward: augmented Riccati factorisation of the unconstrained QP
@@ -26,10 +26,13 @@
 //                 forward sweep that also evaluates the multipliers and re-classifies) until the
 //                 active set is stationary = exact QP solution; roll-out into the second iterate
 //                 buffer with tail verification (acados_solve() epilogue, acados_mpc.cpp:611-616).
-//   k_ipm_rest  : rows k_as left (no stationary set within 12 solves, tail check failed):
-//                 Mehrotra predictor-corrector over stage-wise Riccati sweeps in delta form
-//                 (HPIPM's role, generate_c_code.py:140).  k_ipm = the same without k_as
-//                 (cfnmpc_opts.active_set = 0).
+//   k_ipm_list  : compacts the rows k_as left (large fleets), four per wave for
+//   k_ipm_rest  : rows k_as left (no stationary set within 12 solves, tail check failed, or too far outside the
+//                 box to try): Mehrotra predictor-corrector over stage-wise Riccati sweeps in delta form, clipped
+//                 start for rows far outside the box (HPIPM's role, generate_c_code.py:140).  k_ipm = the same
+//                 without k_as (cfnmpc_opts.active_set = 0).
+//   k_as_solves / k_ascommit / k_as_retry, k_asf / k_asw / k_asp : scheduling variants of the active-set phase
+//                 (cfnmpc_opts.as_passes; solves + commit kernel is the default of small fleets).
 //   k_linearise_list : cfnmpc_opts.overlap_linearise only -- re-linearises the interior-point
 //                 instances after the early pass that ran beside k_ipm.
 //   k_sim / k_estimate : RK4 plant step / predictor (acados_estimator.cpp:573-593).
