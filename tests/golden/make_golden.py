@@ -151,6 +151,6 @@ if __name__ == "__main__":
 
 # hard_qps.npz (round 3) is NOT produced by this script: its inputs (iterate, x0) are 16 QPs CAPTURED from the HIP engine's
 # closed loop at twice the bench's disturbance level (vehicles that left the region of attraction: the unconstrained minimiser
-# lies 100 - 6000 kRPM outside the box; tools/dev/capture_st2.py / capture_hard.py on a GPU box), its expected values are the
+# lies 100 - 6000 kRPM outside the box; tools/r3_capture_st2.py on a GPU box), its expected values are the
 # numpy oracle's riccati_ipm on them (infeasible start with clip_viol = 0, clipped start with the defaults; objective of the
 # condensed QP at the clipped-start solution).
