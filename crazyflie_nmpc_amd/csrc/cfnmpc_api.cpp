@@ -228,9 +228,28 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     // workgroups to fill the 1024 SIMDs when the batch alone does not (a single instance then
     // linearises its 50 intervals in parallel instead of one after the other)
     {
+        // k_linearise runs one wavefront per SIMD: a launch of groups x c workgroups takes ceil(groups c / SIMDs) rounds of
+        // ceil(N / c) stages each (+ a prologue per workgroup) -- take the c that minimises it (rounding groups c UP past the
+        // number of SIMDs would cost a whole second round: 255 groups x 5 chunks = 1275 workgroups ran 35 % slower than x 4)
         const int groups = (batch + 63) / 64;
-        int c = s->overlap ? 5 : 1;
-        if (groups * c < 1024) c = (1024 + groups - 1) / groups;
+        int simds = 1024;
+        {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) simds = 4 * prop.multiProcessorCount;
+        }
+        int c = 1;
+        if (s->overlap) {
+            c = 5;
+            if (groups * c < simds) c = (simds + groups - 1) / groups;
+        } else {
+            double best = 1e300;
+            for (int cc = 1; cc <= o.N; cc++) {
+                const long rounds = ((long)groups * cc + simds - 1) / simds;
+                const double cost = (double)rounds * ((o.N + cc - 1) / cc + 0.35);   // 0.35 stage-equivalents of prologue per workgroup
+                if (cost < best - 1e-9) { best = cost; c = cc; }
+            }
+        }
         s->chunks_all = c < 1 ? 1 : (c > o.N ? o.N : c);
     }
     s->chunks_list = 10;
