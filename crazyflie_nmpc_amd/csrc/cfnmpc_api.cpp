@@ -79,7 +79,8 @@ struct DeviceGuard {
 
 constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the count
 constexpr size_t EV_PER_STEP = 7;
-constexpr int AS_COMMIT_BELOW = 16384;        // below: the active-set kernel leaves the roll-out to k_ascommit
+constexpr int AS_COMMIT_BELOW = 36864;        // below: the active-set kernel leaves the roll-out to k_ascommit (measured cross-over between 32768 and 49152 instances)
+constexpr int IPM_LIST_FROM = 16384;          // from here on the fall-back rows are compacted before k_ipm_rest
 constexpr int FORWARD_RG_BELOW = 8192;        // measured cross-over of the two forward sweeps
 
 // `on_device` argument: 0 host (synchronous), 2 host (enqueued only), anything else: device pointer
@@ -292,7 +293,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     }
     // one fall-back row per wave is as fast as four while those waves fit one per SIMD (1024 rows: 1.6 % of 65 536 instances,
     // 2.5 % fall back at three times the bench's disturbances): only large fleets pay the compaction's extra launch
-    P.ipm_listed = batch >= AS_COMMIT_BELOW ? 1 : 0;
+    P.ipm_listed = batch >= IPM_LIST_FROM ? 1 : 0;
     P.cond_N2 = cond_N2;
     P.cond_M = cond_N2 ? o.N / cond_N2 : 0;
     P.cond_rem = cond_N2 ? o.N % cond_N2 : 0;

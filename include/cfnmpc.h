@@ -131,7 +131,7 @@ typedef struct cfnmpc_opts {
                             over the instances that have not settled yet (work lists re-binned by remaining sweep
                             length between the launches, two wavefronts per SIMD), one launch for the remaining
                             12 - p solves, then the commit kernel;
-                            0 (default): -3 below 16 384 instances (+1 .. 2.5 % there), -1 from there on -- measured on
+                            0 (default): -3 up to 32 768 instances (+1 .. 2.5 % there), -1 beyond -- measured on
                             MI355X, DESIGN.md section 5.5: the phase is bound by the bytes of the home blocks and by
                             the hardest instance's chain of solves, not by occupancy, and -2 / p > 0 are slower at
                             every fleet size; kept as options.  Same solves in every mode; results agree to rounding. */
