@@ -81,6 +81,7 @@ constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the c
 constexpr size_t EV_PER_STEP = 7;
 constexpr int AS_COMMIT_BELOW = 36864;        // below: the active-set kernel leaves the roll-out to k_ascommit (measured cross-over between 32768 and 49152 instances)
 constexpr int IPM_LIST_FROM = 16384;          // from here on the fall-back rows are compacted before k_ipm_rest
+constexpr int FORWARD_DIV_FROM = 32768;       // k_forward (the division form) from this fleet size (measured at 16 384 and 65 536; cfnmpc_kernels.hip, forward_body)
 constexpr int FORWARD_RG_BELOW = 8192;        // measured cross-over of the two forward sweeps
 
 // `on_device` argument: 0 host (synchronous), 2 host (enqueued only), anything else: device pointer
@@ -276,6 +277,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.active_set = o.active_set ? 1 : 0;
     if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise) ||
         (o.reinit_failed && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
+    P.forward_div = batch >= FORWARD_DIV_FROM ? 1 : 0;
     P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && batch < FORWARD_RG_BELOW) ? 1 : 0;
     if (o.as_passes < -3 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
     // internal: 0 = monolithic k_as, -1 = every solve in one launch on the compact z store + commit, -2 = the monolithic

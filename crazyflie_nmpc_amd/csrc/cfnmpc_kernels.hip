@@ -45,6 +45,10 @@
 #include "cfnmpc_model.hpp"
 #include "cfnmpc_ws.hpp"
 
+#ifndef KALIGN_BYTES
+#define KALIGN_BYTES 4096
+#endif
+#define KALIGN __attribute__((aligned(KALIGN_BYTES)))
 namespace cfn {
 
 // ---------------------------------------------------------------------------------------------
@@ -250,6 +254,13 @@ __device__ __forceinline__ void sens_column(const JacPoint (&J)[4], const double
 //   GATHER = true : the instances P.ilist[64 g ..] (the interior-point instances of this step,
 //                   whose iterate only became final after the early pass over everybody).
 // Lanes without an instance work on the spare workspace block NW (finite data, never read).
+__host__ __device__ constexpr unsigned div_magic(int ns) { return (65536u + (unsigned)ns - 1u) / (unsigned)ns; }
+__host__ __device__ constexpr bool div_ok(int ns) {
+    for (unsigned e = 0; e < 64u * (unsigned)ns; e++)
+        if (((e * div_magic(ns)) >> 16) != e / (unsigned)ns || e * div_magic(ns) >= (1u << 24)) return false;
+    return true;
+}
+static_assert(div_ok(13) && div_ok(10) && div_ok(6), "k_linearise: e / NS by multiply-shift");
 template <bool GATHER>
 __device__ __forceinline__ void linearise_body(const Params& P, double* sx, double (*sc)[64 * 13], int* sinst) {
     const int tid = threadIdx.x;
@@ -281,7 +292,8 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
             return gm(field) + ((size_t)(in >> 2) * stages + k) * SZ + pre4 + (in & 3) * NS + i;
         }
         const int w0 = (int)blockIdx.x * 16;
-        const unsigned off = (unsigned)(imin(li >> 2, P.NW - w0) * (stages * SZ) + (li & 3) * NS + i) * 8u;
+        // (24-bit multiply: full rate, the 32-bit one takes four issue slots; block index <= 16, stages * SZ < 2^24 for N <= 4096)
+        const unsigned off = (__umul24((unsigned)imin(li >> 2, P.NW - w0), (unsigned)(stages * SZ)) + (unsigned)((li & 3) * NS + i)) * 8u;
         const char* base = (const char*)(gm(field) + ((size_t)w0 * stages + k) * SZ + pre4);
         return (gdouble*)(base + off);
     };
@@ -290,7 +302,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     auto issue_x = [&](int k, int tl, double (&xr)[13]) {  // stage k of xit -> registers (no wait)
         SFOR(r, 0, 13, {
             const int e = tl + 64 * r;
-            const int li = e / 13, i = e - li * 13;
+            const int li = (int)(__umul24((unsigned)e, div_magic(13)) >> 16), i = e - li * 13;
             xr[r] = *el(P.xit, li, i, N + 1, k, SZ_V13, 0, 13);
         });
     };
@@ -343,17 +355,19 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         });
         __syncthreads();
         // rows < NS of column tile `ti` -> `field` (SZ doubles per block and stage) at `pre4`
+        // e / NS for e < 64 * NS as a 24-bit multiply + shift (verified at compile time: div_ok)
+#define CFN_DIV(e, NS) ((int)(__umul24((unsigned)(e), div_magic(NS)) >> 16))
 #define CFN_STORE(field, SZ, ti, NS, pre4)                                                              \
     {                                                                                                   \
         double tv[NS];                                                                                  \
         SFOR(r, 0, NS, {                                                                                \
             const int e = tl + 64 * r;                                                                  \
-            const int li = e / (NS), i = e - li * (NS);                                                 \
+            const int li = CFN_DIV(e, NS), i = e - li * (NS);                                          \
             tv[r] = sc[ti][li * 13 + i];                                                                \
         });                                                                                             \
         SFOR(r, 0, NS, {                                                                                \
             const int e = tl + 64 * r;                                                                  \
-            const int li = e / (NS), i = e - li * (NS);                                                 \
+            const int li = CFN_DIV(e, NS), i = e - li * (NS);                                          \
             *el(field, li, i, N, k, SZ, pre4, NS) = tv[r];                                              \
         });                                                                                             \
     }
@@ -400,9 +414,10 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         land_x(xr);
         __syncthreads();
 #undef CFN_STORE
+#undef CFN_DIV
     }
 }
-__global__ __launch_bounds__(64) void k_linearise(Params P) {
+KALIGN __global__ __launch_bounds__(64) void k_linearise(Params P) {
     __shared__ double sx[64 * 13];       // one 13-vector per instance (internal order)
     __shared__ double sc[4][64 * 13];    // up to four sensitivity columns, [inst][row] (internal order)
     __shared__ int sinst[64];
@@ -1013,7 +1028,7 @@ __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, 
 // =============================================================================================
 // start solve: backward factorisation, forward sweep
 // =============================================================================================
-__global__ __launch_bounds__(64, 2) void k_factor(Params P) {
+KALIGN __global__ __launch_bounds__(64, 2) void k_factor(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
     const Lane t = lane_id(P);
@@ -1095,7 +1110,12 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
 // COND (cfnmpc_opts.cond_N2, partial condensing): the gains of a block's stages are rows of the
 // CONDENSED feedback law, which acts on the state step at the START of the block (dxb); rolling the
 // interior states through the stage dynamics is the `expand` step of partial condensing.
-template <bool COND>
+// FWD_DIV: the model's rotor / gyroscopic terms in the survey's literal form (four FP64 divisions per evaluation) instead
+// of the folded constants -- same function, rounding apart.  Measured on MI355X: the shorter instruction stream makes
+// the sweep FASTER where it is a latency chain (8192 instances 0.210 -> 0.187 ms, 16 384: 0.228 -> 0.205 ms) and SLOWER
+// where it streams at the HBM rate (65 536 instances, 1024 waves in step: 0.617 -> 0.666 ms, three A/B/A runs on one box),
+// so the launcher picks by fleet size (Params.forward_div).
+template <bool COND, bool FWD_DIV = false>
 __device__ __forceinline__ void forward_body(const Params& P, double* xs, double* cs, int* sflag) {
     // 13-vectors travel through LDS tiles [instance][13] so that every global access of the wave
     // is a contiguous run (as in k_linearise); K, d, u, v are 32-byte runs per lane already.
@@ -1191,26 +1211,26 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         }
         JacPoint J;
         // stage 1
-        f_expl(x, uc, kk);
+        f_expl<FWD_DIV>(x, uc, kk);
         jac_point(x, J);
         jvp<true, true>(J, s, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
         SFOR(e, 0, 13, { acc[e] = dk[e]; ks[e] = kk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
         // stage 2
-        f_expl(xt, uc, kk);
+        f_expl<FWD_DIV>(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
         SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; ks[e] = ks[e] + 2 * kk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
         // stage 3
-        f_expl(xt, uc, kk);
+        f_expl<FWD_DIV>(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
         SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; ks[e] = ks[e] + 2 * kk[e]; xt[e] = x[e] + h * kk[e]; st[e] = s[e] + h * dk[e]; });
         // stage 4 (the nominal slope too: b_k = Phi(x_k, u_k) - x_{k+1} is formed here, as k_linearise
         // forms it, instead of being read back)
-        f_expl(xt, uc, kk);
+        f_expl<FWD_DIV>(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
@@ -1285,10 +1305,15 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
     }
 }
 
-__global__ __launch_bounds__(64) void k_forward(Params P) {
+KALIGN __global__ __launch_bounds__(64) void k_forward(Params P) {   // large fleets (see FWD_DIV above)
     __shared__ double xs[64 * 13], cs[64 * 13];
     __shared__ int sflag[64];
-    forward_body<false>(P, xs, cs, sflag);
+    forward_body<false, true>(P, xs, cs, sflag);
+}
+__global__ __launch_bounds__(64) void k_forward_mid(Params P) {   // fleets below cfnmpc_api.cpp's FORWARD_DIV_FROM
+    __shared__ double xs[64 * 13], cs[64 * 13];
+    __shared__ int sflag[64];
+    forward_body<false, false>(P, xs, cs, sflag);
 }
 __global__ __launch_bounds__(64) void k_cforward(Params P) {
     __shared__ double xs[64 * 13], cs[64 * 13];
@@ -2124,7 +2149,7 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {       // MODE 0: used wh
     __shared__ double btile[4][64];
     qp_wave<0>(P, wtile, btile, blockIdx.x);
 }
-__global__ __launch_bounds__(64) void k_as(Params P) {        // active-set solves
+KALIGN __global__ __launch_bounds__(64) void k_as(Params P) {        // active-set solves
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
     qp_wave<1>(P, wtile, btile, blockIdx.x);
@@ -2980,7 +3005,8 @@ void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev) {
         hipLaunchKernelGGL(k_forward_rg, dim3(P.NW), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_rank, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     } else {
-        hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+        if (P.forward_div) hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+        else hipLaunchKernelGGL(k_forward_mid, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     }
     if (ev) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_compact, dim3(N_BIN), dim3(256), 0, st, P);

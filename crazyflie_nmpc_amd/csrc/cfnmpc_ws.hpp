@@ -111,6 +111,7 @@ struct Params {
     // stage-chunked hand-over experiment (cfnmpc_debug_chunked_pair): stage ranges of k_linearise / k_factor_chunk
     int lin_k0, lin_k1, fk_lo, fk_hi;
     double *Ppark;               // cost-to-go between the chunks, [wave][13][64]
+    int forward_div;             // 1: k_forward (division form: fleets that stream at the HBM rate), 0: k_forward_mid; see forward_body
     int forward_rg;              // 1: forward sweep of the start solve on the stored blocks (k_forward_rg; small fleets)
     int cond_N2, cond_M, cond_rem;
     double *cb;                  // condensed blocks, [instance][block][cb_size(w_max)] (layout: cfnmpc_pcond.hip)
