@@ -255,12 +255,13 @@ __device__ __forceinline__ void sens_column(const JacPoint (&J)[4], const double
 //                   whose iterate only became final after the early pass over everybody).
 // Lanes without an instance work on the spare workspace block NW (finite data, never read).
 __host__ __device__ constexpr unsigned div_magic(int ns) { return (65536u + (unsigned)ns - 1u) / (unsigned)ns; }
-__host__ __device__ constexpr bool div_ok(int ns) {
-    for (unsigned e = 0; e < 64u * (unsigned)ns; e++)
+__host__ __device__ constexpr bool div_ok(int ns, unsigned n = 0) {   // exact for e < n (default: 64 * ns)
+    for (unsigned e = 0; e < (n ? n : 64u * (unsigned)ns); e++)
         if (((e * div_magic(ns)) >> 16) != e / (unsigned)ns || e * div_magic(ns) >= (1u << 24)) return false;
     return true;
 }
 static_assert(div_ok(13) && div_ok(10) && div_ok(6), "k_linearise: e / NS by multiply-shift");
+static_assert(div_ok(52, 64 * 13), "k_forward: e / 52 by multiply-shift");
 template <bool GATHER>
 __device__ __forceinline__ void linearise_body(const Params& P, double* sx, double (*sc)[64 * 13], int* sinst) {
     const int tid = threadIdx.x;
@@ -1134,8 +1135,8 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
     // element e = 13 * (local instance) + i of a 13-vector field with `stages` stages per block
     // (wave-uniform 64-bit base + 32-bit byte offset per lane: saddr form of the global access)
     auto el13 = [&](const double* f, int e, int stages, int k) -> gdouble* {
-        const int bk = e / 52, off = e - bk * 52;
-        const unsigned bo = (unsigned)(imin(bk, P.NW - w0) * (stages * SZ_V13) + off) * 8u;
+        const int bk = (int)(__umul24((unsigned)e, div_magic(52)) >> 16), off = e - bk * 52;   // e / 52 (24-bit multiplies, as in k_linearise)
+        const unsigned bo = (__umul24((unsigned)imin(bk, P.NW - w0), (unsigned)(stages * SZ_V13)) + (unsigned)off) * 8u;
         const char* base = (const char*)(gm(f) + ((size_t)w0 * stages + k) * SZ_V13);
         return (gdouble*)(base + bo);
     };
