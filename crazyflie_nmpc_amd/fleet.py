@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import NU, NX, NY
-from .solver import _arg, _check, default_opts
+from .solver import _arg, _check, default_opts, _launch_stream, _torch_device
 from .synthetic import regulation_row
 
 
@@ -27,6 +27,7 @@ class MixedHorizonFleet:
         _check(self._L.cfnmpc_fleet_create(C.byref(h), self.B, self.horizons.ctypes.data_as(C.c_void_p), C.byref(self.opts)),
                "cfnmpc_fleet_create")
         self._h = h
+        self._device = _torch_device()
         self.Nmin = self._L.cfnmpc_fleet_min_horizon(h)
         self.Nmax = self._L.cfnmpc_fleet_max_horizon(h)
 
@@ -108,10 +109,10 @@ class MixedHorizonFleet:
         return cmd_vel, motvel
 
     def init_iterate(self, mode, stream=None):
-        _check(self._L.cfnmpc_fleet_init_iterate(self._h, int(mode), C.c_void_p(stream or 0)), "cfnmpc_fleet_init_iterate")
+        _check(self._L.cfnmpc_fleet_init_iterate(self._h, int(mode), _launch_stream(stream, self._device)), "cfnmpc_fleet_init_iterate")
 
     def solve(self, n_rti=1, stream=None):
-        _check(self._L.cfnmpc_fleet_solve(self._h, int(n_rti), C.c_void_p(stream or 0)), "cfnmpc_fleet_solve")
+        _check(self._L.cfnmpc_fleet_solve(self._h, int(n_rti), _launch_stream(stream, self._device)), "cfnmpc_fleet_solve")
 
     def get_u(self, stage, out=None):
         if out is None:

@@ -51,6 +51,35 @@ def _stream_ptr(a):
     return C.c_void_p(torch.cuda.current_stream(a.device).cuda_stream)
 
 
+def _torch_device():
+    """torch's current HIP device if its runtime is up (a solver lives on the device current at its creation), else None"""
+    import sys
+    torch = sys.modules.get("torch")
+    try:
+        if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+            return int(torch.cuda.current_device())
+    except Exception:
+        pass
+    return None
+
+
+def _launch_stream(stream, device=None):
+    """Stream of a launch call: the caller's raw hipStream_t, else torch's CURRENT stream on the solver's device (the one
+    the device-tensor setters enqueue on: a `with torch.cuda.stream(s):` block keeps setters and solve in one queue),
+    else the default stream."""
+    if stream:
+        return C.c_void_p(stream)
+    if device is not None:
+        import sys
+        torch = sys.modules.get("torch")
+        try:
+            if torch is not None and torch.cuda.is_initialized():
+                return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        except Exception:
+            pass
+    return C.c_void_p(0)
+
+
 def _arg(a, shape, dtype=np.float64):
     """-> (pointer, on_device, stream, keepalive)"""
     if _is_torch(a):
@@ -74,6 +103,7 @@ class BatchSolver:
         h = C.c_void_p()
         _check(self._L.cfnmpc_create(C.byref(h), self.B, C.byref(self.opts)), "cfnmpc_create")
         self._h = h
+        self._device = _torch_device()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -138,7 +168,7 @@ class BatchSolver:
         _check(self._L.cfnmpc_set_box_stages(self._h, p, pu, dev, st), "cfnmpc_set_box_stages")
 
     def init_iterate(self, mode=INIT_ACADOS, stream=None):
-        _check(self._L.cfnmpc_init_iterate(self._h, mode, C.c_void_p(stream or 0)), "cfnmpc_init_iterate")
+        _check(self._L.cfnmpc_init_iterate(self._h, mode, _launch_stream(stream, self._device)), "cfnmpc_init_iterate")
 
     def set_iterate(self, x, u):
         p, dev, st, _k = _arg(x, (self.B, self.N + 1, NX))
@@ -149,7 +179,7 @@ class BatchSolver:
     # ---- solve
     def solve(self, n_rti=1, stream=None):
         """acados_solve() for the batch; `stream` is a raw hipStream_t (int) or None = default."""
-        _check(self._L.cfnmpc_solve(self._h, int(n_rti), C.c_void_p(stream or 0)), "cfnmpc_solve")
+        _check(self._L.cfnmpc_solve(self._h, int(n_rti), _launch_stream(stream, self._device)), "cfnmpc_solve")
 
     def step_host(self, x0, yref, yref_e, stream=None):
         """cfnmpc_step_host: host arrays in (x0 [B,13], yref [B,N,17], yref_e [B,13]), one RTI step,
@@ -161,7 +191,7 @@ class BatchSolver:
         st = np.empty(self.B, dtype=np.int32); it = np.empty(self.B, dtype=np.int32); rs = np.empty(self.B)
         vp = lambda a: a.ctypes.data_as(C.c_void_p)
         _check(self._L.cfnmpc_step_host(self._h, vp(x0), vp(yref), vp(yref_e), vp(u), vp(x), vp(st), vp(it), vp(rs),
-                                        C.c_void_p(stream or 0)), "cfnmpc_step_host")
+                                        _launch_stream(stream, self._device)), "cfnmpc_step_host")
         return u, x, st, it, rs
 
     def set_profiling(self, enable=True):
@@ -180,7 +210,7 @@ class BatchSolver:
         return [float(v) for v in ms], n.value
 
     def linearise_only(self, stream=None):
-        _check(self._L.cfnmpc_debug_linearise(self._h, C.c_void_p(stream or 0)), "cfnmpc_debug_linearise")
+        _check(self._L.cfnmpc_debug_linearise(self._h, _launch_stream(stream, self._device)), "cfnmpc_debug_linearise")
 
     # ---- outputs
     def get_iterate(self):

@@ -803,3 +803,37 @@ def test_reinit_failed_option_recovers_a_lost_instance(oracle):
     assert np.abs(xa[4] - xf[0]).max() < 1e-9 and np.abs(ua[4] - uf[0]).max() < 1e-9
     with pytest.raises(Exception):
         BatchSolver(4, default_opts(reinit_failed=1, overlap_linearise=1))
+
+
+def test_calls_without_a_stream_argument_follow_torchs_current_stream(oracle):
+    """The Python wrapper's launch calls (init_iterate, solve) take torch's CURRENT stream when none is passed -- the stream
+    the device-tensor setters and getters enqueue on -- so a closed loop written inside `with torch.cuda.stream(s):` is one
+    queue (it used to put the launches on the default stream and the setters on `s`: a race with non-blocking streams)."""
+    import torch
+    from crazyflie_nmpc_amd import BatchSolver, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 4099, 50
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=77, scale=1.5)
+    dev = torch.device("cuda", 0)
+
+    def loop(stream):
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.default_stream(dev))
+        with ctx:
+            s = BatchSolver(B)
+            x = torch.from_numpy(x0).to(dev); xn = torch.empty_like(x)
+            u = torch.empty((B, 4), dtype=torch.float64, device=dev)
+            s.set_yref(torch.from_numpy(yref).to(dev), torch.from_numpy(yref_e).to(dev))
+            s.set_x0(x); s.init_iterate(INIT_HOVER)
+            for _ in range(6):
+                s.set_x0(x); s.solve(1); s.get_u(0, out=u); sim(x, u, T=0.015, steps=1, out=xn); x, xn = xn, x
+            (stream or torch.cuda.current_stream(dev)).synchronize()
+            st = s.stats()[0]
+            out = x.cpu().numpy(), u.cpu().numpy(), st.copy()
+            s.close()
+        return out
+
+    torch.cuda.synchronize()
+    xa, ua, sa = loop(None)
+    xb, ub, sb = loop(torch.cuda.Stream(dev))
+    assert (sa == 0).all() and (sb == 0).all()
+    assert np.array_equal(xa, xb) and np.array_equal(ua, ub)
