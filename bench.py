@@ -513,6 +513,12 @@ def main():
                          "kernels_ms": dict(zip(("k_linearise", "k_factor", "k_forward", "k_compact+k_scatter",
                                                  "k_as (active-set solves, roll-out)", "k_ipm_rest (interior-point fall-back)"), r["kms"])),
                          "traffic_over_alg": (traffic / (alg_bytes_step(N) * B_launch)) if traffic else None,
+                         # the survey's LOWER bound for reference (section 8d): an engine that never materialised the stage
+                         # blocks would still move x0, yref, the iterate in and out and the status = 8 (51 N + 54) bytes
+                         "compulsory_io": {"bytes_per_instance": 8 * (51 * N + 54),
+                                           "achieved": 8 * (51 * N + 54) * B_launch / (ms_step * 1e-3) / 1e9, "unit": "GB/s",
+                                           "frac": 8 * (51 * N + 54) * B_launch / (ms_step * 1e-3) / HBM_PEAK,
+                                           "traffic_over_compulsory": (traffic / (8 * (51 * N + 54) * B_launch)) if traffic else None},
                          "qp_phase": {"kernels": "k_factor + k_forward + k_compact + k_scatter + k_as + k_ipm_rest",
                                       "alg_bytes_per_launch": alg_bytes_qp(N) * B_launch, "achieved": ach_qp / 1e9,
                                       "frac": ach_qp / HBM_PEAK, "traffic": traffic_qp},
