@@ -516,7 +516,7 @@ def test_create_rejects_bad_options_and_windows_without_trajectory(oracle):
     assert np.array_equal(ref.get_u(0), s2.get_u(0))
 
 
-@pytest.mark.parametrize("B", [3, 130, 7000])
+@pytest.mark.parametrize("B", [3, 130, 7000, 8257])   # (8257: ragged, the default there is the matrix-free k_forward_mid)
 def test_forward_sweep_variants_agree(oracle, cref, B):
     """cfnmpc_opts.forward_sweep: the matrix-free forward sweep (1, the large-batch kernel) and the
     sweep on the stored blocks (2, the small-batch kernel) give the same closed loops to rounding --
