@@ -14,7 +14,7 @@ SYMBOLS = [
     "cfnmpc_default_opts", "cfnmpc_create", "cfnmpc_free", "cfnmpc_batch", "cfnmpc_horizon",
     "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_set_weights", "cfnmpc_set_box", "cfnmpc_get_cmd", "cfnmpc_set_yref_windows", "cfnmpc_init_iterate",
     "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_step_host", "cfnmpc_get_u", "cfnmpc_get_x",
-    "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_estimate", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise", "cfnmpc_debug_chunked_pair", "cfnmpc_debug_checksum",
+    "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_estimate", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise", "cfnmpc_debug_chunked_pair", "cfnmpc_debug_checksum", "cfnmpc_debug_start_factor", "cfnmpc_debug_get_factor",
     "cfnmpc_debug_get_head", "cfnmpc_debug_get_viol", "cfnmpc_debug_get_condensed", "cfnmpc_set_box_stages", "cfnmpc_set_profiling", "cfnmpc_get_profile", "cfnmpc_get_profile_kernels", "cfnmpc_version",
     "cfnmpc_fleet_create", "cfnmpc_fleet_free", "cfnmpc_fleet_batch", "cfnmpc_fleet_min_horizon", "cfnmpc_fleet_max_horizon",
     "cfnmpc_fleet_num_buckets", "cfnmpc_fleet_bucket", "cfnmpc_fleet_workspace_bytes", "cfnmpc_fleet_set_x0",
@@ -32,7 +32,7 @@ class Opts(C.Structure):
                 ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
                 ("lam0_min", C.c_double), ("mu0_scale", C.c_double), ("active_horizon", C.c_int), ("ah_margin", C.c_double),
-                ("ah_extra", C.c_int), ("overlap_linearise", C.c_int), ("active_set", C.c_int), ("forward_sweep", C.c_int), ("cond_N2", C.c_int), ("step_graph", C.c_int), ("as_passes", C.c_int), ("ipm_clip_viol", C.c_double), ("ipm_clip_margin", C.c_double), ("as_skip_viol", C.c_double), ("reinit_failed", C.c_int)]
+                ("ah_extra", C.c_int), ("overlap_linearise", C.c_int), ("active_set", C.c_int), ("forward_sweep", C.c_int), ("cond_N2", C.c_int), ("step_graph", C.c_int), ("as_passes", C.c_int), ("ipm_clip_viol", C.c_double), ("ipm_clip_margin", C.c_double), ("as_skip_viol", C.c_double), ("reinit_failed", C.c_int), ("start_solve", C.c_int)]
 
 
 _lib = None
@@ -90,6 +90,8 @@ def lib():
     L.cfnmpc_debug_linearise.argtypes = [vp, vp]
     L.cfnmpc_debug_chunked_pair.argtypes = [vp, i32, i32, vp, vp]
     L.cfnmpc_debug_checksum.argtypes = [vp, vp]
+    L.cfnmpc_debug_start_factor.argtypes = [vp, i32, i32, vp, vp]
+    L.cfnmpc_debug_get_factor.argtypes = [vp, vp, vp, vp, vp]
     L.cfnmpc_version.restype = C.c_char_p
     L.cfnmpc_fleet_create.argtypes = [C.POINTER(vp), i32, vp, C.POINTER(Opts)]
     for n in ("free", "batch", "min_horizon", "max_horizon", "num_buckets", "workspace_bytes"):

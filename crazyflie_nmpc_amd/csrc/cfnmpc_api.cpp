@@ -184,6 +184,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->ipm_clip_margin = 0.05;
     o->as_skip_viol = 4.0;
     o->reinit_failed = 0;
+    o->start_solve = 0;
 }
 
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
@@ -278,12 +279,13 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise) ||
         (o.reinit_failed && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
     P.forward_div = batch >= FORWARD_DIV_FROM ? 1 : 0;
-    P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && batch < FORWARD_RG_BELOW) ? 1 : 0;
+    // (an explicitly fused start solve stores no stage blocks: the automatic choice then stays with the matrix-free sweep)
+    P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && batch < FORWARD_RG_BELOW && o.start_solve != 2) ? 1 : 0;
     if (o.as_passes < -3 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
     // internal: 0 = monolithic k_as, -1 = every solve in one launch on the compact z store + commit, -2 = the monolithic
     // kernel's solves + commit, p > 0 = p single-solve passes
     P.as_passes = o.as_passes > 0 ? o.as_passes : (o.as_passes == -2 ? -1 : (o.as_passes == -3 ? -2 : 0));
-    if (o.as_passes == 0 && batch < AS_COMMIT_BELOW) P.as_passes = -2;   // small fleets: solves + commit kernel (measured)
+    if (o.as_passes == 0 && batch < AS_COMMIT_BELOW && o.start_solve != 2) P.as_passes = -2;   // small fleets: solves + commit kernel (measured); the commit kernel reads stored blocks
     if (const char* e = std::getenv("CFNMPC_AS_PASSES")) {   // development aid (internal encoding)
         const int v = std::atoi(e);
         if (v >= -2 && v <= 12) P.as_passes = v;
@@ -296,6 +298,17 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     // one fall-back row per wave is as fast as four while those waves fit one per SIMD (1024 rows: 1.6 % of 65 536 instances,
     // 2.5 % fall back at three times the bench's disturbances): only large fleets pay the compaction's extra launch
     P.ipm_listed = batch >= IPM_LIST_FROM ? 1 : 0;
+    // start solve: the fused kernel replaces k_linearise + k_factor where nothing but the constrained instances' QP kernels
+    // reads the stage blocks afterwards (matrix-free forward sweep, monolithic active-set kernel, no partial condensing,
+    // no overlapped preparation); per-stage boxes (cfnmpc_set_box_stages) switch a solver back at launch time
+    if (o.start_solve < 0 || o.start_solve > 3) { delete s; return CFNMPC_EINVAL; }
+    {
+        const bool can_fuse = !cond_N2 && !o.overlap_linearise && !P.forward_rg && P.as_passes == 0;
+        if (o.start_solve == 2 && !can_fuse) { delete s; return CFNMPC_EINVAL; }
+        if (o.start_solve == 3 && (cond_N2 || o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
+        P.fused = o.start_solve == 2 ? 1 : (o.start_solve == 3 ? 2 : 0);
+        P.clist_chunks = o.N >= 10 ? 10 : o.N;
+    }
     P.cond_N2 = cond_N2;
     P.cond_M = cond_N2 ? o.N / cond_N2 : 0;
     P.cond_rem = cond_N2 ? o.N % cond_N2 : 0;
@@ -316,6 +329,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(cSinv, NW * N * cfn::SZ_S); ALLOC(cd, NW * 4 * N * 4); ALLOC(cPchk, NW * cfn::N_CHK * cfn::SZ_P);
     ALLOC(cv, NW * 4 * N * 4); ALLOC(cuit, NW * 4 * N * 4); ALLOC(cGR, NW * N * cfn::SZ_K);
     ALLOC(cS, NW * N * cfn::SZ_S4); ALLOC(crho, NW * 4 * N * 4);
+    if (P.fused == 1) ALLOC(cbv, NW * N * cfn::SZ_V13);
     ALLOC(cPs, NW * 32 * cfn::SZ_PA);
     ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4); ALLOC(viol, NW * 4);
     ALLOC(ilist, NW * 4); ALLOC(ilist2, NW * 4); ALLOC(nipm, 64);
@@ -528,7 +542,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
                 hipGraph_t g = nullptr;
                 bool ok = hipStreamBeginCapture(s->cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
                 if (ok) {
-                    cfn::launch_linearise(s->P, s->chunks_all, s->cap);
+                    if (s->P.fused != 1 || s->P.lbs) cfn::launch_linearise(s->P, s->chunks_all, s->cap);
                     if (s->P.cond_N2) cfn::launch_qp_cond(s->P, s->cap);
                     else cfn::launch_qp(s->P, s->cap);
                     ok = hipStreamEndCapture(s->cap, &g) == hipSuccess && g != nullptr;   // (always ends the capture)
@@ -560,7 +574,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
         if (!s->overlap) {
             // linearise -> QP, everything on the caller's stream
             if (e) HIP_TRY(hipEventRecord(e[0], st));
-            cfn::launch_linearise(s->P, s->chunks_all, st);
+            if (s->P.fused != 1 || s->P.lbs) cfn::launch_linearise(s->P, s->chunks_all, st);   // (fused start solve: k_linfactor linearises)
             if (e) HIP_TRY(hipEventRecord(e[1], st));
             if (s->P.cond_N2) {
                 cfn::launch_qp_cond(s->P, st);   // pcond -> condensed Riccati -> expand (-> interior point)
@@ -828,6 +842,71 @@ int cfnmpc_debug_checksum(cfnmpc_solver* s, double* out3) {
         for (size_t i = 0; i < n[f]; i++) acc += h[i] * (double)(1 + (i % 7));
         out3[f] = acc;
     }
+    return CFNMPC_OK;
+}
+
+// Start solve, backward half only, for parity tests and timing: mode 1 = k_linearise + k_factor, mode 2 = k_linfactor;
+// `reps` repetitions timed with HIP events on `stream` (*ms = average per repetition; may be NULL).
+int cfnmpc_debug_start_factor(cfnmpc_solver* s, int mode, int reps, double* ms, void* stream) {
+    if (!s || (mode != 1 && mode != 2) || reps < 1) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; r++) {
+        if (mode == 1) {
+            cfn::launch_linearise(s->P, s->chunks_all, st);
+            cfn::launch_factor_only(s->P, st);
+        } else {
+            cfn::launch_linfactor(s->P, st);
+        }
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    if (ms) *ms = (double)t / reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIP_TRY(hipGetLastError());
+    s->lin_valid = mode == 1;
+    return CFNMPC_OK;
+}
+
+// What the start solve's backward sweep leaves behind, decoded into dense arrays in the EXTERNAL state order (host
+// pointers, any may be NULL): gains K [B][N][4][13], feed-forward d [B][N][4], cost-to-go checkpoints Pchk [B][6][13][13]
+// (stages 4, 8, 12, 16, 24, 32; only those below N are written by the kernels), status [B].
+int cfnmpc_debug_get_factor(cfnmpc_solver* s, double* K, double* d, double* Pchk, int* status) {
+    if (!s) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    const cfn::Params& P = s->P;
+    const size_t NW = P.NW, N = P.N, B = P.B;
+    HIP_TRY(hipDeviceSynchronize());
+    if (K) {
+        std::vector<double> h(NW * N * cfn::SZ_K);
+        HIP_TRY(hipMemcpy(h.data(), P.KR, h.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < B; i++)
+            for (size_t k = 0; k < N; k++) {
+                const double* kb = h.data() + ((i / 4) * N + k) * cfn::SZ_K;
+                for (int l = 0; l < 13; l++)
+                    for (int a = 0; a < 4; a++) K[((i * N + k) * 4 + a) * 13 + cfn::ext_of(l)] = kb[(l * 4 + (i % 4)) * 4 + a];
+            }
+    }
+    if (d) HIP_TRY(hipMemcpy(d, P.d, B * N * 4 * 8, hipMemcpyDeviceToHost));
+    if (Pchk) {
+        std::vector<double> h(NW * cfn::N_CHK * cfn::SZ_P);
+        HIP_TRY(hipMemcpy(h.data(), P.Pchk, h.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < B; i++)
+            for (int c = 0; c < cfn::N_CHK; c++) {
+                const double* pb = h.data() + ((i / 4) * cfn::N_CHK + c) * cfn::SZ_P;
+                for (int j = 0; j < 13; j++)
+                    for (int r = 0; r < 13; r++)
+                        Pchk[((i * cfn::N_CHK + c) * 13 + cfn::ext_of(r)) * 13 + cfn::ext_of(j)] = pb[(j * 4 + (i % 4)) * 13 + r];
+            }
+    }
+    if (status) HIP_TRY(hipMemcpy(status, P.status, B * sizeof(int), hipMemcpyDeviceToHost));
     return CFNMPC_OK;
 }
 

@@ -39,180 +39,9 @@
 //   k_put / k_get / k_init_iterate / k_windows : layout glue and reference windows for the C-ABI.
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
+#include "cfnmpc_rg.hpp"
 
-#include "cfnmpc_dpp.hpp"
-#include "cfnmpc_model.hpp"
-#include "cfnmpc_ws.hpp"
-
-#ifndef KALIGN_BYTES
-#define KALIGN_BYTES 4096
-#endif
-#define KALIGN __attribute__((aligned(KALIGN_BYTES)))
 namespace cfn {
-
-// ---------------------------------------------------------------------------------------------
-// small tools
-// ---------------------------------------------------------------------------------------------
-template <int I, int N, class F>
-__device__ __forceinline__ void sfor(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        sfor<I + 1, N>(f);
-    }
-}
-#define SFOR(var, lo, hi, ...) sfor<lo, hi>([&](auto var##_) { constexpr int var = decltype(var##_)::value; __VA_ARGS__ })
-
-// value of v in lane L of the caller's 16-lane row (v_mov_b64_dpp row_newbcast:L)
-template <int L>
-__device__ __forceinline__ double bc(double v) {
-    const long long x = __builtin_bit_cast(long long, v);
-    const long long r = __builtin_amdgcn_update_dpp((long long)0, x, 0x150 + L, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, r);
-}
-// lane i of every row <- lane i + 4 (row_shl:4; lanes 12..15 get 0)
-__device__ __forceinline__ double shift4(const double v) {
-    const long long x = __builtin_bit_cast(long long, v);
-    const long long r = __builtin_amdgcn_update_dpp((long long)0, x, 0x104, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, r);
-}
-__device__ __forceinline__ double row_sum(double x) {
-    double s = 0.0;
-    SFOR(l, 0, 16, { s += bc<l>(x); });
-    return s;
-}
-__device__ __forceinline__ double row_min(double x) {
-    double s = x;
-    SFOR(l, 0, 16, { s = fmin(s, bc<l>(x)); });
-    return s;
-}
-__device__ __forceinline__ double row_max(double x) {
-    double s = x;
-    SFOR(l, 0, 16, { s = fmax(s, bc<l>(x)); });
-    return s;
-}
-
-__device__ __forceinline__ double lane_wu(const Params& P, int a) {
-    double w = a == 0 ? P.W[13] : (a == 1 ? P.W[14] : (a == 2 ? P.W[15] : P.W[16]));
-    asm volatile("" : "+v"(w));
-    return w;
-}
-struct Lane {
-    int L;      // lane in row: 0..12 state rows, 13 affine row, 14/15 idle
-    int row;    // DPP row of this lane inside the wavefront, 0..3 (LDS tile index)
-    int q;      // position of the instance inside its workspace block, 0..3
-    int wave;   // workspace block (= "home" wave) of the instance
-    int inst;   // global instance
-    bool valid;
-    double wu;  // input weight R_a of this lane's input slot a = L & 3 (kept in a register: a select
-                // chain at the point of use gets turned into a lookup table in scratch, whose load
-                // then sits in the middle of the prefetch queue of every stage)
-};
-__device__ __forceinline__ Lane lane_id(const Params& P) {
-    Lane t;
-    t.L = threadIdx.x & 15;
-    t.row = threadIdx.x >> 4;
-    t.q = t.row;
-    t.wave = blockIdx.x;
-    t.inst = t.wave * 4 + t.q;
-    t.valid = t.inst < P.B;
-    t.wu = lane_wu(P, t.L & 3);
-    return t;
-}
-// Row r of this wavefront works on an arbitrary instance (compacted interior-point waves);
-// rows without work are parked on the spare workspace block NW (never read by anyone else).
-__device__ __forceinline__ Lane lane_indirect(const Params& P, int inst, bool valid) {
-    Lane t;
-    t.L = threadIdx.x & 15;
-    t.row = threadIdx.x >> 4;
-    t.inst = valid ? inst : P.NW * 4 + t.row;
-    t.wave = t.inst >> 2;
-    t.q = t.inst & 3;
-    t.valid = valid;
-    t.wu = lane_wu(P, t.L & 3);
-    return t;
-}
-// Workspace pointers live inside the by-value Params struct, where clang cannot infer the
-// address space: gm() re-types them as global (address_space(1)) so that loads / stores are
-// global_* instead of flat_*.
-typedef __attribute__((address_space(1))) double gdouble;
-typedef __attribute__((address_space(1))) int gint;
-__device__ __forceinline__ gdouble* gm(double* p) { return (gdouble*)(unsigned long long)p; }
-__device__ __forceinline__ const gdouble* gm(const double* p) { return (const gdouble*)(unsigned long long)p; }
-__device__ __forceinline__ gint* gm(int* p) { return (gint*)(unsigned long long)p; }
-// (wave, stage) block of a field
-__device__ __forceinline__ gdouble* blk(double* f, const Lane& t, int nst, int k, int sz) {
-    return gm(f) + ((size_t)t.wave * nst + k) * sz;
-}
-// hides a value from common-subexpression elimination (keeps broadcast temporaries short-lived)
-__device__ __forceinline__ void opaque(double& x) { asm volatile("" : "+v"(x)); }
-// a value produced by one of the asm primitives of cfnmpc_dpp.hpp is about to be read through
-// DPP by compiler-generated code (bc<>): give it the two wait states hipcc cannot know about
-__device__ __forceinline__ void settle(double& x) { asm volatile("s_nop 1" : "+v"(x)); }
-// makes a value live in every lane at this point (stops the compiler from sinking the load that
-// produced it into a divergent branch)
-__device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
-// instance-major 4-vectors (interior-point state, inputs): [inst][stage][4]
-__device__ __forceinline__ size_t i4(const Params& P, const Lane& t, int k, int a) {
-    return ((size_t)t.inst * P.N + k) * 4 + a;
-}
-
-// Input box of element idx (instance-major 4-vector index in P's own indexing): the scalar box of cfnmpc_set_box,
-// or -- SBOX, kernels instantiated for cfnmpc_set_box_stages -- the per-stage, per-input arrays (acados' "lbu" /
-// "ubu" on individual stages, acados_mpc.cpp:605-608).
-template <bool SBOX>
-__device__ __forceinline__ void box_at(const Params& P, const size_t idx, double& lo, double& hi) {
-    if (SBOX) { lo = gm(P.lbs)[idx]; hi = gm(P.ubs)[idx]; }
-    else { lo = P.u_min; hi = P.u_max; }
-}
-
-// Loads are branch-free: every lane reads a valid (clamped) address and lanes outside the
-// stored range select 0 -- exec-masked loads would split the unrolled code into tiny blocks.
-__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ double ld13(const gdouble* b, const Lane& t) {
-    const double v = b[t.q * 13 + imin(t.L, 12)];
-    return t.L < 13 ? v : 0.0;
-}
-__device__ __forceinline__ void st13(gdouble* b, const Lane& t, double v) { if (t.L < 13) b[t.q * 13 + t.L] = v; }
-
-__device__ __forceinline__ void ld_ar(const gdouble* b, const Lane& t, double (&ar)[10]) {
-    SFOR(s, 0, 10, {
-        const double v = b[4 * ar_pre(s) + t.q * ar_n(s) + imin(t.L, ar_n(s) - 1)];
-        ar[s] = t.L < ar_n(s) ? v : 0.0;
-    });
-}
-// Unmasked variants: for operands that are consumed ONLY as DPP broadcast sources (always read
-// from lanes inside the stored range) the out-of-range lanes may hold anything -- no selects.
-__device__ __forceinline__ void ld_ar_raw(const gdouble* b, const Lane& t, double (&ar)[10]) {
-    SFOR(s, 0, 10, { ar[s] = b[4 * ar_pre(s) + t.q * ar_n(s) + imin(t.L, ar_n(s) - 1)]; });
-}
-__device__ __forceinline__ void ld_rows4_raw(const gdouble* b, const Lane& t, double (&r)[4]) {
-    SFOR(a, 0, 4, { r[a] = b[(a * 4 + t.q) * 13 + imin(t.L, 12)]; });
-}
-__device__ __forceinline__ void ld_cols4_raw(const gdouble* b, const Lane& t, double (&c)[13]) {
-    SFOR(l, 0, 13, { c[l] = b[(l * 4 + t.q) * 4 + (t.L & 3)]; });
-}
-__device__ __forceinline__ void ld_rows4(const gdouble* b, const Lane& t, double (&r)[4]) {  // BR / KP
-    SFOR(a, 0, 4, {
-        const double v = b[(a * 4 + t.q) * 13 + imin(t.L, 12)];
-        r[a] = t.L < 13 ? v : 0.0;
-    });
-}
-__device__ __forceinline__ void ld_cols4(const gdouble* b, const Lane& t, double (&c)[13]) {  // BC / KR
-    SFOR(l, 0, 13, {
-        const double v = b[(l * 4 + t.q) * 4 + (t.L & 3)];
-        c[l] = t.L < 4 ? v : 0.0;
-    });
-}
-
-// select element `idx` (runtime) of a register array
-template <int N>
-__device__ __forceinline__ double pick(const double (&a)[N], int idx) {
-    double r = 0.0;
-    SFOR(j, 0, N, { r = (idx == j) ? a[j] : r; });
-    return r;
-}
 
 // =============================================================================================
 // linearisation
@@ -262,15 +91,21 @@ __host__ __device__ constexpr bool div_ok(int ns, unsigned n = 0) {   // exact f
 }
 static_assert(div_ok(13) && div_ok(10) && div_ok(6), "k_linearise: e / NS by multiply-shift");
 static_assert(div_ok(52, 64 * 13), "k_forward: e / 52 by multiply-shift");
-template <bool GATHER>
-__device__ __forceinline__ void linearise_body(const Params& P, double* sx, double (*sc)[64 * 13], int* sinst) {
+//   CSTORE (with GATHER): the results go to the COMPACT store of the constrained-QP kernels (P.cAR, P.cBR, P.cbv; list
+//                   slot c owns row c & 3 of compact block c >> 2, i.e. 64 consecutive slots = 16 consecutive blocks,
+//                   written in the same contiguous runs as the home blocks) -- the fused start solve never stores
+//                   (A, B, b), so the instances whose QP needs them again get them here (k_linearise_clist);
+//                   which = 0: P.ilist (count P.nipm[0]), 1: P.ilist2 (P.nipm[40], the interior-point fall-back rows).
+template <bool GATHER, bool CSTORE = false>
+__device__ __forceinline__ void linearise_body(const Params& P, double* sx, double (*sc)[64 * 13], int* sinst,
+                                               const int which = 0) {
     const int tid = threadIdx.x;
     const double h = P.dt;
     const int N = P.N;
     {
         const int li = blockIdx.x * 64 + tid;
         int inst;
-        if (GATHER) inst = li < gm(P.nipm)[0] ? gm(P.ilist)[li] : P.NW * 4 + (tid & 3);
+        if (GATHER) inst = li < gm(P.nipm)[which ? 40 : 0] ? gm(which ? P.ilist2 : P.ilist)[li] : P.NW * 4 + (tid & 3);
         else inst = li < P.NW * 4 ? li : P.NW * 4 + (tid & 3);
         sinst[tid] = inst;
     }
@@ -287,8 +122,8 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     // Consecutive instances: a wave-uniform 64-bit base (scalar registers) + a 32-bit byte offset
     // per lane (one multiply-add instead of four 64-bit operations per element; 16 blocks x stages x
     // SZ x 8 bytes < 4 GB for any admissible horizon), i.e. the saddr form of global_load / store.
-    auto el = [&](double* field, int li, int i, int stages, int k, int SZ, int pre4, int NS) -> gdouble* {
-        if (GATHER) {
+    auto el = [&](double* field, int li, int i, int stages, int k, int SZ, int pre4, int NS, bool home = true) -> gdouble* {
+        if (GATHER && (home || !CSTORE)) {
             const int in = sinst[li];
             return gm(field) + ((size_t)(in >> 2) * stages + k) * SZ + pre4 + (in & 3) * NS + i;
         }
@@ -369,10 +204,10 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         SFOR(r, 0, NS, {                                                                                \
             const int e = tl + 64 * r;                                                                  \
             const int li = CFN_DIV(e, NS), i = e - li * (NS);                                          \
-            *el(field, li, i, N, k, SZ, pre4, NS) = tv[r];                                              \
+            *el(field, li, i, N, k, SZ, pre4, NS, false) = tv[r];                                       \
         });                                                                                             \
     }
-        CFN_STORE(P.b, SZ_V13, 0, 13, 0);
+        CFN_STORE(CSTORE ? P.cbv : P.b, SZ_V13, 0, 13, 0);
         double col[13];
         // state columns in internal order: v (internal 3..5 = external 7..9), q (6..9 = 3..6), w (10..12)
         __syncthreads();
@@ -383,7 +218,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
             SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
         }
         __syncthreads();
-        SFOR(j, 0, 3, { CFN_STORE(P.AR, SZ_A, j, ar_n(j), 4 * ar_pre(j)); });
+        SFOR(j, 0, 3, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(j), 4 * ar_pre(j)); });
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < 4; j++) {  // quaternion columns: rows p, v, q
@@ -391,7 +226,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
             SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
         }
         __syncthreads();
-        SFOR(j, 0, 4, { CFN_STORE(P.AR, SZ_A, j, ar_n(3 + j), 4 * ar_pre(3 + j)); });
+        SFOR(j, 0, 4, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(3 + j), 4 * ar_pre(3 + j)); });
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < 3; j++) {  // rate columns: all rows
@@ -399,7 +234,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
             SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
         }
         __syncthreads();
-        SFOR(j, 0, 3, { CFN_STORE(P.AR, SZ_A, j, ar_n(7 + j), 4 * ar_pre(7 + j)); });
+        SFOR(j, 0, 3, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(7 + j), 4 * ar_pre(7 + j)); });
         __syncthreads();
 #pragma unroll 1
         for (int a = 0; a < 4; a++) {  // input columns: all rows
@@ -411,7 +246,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         issue_x(imin(k + 2, N), tl, xr);
         issue_u(imin(k + 1, N - 1), un);
         __syncthreads();
-        SFOR(a, 0, 4, { CFN_STORE(P.BR, SZ_B, a, 13, a * 52); });
+        SFOR(a, 0, 4, { CFN_STORE(CSTORE ? P.cBR : P.BR, SZ_B, a, 13, a * 52); });
         land_x(xr);
         __syncthreads();
 #undef CFN_STORE
@@ -431,231 +266,14 @@ __global__ __launch_bounds__(64) void k_linearise_list(Params P) {
     if ((int)blockIdx.x * 64 >= gm(P.nipm)[0]) return;
     linearise_body<true>(P, sx, sc, sinst);
 }
-
-// =============================================================================================
-// Riccati sweeps
-// =============================================================================================
-// 1/sqrt(s) to full double accuracy: hardware estimate + two Newton steps (no IEEE div / sqrt
-// sequences in the per-stage critical path)
-__device__ __forceinline__ double rsqrt_nr(double s) {
-    double y = __builtin_amdgcn_rsq(s);
-    const double hs = 0.5 * s;
-    y = y * (1.5 - hs * y * y);
-    y = y * (1.5 - hs * y * y);
-    return y;
-}
-// 1/x to full double accuracy: hardware estimate + two Newton steps (instead of the IEEE
-// division sequence; the interior-point iteration is self-correcting at rounding level)
-__device__ __forceinline__ double rcp_nr(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = r * (2.0 - x * r);
-    r = r * (2.0 - x * r);
-    return r;
-}
-// Symmetric positive definite 4x4 (packed upper) -> inverse (packed upper) by Cholesky, in stages,
-// so that the caller can place independent work between the four pivots (each is a dependent
-// chain through v_rsq_f64 and two Newton steps; with one or two waves per SIMD nothing else hides
-// that latency).  c.ok = false if a pivot is not positive.
-struct Chol4 {
-    double Lm[4][4], Li[4][4];
-    bool ok;
-};
-template <int J>
-__device__ __forceinline__ void chol4_pivot(const double (&S)[10], Chol4& c) {
-    double s = S[s4(J, J)];
-    SFOR(k, 0, J, { s -= c.Lm[J][k] * c.Lm[J][k]; });
-    c.ok = (J == 0 ? true : c.ok) && (s > 0.0);
-    const double inv = rsqrt_nr(s);   // 1 / L_jj
-    c.Lm[J][J] = s * inv;
-    c.Li[J][J] = inv;
-    SFOR(i, J + 1, 4, {
-        double tt = S[s4(i, J)];
-        SFOR(k, 0, J, { tt -= c.Lm[i][k] * c.Lm[J][k]; });
-        c.Lm[i][J] = tt * inv;
-    });
-}
-__device__ __forceinline__ void chol4_finish(Chol4& c, double (&Si)[10]) {
-    SFOR(j, 0, 4, {
-        SFOR(i, j + 1, 4, {
-            double tt = 0;
-            SFOR(k, j, i, { tt -= c.Lm[i][k] * c.Li[k][j]; });
-            c.Li[i][j] = tt * c.Li[i][i];
-        });
-    });
-    SFOR(i, 0, 4, {
-        SFOR(j, i, 4, {
-            double tt = 0;
-            SFOR(k, j, 4, { tt += c.Li[k][i] * c.Li[k][j]; });
-            Si[s4(i, j)] = tt;
-        });
-    });
+__global__ __launch_bounds__(64) void k_linearise_clist(Params P, int which) {
+    __shared__ double sx[64 * 13];
+    __shared__ double sc[4][64 * 13];
+    __shared__ int sinst[64];
+    if ((int)blockIdx.x * 64 >= gm(P.nipm)[which ? 40 : 0]) return;
+    linearise_body<true, true>(P, sx, sc, sinst, which);
 }
 
-// Everything one factorisation stage reads from HBM (so that the caller can prefetch it).
-template <bool ABSOLUTE>
-struct StageIn {
-    double ar[10], br[4];
-    double Rh, g;            // lanes a < 4: input Hessian diagonal / gradient element a
-    double bv, qv;           // ABSOLUTE: b_k[i] and q_k[i] = Q_i (x_k[i] - yref_k[i]) in lane i
-};
-// wq: this lane's state weight Q_i (lane i < 13), computed once per kernel
-template <bool ABSOLUTE>
-__device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const int k, const double wq,
-                                           StageIn<ABSOLUTE>& in) {
-    ld_ar_raw(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
-    ld_rows4_raw(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
-    const int a = t.L & 3;
-    if (ABSOLUTE) {
-        const double uk = gm(P.uit)[i4(P, t, k, a)];
-        const gdouble* yb = blk(P.yref, t, P.N, k, SZ_Y);
-        const double yr = yb[t.q * 17 + 13 + a];
-        const double wa = t.wu;
-        in.Rh = wa;                 // read in lanes a < 4 only
-        in.g = wa * (uk - yr);
-        in.bv = blk(P.b, t, P.N, k, SZ_V13)[t.q * 13 + imin(t.L, 12)];
-        const double xk = blk(P.xit, t, P.N + 1, k, SZ_V13)[t.q * 13 + imin(t.L, 12)];
-        const double yk = yb[t.q * 17 + imin(t.L, 12)];
-        in.qv = wq * (xk - yk);     // q_k[i] in lane i < 13
-    } else {
-        in.Rh = gm(P.Rh)[i4(P, t, k, a)];
-        in.g = gm(P.g)[i4(P, t, k, a)];
-        in.bv = 0.0;
-        in.qv = 0.0;
-    }
-}
-
-// LDS tile of the W transpose, one per row group: lane L writes its row W[L][0..12] as one
-// contiguous run (16-byte stores, row stride WT_ROW = 14 doubles: the 13 runs of a row group fall
-// on disjoint banks) and reads column l as wt[l * WT_ROW + L] (consecutive lanes = consecutive
-// banks).  WT_TILE = 204 doubles staggers the four row groups of a wave by 24 banks, so that their
-// 26-bank runs collide two-fold at most (they collided four-fold with a 224-double tile).
-constexpr int WT_ROW = 14, WT_TILE = 204;
-static_assert(WT_TILE >= 13 * WT_ROW && WT_TILE % 2 == 0, "W transpose tile");
-// One stage of the augmented backward recursion.
-//   Pa[13]: lanes 0..12 row i of P_{k+1}; lane 13 the affine row p_{k+1}' -- on exit the same for
-//           stage k.  ABSOLUTE: start solve with the QP's own affine terms (q_k, b_k, r_k);
-//   otherwise R^ and g come from the interior-point state (homogeneous Newton system).
-//   wt: LDS [13*17] (transpose of W), sb: LDS [4*16] (columns of B for lanes 0..3).
-//   ZL: the stage's outputs go to the instance-contiguous compact store of the level-synchronous
-//   active-set passes (t.inst = compact slot; layouts at zrow() below); act = false: compute only,
-//   store nothing (a row of a pass wave that has not joined the backward sweep yet).
-template <bool ABSOLUTE, bool AS = false, bool ZL = false>
-__device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, const int k, double (&Pa)[13],
-                                             const StageIn<ABSOLUTE>& in, const double wq, const double is13,
-                                             double* wt, double* sb, const bool act = true) {
-    const double(&ar)[10] = in.ar;
-    const double(&br)[4] = in.br;
-    if (ABSOLUTE) {
-        // hb' = p' + (P b)' in lane 13
-        double pb = 0.0;
-        dotbc<13, 0>(pb, Pa, in.bv);          // lanes 0..12: (P b)[i]
-        SFOR(j, 0, 13, { dotbc<1, j>(Pa[j], &is13, pb); });   // lane 13: p'[j] += (P b)[j]
-    }
-    // (1) W = Pa A (row form, instruction-level sparsity of A), (2) V = Pa B
-    double W[13], V[4];
-    SFOR(j, 0, 3, { W[j] = Pa[j]; });
-    SFOR(j, 3, 13, { W[j] = 0.0; });
-    dot2bc<6, 0>(W[3], W[4], Pa, ar[0], ar[1]);
-    dotbc<6, 0>(W[5], Pa, ar[2]);
-    dot2bc<10, 0>(W[6], W[7], Pa, ar[3], ar[4]);
-    dot2bc<10, 0>(W[8], W[9], Pa, ar[5], ar[6]);
-    dot2bc<13, 0>(W[10], W[11], Pa, ar[7], ar[8]);
-    dotbc<13, 0>(W[12], Pa, ar[9]);
-    // (3) Wt = transpose of W over lanes 0..12 through the LDS tile (lane 13 keeps the affine row);
-    //     the same round trip hands the columns of B to lanes 0..3.  The tile is written BEFORE V
-    //     is formed and S is formed BEFORE the transposed rows are used, so that both LDS
-    //     latencies sit behind 52 broadcast FMAs each.
-    double Wt[13];
-    __syncthreads();
-    if (t.L < 13) {
-        SFOR(j, 0, 13, { wt[t.L * WT_ROW + j] = W[j]; });
-        SFOR(a, 0, 4, { sb[a * 16 + t.L] = br[a]; });
-    }
-    SFOR(a, 0, 4, { V[a] = 0.0; });
-    dot2bc<13, 0>(V[0], V[1], Pa, br[0], br[1]);
-    dot2bc<13, 0>(V[2], V[3], Pa, br[2], br[3]);
-    __syncthreads();
-    double bcl[13];   // lanes >= 4 compute don't-care rows of S (never broadcast)
-    SFOR(l, 0, 13, { bcl[l] = sb[(t.L & 3) * 16 + l]; });
-    // (all 13 reads issued unconditionally, then pinned: otherwise the compiler sinks every
-    //  read into its own branch on "lane != 13")
-    SFOR(l, 0, 13, { Wt[l] = wt[l * WT_ROW + imin(t.L, 12)]; });
-    // (4) S = R^ + B'V in lanes a < 4, replicated; every lane inverts it redundantly (4x4 Cholesky),
-    //     one pivot at a time BETWEEN the blocks of (5) and (6), which hide the pivots' latency
-    double Srow[4];
-    SFOR(c, 0, 4, { Srow[c] = (t.L == c) ? in.Rh : 0.0; });
-    dot2bc<13, 0>(Srow[0], Srow[1], bcl, V[0], V[1]);
-    dot2bc<13, 0>(Srow[2], Srow[3], bcl, V[2], V[3]);
-    SFOR(c, 0, 4, { settle(Srow[c]); });
-    if (AS && t.L < 4 && act) {
-        gdouble* sr = ZL ? gm(P.cS) + ((size_t)t.inst * P.N + k) * 16 + t.L : blk(P.cS, t, P.N, k, SZ_S4) + t.q * 4 + t.L;
-        SFOR(c, 0, 4, { sr[c * (ZL ? 4 : 16)] = Srow[c]; });
-    }
-    double S[10], Si[10];
-    SFOR(a, 0, 4, { SFOR(c, a, 4, { S[s4(a, c)] = bc<a>(Srow[c]); }); });
-    SFOR(l, 0, 13, { pin(Wt[l]); });
-    SFOR(l, 0, 13, { Wt[l] = t.L == 13 ? Pa[l] : Wt[l]; });   // lanes 14, 15: don't-care (never broadcast)
-    Chol4 ch;
-    chol4_pivot<0>(S, ch);
-    // (5) M = Q + Wt A  (lane 13: q_k' + hb'A)
-    double M[13];
-    SFOR(j, 0, 13, { M[j] = (t.L == j) ? wq : 0.0; });
-    if (ABSOLUTE) SFOR(j, 0, 13, { dotbc<1, j>(M[j], &is13, in.qv); });   // lane 13: += q_k[j]
-    SFOR(j, 0, 3, { M[j] += Wt[j]; });
-    dot2bc<6, 0>(M[3], M[4], Wt, ar[0], ar[1]);
-    dotbc<6, 0>(M[5], Wt, ar[2]);
-    chol4_pivot<1>(S, ch);
-    dot2bc<10, 0>(M[6], M[7], Wt, ar[3], ar[4]);
-    dot2bc<10, 0>(M[8], M[9], Wt, ar[5], ar[6]);
-    chol4_pivot<2>(S, ch);
-    dot2bc<13, 0>(M[10], M[11], Wt, ar[7], ar[8]);
-    dotbc<13, 0>(M[12], Wt, ar[9]);
-    chol4_pivot<3>(S, ch);
-    // (6) G' = Wt B ; lane 13: rho = g + B'hb
-    double Gp[4];
-    SFOR(a, 0, 4, { Gp[a] = 0.0; });
-    dot2bc<13, 0>(Gp[0], Gp[1], Wt, br[0], br[1]);
-    dot2bc<13, 0>(Gp[2], Gp[3], Wt, br[2], br[3]);
-    SFOR(a, 0, 4, { dotbc<1, a>(Gp[a], &is13, in.g); });   // lane 13: += g[a]
-    if (AS) {
-        // active-set solve: the forward sweep evaluates the multipliers of the fixed inputs from the
-        // stage's own blocks, B'pi_{k+1} = G dx_k + (B'PB) du_free + rho -- keep G (gain layout),
-        // rho (lane 13) and the rows of S (off-diagonal entries = B'PB, untouched by the fixing weight)
-        gdouble* gr = ZL ? gm(P.cGR) + ((size_t)t.inst * P.N + k) * 52 + imin(t.L, 12) * 4
-                         : blk(P.cGR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
-        gdouble* dst = t.L == 13 ? gm(P.crho) + i4(P, t, k, 0) : gr;
-        if (t.L < 14 && act) SFOR(a, 0, 4, { dst[a] = Gp[a]; });
-    }
-    chol4_finish(ch, Si);
-    const bool ok = ch.ok;
-    // (7) K' = G' Sinv  (lane 13: feed-forward d)
-    double Kp[4], nGp[4];
-    SFOR(a, 0, 4, {
-        double s = 0.0;
-        SFOR(c, 0, 4, { s += Gp[c] * Si[s4(c, a)]; });
-        Kp[a] = s;
-        nGp[a] = -Gp[a];
-    });
-    // (8) P <- M - G' K  (lane 13: p' <- M_13 - rho' K)
-    SFOR(j, 0, 13, {
-        Pa[j] = M[j];
-        updbc<j>(Pa[j], Kp, nGp);
-    });
-    // (9) stores: gain in "lane a holds K[a][.]" form, Sinv, feed-forward
-    {
-        // lanes 0..12 store their column of the gain, lane 13 the feed-forward: one masked
-        // region with per-lane addresses
-        gdouble* kr = ZL ? gm(P.KR) + ((size_t)t.inst * P.N + k) * 52 + imin(t.L, 12) * 4
-                         : blk(P.KR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
-        gdouble* dst = t.L == 13 ? gm(P.d) + i4(P, t, k, 0) : kr;
-        if (t.L < 14 && act) SFOR(a, 0, 4, { dst[a] = Kp[a]; });
-        if (!ABSOLUTE && t.L == 0) {  // only the corrector of the interior-point iteration reads it
-            gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S);
-            SFOR(e, 0, 10, { sv[t.q * 10 + e] = Si[e]; });
-        }
-    }
-    return ok;
-}
 
 // Backward factorisation over stages [0, head), next stage prefetched while the current one is
 // computed.  chk >= 0: start from a stored checkpoint of the unconstrained tail (P.Pchk, affine
@@ -1636,7 +1254,10 @@ __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave
 // than this kernel's registers allow: for small fleets, where the roll-out is a latency chain).
 // vb: index of the compact block (group of four list slots) this call works on -- the workgroup index, or the running
 // index of a grid-stride loop (k_ipm_rest: a small fixed grid instead of one mostly idle workgroup per four instances)
-template <int MODE, bool SBOX = false>
+// CST (fused start solve, Params.fused = 1): the instance's (A, B, b) of ALL stages are already in the wave's compact blocks
+// (k_linearise_clist wrote them there; the home blocks hold none) -- nothing to gather but the 4-vectors and the
+// checkpoint, and the roll-out reads the compact copy over the whole horizon.
+template <int MODE, bool SBOX = false, bool CST = false>
 __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64], const int vb) {
 #ifdef CFN_PROF
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
@@ -1688,8 +1309,10 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             double ar[4][10], br[4][4], vv[4], uu[4], blo[4], bhi[4];
             SFOR(j, 0, 4, {
                 const int k = imin(k0 + j, hd - 1);
-                ld_ar(blk(P.AR, t, N, k, SZ_A), t, ar[j]);
-                ld_rows4(blk(P.BR, t, N, k, SZ_B), t, br[j]);
+                if (!CST) {
+                    ld_ar(blk(P.AR, t, N, k, SZ_A), t, ar[j]);
+                    ld_rows4(blk(P.BR, t, N, k, SZ_B), t, br[j]);
+                }
                 vv[j] = gm(P.v)[i4(P, t, k, t.L & 3)];
                 uu[j] = gm(P.uit)[i4(P, t, k, t.L & 3)];
                 box_at<SBOX>(P, i4(P, t, k, t.L & 3), blo[j], bhi[j]);
@@ -1697,10 +1320,12 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             SFOR(j, 0, 4, {
                 const int k = k0 + j;
                 if (k < hd) {
-                    gdouble* ca = blk(Q.AR, tc, N, k, SZ_A);
-                    SFOR(sl, 0, 10, { if (t.L < ar_n(sl)) ca[4 * ar_pre(sl) + tc.q * ar_n(sl) + t.L] = ar[j][sl]; });
-                    gdouble* cb = blk(Q.BR, tc, N, k, SZ_B);
-                    SFOR(a, 0, 4, { if (t.L < 13) cb[(a * 4 + tc.q) * 13 + t.L] = br[j][a]; });
+                    if (!CST) {
+                        gdouble* ca = blk(Q.AR, tc, N, k, SZ_A);
+                        SFOR(sl, 0, 10, { if (t.L < ar_n(sl)) ca[4 * ar_pre(sl) + tc.q * ar_n(sl) + t.L] = ar[j][sl]; });
+                        gdouble* cb = blk(Q.BR, tc, N, k, SZ_B);
+                        SFOR(a, 0, 4, { if (t.L < 13) cb[(a * 4 + tc.q) * 13 + t.L] = br[j][a]; });
+                    }
                     if (t.L < 4) {
                         gm(Q.v)[i4(Q, tc, k, t.L)] = vv[j];
                         gm(Q.uit)[i4(Q, tc, k, t.L)] = uu[j];
@@ -2010,7 +1635,15 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             // head stages take A, B from the wave's compact copy (the home blocks are interleaved with the three wave-mates:
             // three quarters of every cache line foreign) and need no gain; b and the tail come from the home blocks
             auto load_roll = [&](int k, FwdIn<true>& in) {
-                if (k < head) {
+                if (CST) {   // everything but the start solve's gains from the compact copy
+                    ld_ar(blk(Q.AR, tc, N, k, SZ_A), tc, in.ar);
+                    ld_rows4(blk(Q.BR, tc, N, k, SZ_B), tc, in.br);
+                    in.bv = ld13(blk(P.cbv, tc, N, k, SZ_V13), tc);
+                    if (k >= head) {
+                        ld_cols4(blk(P.KR, t, N, k, SZ_K), t, in.kr);
+                        in.d = gm(P.d)[i4(P, t, k, t.L & 3)];
+                    }
+                } else if (k < head) {
                     ld_ar(blk(Q.AR, tc, N, k, SZ_A), tc, in.ar);
                     ld_rows4(blk(Q.BR, tc, N, k, SZ_B), tc, in.br);
                     in.bv = ld13(blk(P.b, t, N, k, SZ_V13), t);
@@ -2175,6 +1808,22 @@ __global__ __launch_bounds__(64) void k_ipm_rest_sbox(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
     for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[P.ipm_listed ? 40 : 0]; vb += gridDim.x) qp_wave<2, true>(P, wtile, btile, vb);
+}
+// the three for the fused start solve (Params.fused = 1: stage blocks only in the compact store)
+__global__ __launch_bounds__(64) void k_ipm_cst(Params P) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<0, false, true>(P, wtile, btile, blockIdx.x);
+}
+KALIGN __global__ __launch_bounds__(64) void k_as_cst(Params P) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    qp_wave<1, false, true>(P, wtile, btile, blockIdx.x);
+}
+__global__ __launch_bounds__(64) void k_ipm_rest_cst(Params P) {
+    __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
+    __shared__ double btile[4][64];
+    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[P.ipm_listed ? 40 : 0]; vb += gridDim.x) qp_wave<2, false, true>(P, wtile, btile, vb);
 }
 __global__ __launch_bounds__(64) void k_as_solves(Params P) {  // MODE 4: active-set solves, no roll-out
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
@@ -2995,9 +2644,13 @@ void launch_linearise(const Params& P, int chunks, hipStream_t st) {
 void launch_linearise_list(const Params& P, int chunks, hipStream_t st) {
     hipLaunchKernelGGL(k_linearise_list, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P);
 }
+void launch_linearise_clist(const Params& P, int chunks, int which, hipStream_t st) {
+    hipLaunchKernelGGL(k_linearise_clist, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P, which);
+}
 // ev (optional, cfnmpc_set_profiling): events recorded after k_factor, after the forward sweep, after the compaction
 void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev) {
-    hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
+    if (P.fused && !P.lbs) launch_linfactor(P, st);   // fused start solve (cfnmpc_linfactor.hip); per-stage boxes: stored path
+    else hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (P.lbs) {   // per-stage boxes: the row-group forward sweep carries them
         hipLaunchKernelGGL(k_forward_rg_sbox, dim3(P.NW), dim3(64), 0, st, P);
@@ -3025,6 +2678,24 @@ void launch_cforward(const Params& P, hipStream_t st) {
 }
 // ev (optional): event recorded after the active-set kernels (before the interior-point launch for what they left)
 void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
+    if (P.fused == 1 && !P.lbs) {
+        // fused start solve: no stored stage blocks -- the constrained instances are re-linearised into their compact
+        // store first (and the interior-point fall-back rows once more after k_ipm_list has moved them to new slots)
+        launch_linearise_clist(P, P.clist_chunks, 0, st);
+        if (P.active_set) {
+            hipLaunchKernelGGL(k_as_cst, dim3(P.NW), dim3(64), 0, st, P);
+            if (ev) (void)hipEventRecord(ev[0], st);
+            if (P.ipm_listed) {
+                hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
+                launch_linearise_clist(P, P.clist_chunks, 1, st);
+            }
+            hipLaunchKernelGGL(k_ipm_rest_cst, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
+        } else {
+            if (ev) (void)hipEventRecord(ev[0], st);
+            hipLaunchKernelGGL(k_ipm_cst, dim3(P.NW), dim3(64), 0, st, P);
+        }
+        return;
+    }
     if (P.lbs) {   // per-stage boxes: monolithic kernels instantiated for them
         if (P.active_set) {
             hipLaunchKernelGGL(k_as_sbox, dim3(P.NW), dim3(64), 0, st, P);

@@ -83,6 +83,7 @@ struct Params {
     double *v, *tl, *tu, *ll, *lu, *rg, *dva, *dvc, *Rh, *g;
     // compact scratch of the interior-point kernel (same block shapes, indexed by compacted slot)
     double *cAR, *cBR, *cKR, *cSinv, *cd, *cPchk, *cv, *cuit;
+    double *cbv;     // compact b (N x SZ_V13 per compact block): only the fused start solve's k_linearise_clist fills it
     // active-set solve, per compact block and stage: G = B'PA in the gain layout (SZ_K), the rows of
     // S = R^ + B'PB (SZ_S4: [c][inst][a]) and rho = B'(p + P b_eff) (SZ_V4)
     double *cGR, *cS, *crho;
@@ -113,6 +114,10 @@ struct Params {
     double *Ppark;               // cost-to-go between the chunks, [wave][13][64]
     int forward_div;             // 1: k_forward (division form: fleets that stream at the HBM rate), 0: k_forward_mid; see forward_body
     int forward_rg;              // 1: forward sweep of the start solve on the stored blocks (k_forward_rg; small fleets)
+    int clist_chunks;            // workgroups per 64-slot group of k_linearise_clist (stage chunks)
+    int fused;                   // start solve: 0 = k_linearise + k_factor on stored (A, B, b); 1 = k_linfactor, nothing stored (the QP
+                                 // kernels of the constrained instances read the compact store k_linearise_clist fills);
+                                 // 2 = k_linfactor for the factorisation, stored blocks for everything else (validation)
     int cond_N2, cond_M, cond_rem;
     double *cb;                  // condensed blocks, [instance][block][cb_size(w_max)] (layout: cfnmpc_pcond.hip)
 };
@@ -135,6 +140,8 @@ __host__ __device__ constexpr int cb_size(int mmax) { return cond_tri(cond_w(mma
 // (independent) shooting intervals of one 64-instance group are spread over
 void launch_linearise(const Params& P, int chunks, hipStream_t st);
 void launch_linearise_list(const Params& P, int chunks, hipStream_t st);
+// fused start solve: the instances of P.ilist (which = 0) / P.ilist2 (1) re-linearised into the compact store
+void launch_linearise_clist(const Params& P, int chunks, int which, hipStream_t st);
 // ev (optional): four events recorded after k_factor / the forward sweep / the compaction / the active-set kernels
 void launch_qp(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr);        // = launch_qp_start + launch_qp_ipm
 void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr);  // factor, forward (+ full step of feasible rows), compact
@@ -145,6 +152,7 @@ void launch_pcond(const Params& P, hipStream_t st);
 void launch_cfactor(const Params& P, hipStream_t st);
 void launch_factor_chunk(const Params& P, hipStream_t st);   // experiment: stages [P.fk_lo, P.fk_hi) of the start solve
 void launch_factor_only(const Params& P, hipStream_t st);
+void launch_linfactor(const Params& P, hipStream_t st);    // cfnmpc_linfactor.hip: fused linearisation + backward factorisation
 void launch_cforward(const Params& P, hipStream_t st);   // (in cfnmpc_kernels.hip: k_forward with condensed gains)
 void launch_cipm(const Params& P, hipStream_t st);
 void launch_qp_cond(const Params& P, hipStream_t st);    // = the four above

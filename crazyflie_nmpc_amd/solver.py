@@ -212,6 +212,22 @@ class BatchSolver:
     def linearise_only(self, stream=None):
         _check(self._L.cfnmpc_debug_linearise(self._h, _launch_stream(stream, self._device)), "cfnmpc_debug_linearise")
 
+    def start_factor(self, mode, reps=1, stream=None):
+        """Backward half of the start solve only (development / parity tests): mode 1 = k_linearise + k_factor,
+        2 = the fused k_linfactor.  Returns the average duration of one repetition [ms]."""
+        ms = C.c_double(0.0)
+        _check(self._L.cfnmpc_debug_start_factor(self._h, int(mode), int(reps), C.byref(ms), _launch_stream(stream, self._device)),
+               "cfnmpc_debug_start_factor")
+        return ms.value
+
+    def get_factor(self):
+        """-> K [B][N][4][13], d [B][N][4], Pchk [B][6][13][13], status [B] of the last start solve (reference state order)"""
+        K = np.empty((self.B, self.N, 4, NX)); d = np.empty((self.B, self.N, 4)); Pc = np.zeros((self.B, 6, NX, NX))
+        st = np.empty(self.B, dtype=np.int32)
+        _check(self._L.cfnmpc_debug_get_factor(self._h, K.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                               Pc.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)), "cfnmpc_debug_get_factor")
+        return K, d, Pc, st
+
     # ---- outputs
     def get_iterate(self):
         x = np.empty((self.B, self.N + 1, NX)); u = np.empty((self.B, self.N, NU))

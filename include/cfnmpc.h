@@ -154,6 +154,17 @@ typedef struct cfnmpc_opts {
                             u_k = the input reference of its stage, instead of re-linearising around the same iterate and failing
                             the same way for good.  0 (default): the reference's behaviour -- the node ignores the status and keeps
                             the iterate (acados_mpc.cpp:611-616).                                                        */
+    int start_solve;     /* start solve (linearisation + backward Riccati factorisation of the unconstrained QP):
+                            1 = two kernels with the stage blocks (A, B, b) stored in between (k_linearise writes 162 doubles
+                            per instance and stage, k_factor reads them back -- half of the bytes an RTI step moves);
+                            2 = FUSED (k_linfactor): the factorisation's wavefront linearises each stage itself on its way
+                            backward (every lane integrates one sensitivity column, the columns reach the row form through
+                            the LDS tile of the W transpose) and (A, B, b) never touch HBM; the constrained instances alone
+                            are re-linearised straight into the compact store of their QP kernels (k_linearise_clist);
+                            3 = validation: the fused kernel for the factorisation, the stored blocks for everything behind it;
+                            0 (default) = by configuration and fleet size (2 where the step streams at the HBM rate; 1 for
+                            small fleets, per-stage boxes, cond_N2, overlap_linearise, as_passes != -1 and forward_sweep = 2,
+                            whose kernels read the stored blocks).  Same results to rounding (tests/test_gpu_linfactor.py). */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);
@@ -276,6 +287,12 @@ int cfnmpc_debug_get_linearisation(cfnmpc_solver *s, double *A, double *Bm, doub
 int cfnmpc_debug_chunked_pair(cfnmpc_solver *s, int chunk, int reps, double *ms, void *stream);
 int cfnmpc_debug_checksum(cfnmpc_solver *s, double *out3);
 int cfnmpc_debug_linearise(cfnmpc_solver *s, void *stream);
+/* start solve, backward half only (parity tests of the fused kernel, timing): mode 1 = k_linearise + k_factor, 2 = k_linfactor;
+ * `reps` repetitions, *ms (may be NULL) = average duration of one, HIP events on `stream` */
+int cfnmpc_debug_start_factor(cfnmpc_solver *s, int mode, int reps, double *ms, void *stream);
+/* what that sweep leaves behind, as dense host arrays in the reference's state order (any pointer may be NULL):
+ * K [B][N][4][13], d [B][N][4], cost-to-go checkpoints Pchk [B][6][13][13] (stages 4, 8, 12, 16, 24, 32 below N), status [B] */
+int cfnmpc_debug_get_factor(cfnmpc_solver *s, double *K, double *d, double *Pchk, int *status);
 /* partial condensing (cond_N2 > 0): runs linearisation + pcond and copies condensed block `block`
  * of every instance to the host as dense arrays in the reference's state order, with
  * z = (dU (4 m), dx (13), 1), w = 4 m + 14, m = stages of that block:
