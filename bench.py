@@ -244,7 +244,7 @@ class Fleet:
         self.solver.close()
 
 
-def mixed_horizon_run(batch, dev, rng, steps, warmup):
+def mixed_horizon_run(batch, dev, rng, steps, warmup, predictor="queued"):
     """Config C5: `batch` vehicles with N in {30, 50, 100} (one cfnmpc_fleet = one solver per horizon
     bucket behind one handle), regulation targets U(-1,1)^2 x U(0.2,1); the plant applies every input 60 ms
     = 4 sampling periods after it was computed (the communication delay the reference compensates,
@@ -255,7 +255,10 @@ def mixed_horizon_run(batch, dev, rng, steps, warmup):
     approximation destabilises the closed loop, measured: the fleet diverges within 60 steps.)  Closed loop,
     staggered kicks (a kicked vehicle restarts with hover inputs in flight; keeping stale inputs in flight
     across the jump makes a handful of vehicles per step fall back to 30 - 50 interior-point iterations,
-    which then set the duration of the whole fleet's step: 15 - 24 ms instead of 5.8 ms, measured).  -> dict for the `sensitivity` block."""
+    which then set the duration of the whole fleet's step: 15 - 24 ms instead of 5.8 ms, measured).
+    predictor = "latest": the REFERENCE's protocol instead -- x0 = one crazyflie_acados_sim_solve over the whole 60 ms with the
+    latest input held (acados_estimator.cpp:573-593: sim_in_set "T" = delay, "x", "u" = the last published motor speeds), same
+    plant; reported with how long that loop stays healthy (`steps_until_ok_frac_below_0.99`).  -> dict for the `sensitivity` block."""
     import torch
     from crazyflie_nmpc_amd import sim
     from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
@@ -285,10 +288,13 @@ def mixed_horizon_run(batch, dev, rng, steps, warmup):
             x[c0:c1].copy_(kicks[t % KICK_PERIOD, : c1 - c0] + offd[c0:c1])
             for q in uq:
                 q[c0:c1] = HOV_W
-        sim(x, uq[t % 4], T=0.015, steps=1, out=xp)   # delay compensation: through the four inputs in flight
-        for j in (1, 2, 3):
-            sim(xp, uq[(t + j) % 4], T=0.015, steps=1, out=xn)
-            xp, xn = xn, xp
+        if predictor == "latest":   # the reference's predictor: the latest input held over the delay, RK4 with 4 sub-steps (App. D-8)
+            sim(x, uq[(t + 3) % 4], T=0.06, steps=4, out=xp)
+        else:
+            sim(x, uq[t % 4], T=0.015, steps=1, out=xp)   # delay compensation: through the four inputs in flight
+            for j in (1, 2, 3):
+                sim(xp, uq[(t + j) % 4], T=0.015, steps=1, out=xn)
+                xp, xn = xn, xp
         fleet.set_x0(xp); fleet.solve(1); fleet.get_u(0, u0)
         sim(x, uq[t % 4], T=0.015, steps=1, out=xn)   # the plant sees the inputs computed 4 periods ago
         uq[t % 4].copy_(u0)
@@ -307,6 +313,20 @@ def mixed_horizon_run(batch, dev, rng, steps, warmup):
     out = {"value": batch * steps / el, "stage_steps_per_s": float(horizons.sum()) * steps / el, "ms_per_step": el / steps * 1e3,
            "frac_constrained": float((it > 0).mean()), "mean_qp_solves": float(it.mean()), "status_ok_frac": float((st == 0).mean()),
            "buckets": {int(n): int((horizons == n).sum()) for n in (30, 50, 100)}}
+    if predictor == "latest":
+        # how long the reference's protocol keeps this plant (raw motor speeds, no onboard attitude loop) healthy: the loop goes
+        # on untimed, checked every 5 steps, until fewer than 99 % of the vehicles end their step with status 0 or a state
+        # leaves every plausible range (|p| > 50 m)
+        survived = warmup + steps
+        while survived < 400:
+            for _ in range(5):
+                step()
+            survived += 5
+            st2 = fleet.stats()[0]
+            if float((st2 == 0).mean()) < 0.99 or not bool(torch.isfinite(x).all()) or float(x[:, :3].abs().max()) > 50.0:
+                break
+        out["steps_until_ok_frac_below_0.99"] = survived if survived < 400 else ">= 400"
+        out["status_ok_frac_at_the_end"] = float((fleet.stats()[0] == 0).mean())
     fleet.close()
     del fleet
     torch.cuda.empty_cache()
@@ -328,6 +348,11 @@ def timed_run(fleet, steps, warmup, barrier):
     elapsed = time.perf_counter() - t0
     kms, n_prof = fleet.solver.get_profile_kernels()   # linearise | factor | forward | compaction | active set | interior point
     ms_lin, ms_qp = kms[0], sum(kms[1:])
+    if getattr(fleet.solver.opts, "overlap_linearise", 0) or getattr(fleet.solver.opts, "cond_N2", 0):
+        # overlapped / condensed steps report their two phases in kms[0] / kms[5] only, and with the overlap the QP phase
+        # comes FIRST (include/cfnmpc.h: cfnmpc_get_profile_kernels): no per-kernel split for them
+        ms_lin, ms_qp = (kms[5], kms[0]) if fleet.solver.opts.overlap_linearise else (kms[0], sum(kms[1:]))
+        kms = [0.0] * 6
     fleet.solver.set_profiling(False)
     # (n_prof == steps unless K exceeds the library's cap of timed steps: the average then covers the first 4096)
     st, it, _rs = fleet.solver.stats()
@@ -366,6 +391,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=None, help="cfnmpc_opts.overlap_linearise (default: library default)")
     ap.add_argument("--ah-margin", type=float, default=None)
     ap.add_argument("--ah-extra", type=int, default=None)
+    ap.add_argument("--start-solve", type=int, default=None, help="cfnmpc_opts.start_solve (0 auto, 1 k_linearise + k_factor on stored blocks, "
+                    "2 fused k_linfactor, 3 fused factorisation + stored blocks)")
     args = ap.parse_args()
 
     import torch
@@ -383,7 +410,10 @@ def main():
     torch.cuda.set_device(dev)
     dist = None
     red_dev = dev  # device of the tiny reduction tensors
-    if world > 1:
+    # (under torchrun with ONE rank the process group is brought up as well: the report's two all-reduces then run on RCCL
+    #  with device tensors -- the 8-GPU run is not the collective's first contact; tests/test_gpu_bench_distributed.py)
+    launched = world > 1 or ("RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ)
+    if launched:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -399,7 +429,8 @@ def main():
     seed = parallel.shard_seed(rank)
     opt_kw = dict(active_horizon=args.active_horizon, active_set=args.active_set)
     for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2),
-                 ("step_graph", args.step_graph), ("forward_sweep", args.forward_sweep), ("as_passes", args.as_passes)):
+                 ("step_graph", args.step_graph), ("forward_sweep", args.forward_sweep), ("as_passes", args.as_passes),
+                 ("start_solve", args.start_solve)):
         if v is not None:
             opt_kw[k] = v
 
@@ -459,6 +490,12 @@ def main():
             "x0 = RK4 prediction over the 60 ms delay THROUGH THE FOUR QUEUED INPUTS (oldest first); the reference's estimator holds the "
             "LATEST input over the delay (acados_estimator.cpp:573-593) -- with raw motor speeds as plant inputs that closed loop diverges "
             "(no onboard attitude loop in this plant), hence the departure")
+        # ... and the reference's own protocol beside it, for as long as it holds on this plant
+        c5r = mixed_horizon_run(B_rank, dev, np.random.default_rng(seed + 9000), 20, ws, predictor="latest")
+        c5r["predictor"] = ("the reference's: x0 = ONE sim solve over the 60 ms delay with the LATEST input held (acados_estimator.cpp:573-593, "
+                            "launch/acados_predictor.launch:62); timed over the same 20 steps after the same warm-up, then run on until "
+                            "the loop degrades (steps_until_ok_frac_below_0.99)")
+        extras["config_C5_mixed_horizons_30_50_100_reference_predictor (latest input held)"] = c5r
 
     if rank == 0:
         r = main_run
@@ -533,6 +570,8 @@ def main():
             "qp_stats": {"status_ok_frac": r["ok_frac"], "mean_qp_solves": r["mean_qp_solves"],
                          "frac_constrained": r["frac_constrained"], "mean_head_stages": r["mean_head"]},
         }
+        if dist is not None:   # how the aggregate report travelled (torch.distributed under torchrun)
+            out["report_collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "device": red_dev.type}
         if weak is not None:
             out["weak_scaling"] = {"value": weak["value"], "unit": "RTI steps/s", "batch_per_gpu": weak["batch_rank"],
                                    "total_batch": int(weak["total"]), "ms_per_step": weak["ms_per_step"],

@@ -15,6 +15,9 @@
 #include "../../include/cfnmpc.h"
 #include "cfnmpc_model.hpp"
 #include "cfnmpc_ws.hpp"
+#ifdef CFN_DEV
+#include "cfnmpc_dev.h"
+#endif
 
 struct cfnmpc_solver {
     cfn::Params P;
@@ -256,10 +259,12 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
         s->chunks_all = c < 1 ? 1 : (c > o.N ? o.N : c);
     }
     s->chunks_list = 10;
-    if (const char* e = std::getenv("CFNMPC_LIN_CHUNKS")) {   // development aid
+#ifdef CFN_DEV   // development builds only (make DEV=1): the shipped library reads no environment variables
+    if (const char* e = std::getenv("CFNMPC_LIN_CHUNKS")) {
         int a = 0, b = 0;
         if (std::sscanf(e, "%d,%d", &a, &b) == 2 && a > 0 && b > 0) { s->chunks_all = a; s->chunks_list = b; }
     }
+#endif
     if (hipGetDevice(&s->device) != hipSuccess) { delete s; return CFNMPC_EHIP; }
     cfn::Params& P = s->P;
     std::memset(&P, 0, sizeof P);
@@ -286,17 +291,22 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     // kernel's solves + commit, p > 0 = p single-solve passes
     P.as_passes = o.as_passes > 0 ? o.as_passes : (o.as_passes == -2 ? -1 : (o.as_passes == -3 ? -2 : 0));
     if (o.as_passes == 0 && batch < AS_COMMIT_BELOW && o.start_solve != 2) P.as_passes = -2;   // small fleets: solves + commit kernel (measured); the commit kernel reads stored blocks
-    if (const char* e = std::getenv("CFNMPC_AS_PASSES")) {   // development aid (internal encoding)
+#ifdef CFN_DEV
+    if (const char* e = std::getenv("CFNMPC_AS_PASSES")) {   // (internal encoding)
         const int v = std::atoi(e);
         if (v >= -2 && v <= 12) P.as_passes = v;
     }
+#endif
     {   // pass launches: two wavefronts per SIMD of this device
         hipDeviceProp_t prop;
         P.as_grid = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? 8 * prop.multiProcessorCount : 2048;
+#ifdef CFN_DEV
         if (const char* e = std::getenv("CFNMPC_AS_GRID")) { const int v = std::atoi(e); if (v > 0) P.as_grid = v; }
+#endif
     }
     // one fall-back row per wave is as fast as four while those waves fit one per SIMD (1024 rows: 1.6 % of 65 536 instances,
     // 2.5 % fall back at three times the bench's disturbances): only large fleets pay the compaction's extra launch
+    P.as_sparse_max = P.as_grid / 2;   // = the SIMDs of the device: one constrained row per wave while they all fit at once
     P.ipm_listed = batch >= IPM_LIST_FROM ? 1 : 0;
     // start solve: the fused kernel replaces k_linearise + k_factor where nothing but the constrained instances' QP kernels
     // reads the stage blocks afterwards (matrix-free forward sweep, monolithic active-set kernel, no partial condensing,
@@ -439,19 +449,25 @@ int cfnmpc_set_box_stages(cfnmpc_solver* s, const double* lb, const double* ub, 
     }
     if (P.cond_N2) return CFNMPC_EINVAL;   // the condensed path has no per-stage boxes
     const size_t n = (size_t)P.B * P.N * 4;
+    // host arrays are validated here (NaN fails too; lb = ub pins the input); DEVICE arrays are taken as they are -- a caller
+    // that hands over device pointers is responsible for lb <= ub (an inverted box ends in status 4 for that vehicle)
     if (is_host(on_device))
-        for (size_t i = 0; i < n; i++) if (!(lb[i] <= ub[i])) return CFNMPC_EINVAL;   // (NaN fails too; lb = ub pins the input)
-    if (!s->lbs_keep) {
+        for (size_t i = 0; i < n; i++) if (!(lb[i] <= ub[i])) return CFNMPC_EINVAL;
+    if (!s->lbs_keep || !P.clbs || !P.cubs) {
+        // allocated and initialised as a whole before any pointer is committed: a failure half-way (ENOMEM, a failed copy)
+        // leaves the solver on the scalar box with nothing dangling (the blocks stay owned by s->allocs until cfnmpc_free)
         const size_t cnt = ((size_t)P.NW + 1) * 4 * P.N * 4;
-        int rc = dev_alloc(s, &s->lbs_keep, cnt);
-        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->ubs_keep, cnt);
-        if (rc == CFNMPC_OK) rc = dev_alloc(s, &P.clbs, cnt);
-        if (rc == CFNMPC_OK) rc = dev_alloc(s, &P.cubs, cnt);
+        double *lk = nullptr, *uk = nullptr, *cl = nullptr, *cu = nullptr;
+        int rc = dev_alloc(s, &lk, cnt);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &uk, cnt);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &cl, cnt);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &cu, cnt);
         if (rc != CFNMPC_OK) return rc;
         // rows of the spare block (parked rows of compacted waves): a wide finite box
         std::vector<double> lo(4 * (size_t)P.N * 4, -1e30), hi(4 * (size_t)P.N * 4, 1e30);
-        HIP_TRY(hipMemcpy(s->lbs_keep + (size_t)P.NW * 4 * P.N * 4, lo.data(), lo.size() * 8, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(s->ubs_keep + (size_t)P.NW * 4 * P.N * 4, hi.data(), hi.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(lk + (size_t)P.NW * 4 * P.N * 4, lo.data(), lo.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(uk + (size_t)P.NW * 4 * P.N * 4, hi.data(), hi.size() * 8, hipMemcpyHostToDevice));
+        s->lbs_keep = lk; s->ubs_keep = uk; P.clbs = cl; P.cubs = cu;
     }
     // instance-major [inst][stage][4] is the caller's AoS order: plain copies
     hipStream_t st = (hipStream_t)stream;
@@ -782,6 +798,7 @@ float cfnmpc_debug_bench_sweep(cfnmpc_solver* s, int waves, int head, int reps, 
 int cfnmpc_debug_prof(unsigned long long* out, int reset) { (void)hipDeviceSynchronize(); cfn::debug_prof_read(out, reset); return 0; }
 #endif
 
+#ifdef CFN_DEV
 // EXPERIMENT: linearisation + backward factorisation of the start solve, either as the two
 // kernels of the product (chunk = 0) or alternating in chunks of `chunk` stages going backward -- linearise stages
 // [k, k + chunk), then factorise them (cost-to-go parked between the launches) -- so that the stage blocks might be
@@ -844,6 +861,7 @@ int cfnmpc_debug_checksum(cfnmpc_solver* s, double* out3) {
     }
     return CFNMPC_OK;
 }
+#endif   // CFN_DEV
 
 // Start solve, backward half only, for parity tests and timing: mode 1 = k_linearise + k_factor, mode 2 = k_linfactor;
 // `reps` repetitions timed with HIP events on `stream` (*ms = average per repetition; may be NULL).
@@ -909,6 +927,28 @@ int cfnmpc_debug_get_factor(cfnmpc_solver* s, double* K, double* d, double* Pchk
     if (status) HIP_TRY(hipMemcpy(status, P.status, B * sizeof(int), hipMemcpyDeviceToHost));
     return CFNMPC_OK;
 }
+
+#ifdef CFN_DEV
+// development experiment (tools/sub_fleet_emul.py): the parts of one fused RTI step on separate streams.
+// part 1: k_linfactor; part 2: everything behind it + the swap of the iterate buffers; flags bit 0: k_forward_half
+int cfnmpc_debug_solve_part(cfnmpc_solver* s, int part, int flags, void* stream) {
+    if (!s || s->P.fused != 1 || s->P.lbs) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    hipStream_t st = (hipStream_t)stream;
+    if (part == 1) cfn::launch_linfactor(s->P, st);
+    else {
+        cfn::Params Q = s->P;
+        Q.forward_half = flags & 1;
+        cfn::launch_qp_start(Q, st, nullptr, true);
+        cfn::launch_qp_ipm(Q, st);
+        std::swap(s->P.xit, s->P.xitn);
+        std::swap(s->P.uit, s->P.uitn);
+        s->parity ^= 1;
+    }
+    HIP_TRY(hipGetLastError());
+    return CFNMPC_OK;
+}
+#endif   // CFN_DEV
 
 int cfnmpc_debug_linearise(cfnmpc_solver* s, void* stream) {
     if (!s) return CFNMPC_EINVAL;

@@ -111,8 +111,11 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     }
     __syncthreads();
     const int inst = sinst[tid];
-    // (P.lin_k1 > 0: only the shooting intervals [lin_k0, lin_k1) -- the stage-chunked hand-over experiment)
+#ifdef CFN_DEV   // (P.lin_k1 > 0: only the shooting intervals [lin_k0, lin_k1) -- the stage-chunked hand-over experiment)
     const int ka = P.lin_k1 > 0 ? P.lin_k0 : 0, kb = P.lin_k1 > 0 ? P.lin_k1 : N;
+#else
+    const int ka = 0, kb = N;
+#endif
     const int per = (kb - ka + gridDim.y - 1) / gridDim.y;
     const int k0 = ka + blockIdx.y * per, k1 = imin(kb, k0 + per);
     if (k0 >= k1) return;
@@ -656,6 +659,7 @@ KALIGN __global__ __launch_bounds__(64, 2) void k_factor(Params P) {
     if (t.L == 0 && t.valid) gm(P.status)[t.inst] = ok ? 0 : 4;
 }
 
+#ifdef CFN_DEV
 // Stage-chunked hand-over experiment (cfnmpc_debug_chunked_pair): the stages [fk_lo, fk_hi) of
 // the start solve's backward sweep, cost-to-go parked in P.Ppark between the launches, so that k_linearise can produce
 // the same stages right before (its output then being read from the L2 / MALL instead of HBM -- or not: measured).
@@ -672,6 +676,7 @@ __global__ __launch_bounds__(64, 2) void k_factor_chunk(Params P) {
         else if (!ok) gm(P.status)[t.inst] = 4;
     }
 }
+#endif
 
 // a row whose QP failed keeps its iterate: old -> new buffers (`keep` is row-uniform; rare)
 __device__ __forceinline__ void keep_row(const Params& P, const Lane& t, const bool keep) {
@@ -925,6 +930,13 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
 }
 
 KALIGN __global__ __launch_bounds__(64) void k_forward(Params P) {   // large fleets (see FWD_DIV above)
+    __shared__ double xs[64 * 13], cs[64 * 13];
+    __shared__ int sflag[64];
+    forward_body<false, true>(P, xs, cs, sflag);
+}
+// the same at two waves per SIMD (<= 256 registers, a few spills): beside the fused start solve of ANOTHER sub-fleet, whose
+// waves leave half a SIMD's register file each (cfnmpc_opts.sub_fleets)
+__global__ __launch_bounds__(64, 2) void k_forward_half(Params P) {
     __shared__ double xs[64 * 13], cs[64 * 13];
     __shared__ int sflag[64];
     forward_body<false, true>(P, xs, cs, sflag);
@@ -1268,9 +1280,15 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     // P.nipm[40]): four fall-back rows per wave instead of one row in each of the waves they were scattered over
     const bool listed = MODE == 2 && P.ipm_listed;   // (small fleets skip k_ipm_list: the rows stay where k_as had them)
     const int nipm = gm(P.nipm)[listed ? 40 : 0];
-    const int slot = vb * 4 + (threadIdx.x >> 4);
-    if (vb * 4 >= nipm) return;  // wave-uniform: no work for this wave
-    bool has = slot < nipm;
+    // SPARSE (active-set kernels, short lists): ONE list slot per wave (row 0; rows 1..3 idle) while the constrained rows
+    // number fewer than the SIMDs -- every row then sweeps its own head, restarts at its own stage and stops after its own
+    // last solve instead of following the slowest of four wave-mates, and the kernel lasts as long as its hardest ROW.
+    // The compact slot of list slot c is c in both modes (row c & 3 of compact block c >> 2), so kernels of either
+    // mode read each other's results.
+    const bool sparse = (MODE == 1 || MODE == 3 || MODE == 4) && nipm <= P.as_sparse_max && nipm <= (int)gridDim.x;
+    const int slot = sparse ? vb : vb * 4 + (threadIdx.x >> 4);
+    if ((sparse ? vb : vb * 4) >= nipm) return;  // wave-uniform: no work for this wave
+    bool has = slot < nipm && (!sparse || (threadIdx.x >> 4) == 0);
     const int inst0 = has ? gm(listed ? P.ilist2 : P.ilist)[imin(slot, nipm - 1)] : 0;
     constexpr bool AS_ONLY = MODE == 1 || MODE == 3 || MODE == 4;
     constexpr bool NO_ROLL = MODE == 4;   // solves only: roll-out, tail check and publication are left to k_ascommit
@@ -1292,13 +1310,20 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     const bool infeasible = t.valid && (viol > 0.0);
     // rows whose unconstrained minimiser lies more than as_skip_viol box widths outside the box do not try the active-set
     // iteration (it settles on 15 % of them beyond 4 widths, 1-2 % beyond 8: measured) -- straight to the interior point
-    const bool try_as = infeasible && !(P.as_skip_viol > 0.0 && viol > P.as_skip_viol * (P.u_max - P.u_min));
+    // (per-stage boxes: never skipped -- a pinned input, lb = ub, is an equality only the active-set solves can hold, and the
+    //  scalar box width is no measure of "far outside" when the boxes differ from stage to stage)
+    const bool try_as = infeasible && !(!SBOX && P.as_skip_viol > 0.0 && viol > P.as_skip_viol * (P.u_max - P.u_min));
     // All interior-point sweeps run on a COMPACT copy of the head stages (row r of this wave =
     // slot r of compact block blockIdx.x): the instance's own blocks are interleaved with three
     // unrelated instances, which would waste 3/4 of every cache line on every sweep of every
     // iteration.  The start solve's gains / inputs in P stay untouched until the QP is accepted.
     Lane tc = t;
-    tc.wave = vb; tc.q = t.row; tc.inst = vb * 4 + t.row;
+    if (sparse) {   // row 0: compact slot `slot`; idle rows: parked on the spare compact block
+        tc.inst = t.row == 0 ? slot : P.NW * 4 + t.row;
+        tc.wave = tc.inst >> 2; tc.q = tc.inst & 3;
+    } else {
+        tc.wave = vb; tc.q = t.row; tc.inst = vb * 4 + t.row;
+    }
     Params Q = P;
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
     Q.lbs = P.clbs; Q.ubs = P.cubs;
@@ -1416,7 +1441,18 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         const bool start_ipm = infeasible && !as_done;
         // Clipped start for rows whose unconstrained minimiser lies more than clip_viol box widths outside the box
         // (vehicles far from their iterate's trajectory: the infeasible start below spends 30 - 60 iterations there)
-        const bool clip = start_ipm && P.clip_viol > 0.0 && viol > P.clip_viol * (P.u_max - P.u_min);
+        // (per-stage boxes: "box widths" = the widest box of the row's head stages)
+        double wref = P.u_max - P.u_min;
+        if (SBOX && __any(start_ipm)) {
+            double wm = 0.0;
+            for (int e0 = t.L; e0 < head * 4; e0 += 64) {
+                double blo[4], bhi[4];
+                SFOR(j, 0, 4, { box_at<SBOX>(Q, cbase + imin(e0 + 16 * j, head * 4 - 1), blo[j], bhi[j]); });
+                SFOR(j, 0, 4, { wm = fmax(wm, bhi[j] - blo[j]); });
+            }
+            wref = row_max(wm);
+        }
+        const bool clip = start_ipm && P.clip_viol > 0.0 && viol > P.clip_viol * wref;
         double mu0c = P.lam0_min;
         if (__any(clip)) {
             for (int e0 = t.L; e0 < head * 4; e0 += 64) {   // v <- clipped into the box, dv -> Q.dva (0 for the other rows)
@@ -1474,7 +1510,10 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                         const double v = vv[j];
                         const double lb = blo[j] - uk[j], ub = bhi[j] - uk[j];
                         // clipped rows: exact slacks, multipliers absorb the gradient; others: slacks floored at thr0
-                        const double tl = clip ? v - lb : fmax(v - lb, P.thr0), tu = clip ? ub - v : fmax(ub - v, P.thr0);
+                        // (a pinned input, lb = ub, has no interior: its slacks take the floor in either start, so that the
+                        //  iteration stays finite and such a row ends at the iteration cap -- status 2 -- instead of NaN)
+                        const bool pinned = SBOX && !(ub > lb);
+                        const double tl = (clip && !pinned) ? v - lb : fmax(v - lb, P.thr0), tu = (clip && !pinned) ? ub - v : fmax(ub - v, P.thr0);
                         const double itl = rcp_nr(tl), itu = rcp_nr(tu);
                         const double ll = fmax(gg[j], 0.0) + mu0 * itl, lu = fmax(-gg[j], 0.0) + mu0 * itu;
                         const double rg = gg[j] - ll + lu;
@@ -2648,8 +2687,9 @@ void launch_linearise_clist(const Params& P, int chunks, int which, hipStream_t 
     hipLaunchKernelGGL(k_linearise_clist, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P, which);
 }
 // ev (optional, cfnmpc_set_profiling): events recorded after k_factor, after the forward sweep, after the compaction
-void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev) {
-    if (P.fused && !P.lbs) launch_linfactor(P, st);   // fused start solve (cfnmpc_linfactor.hip); per-stage boxes: stored path
+void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev, bool skip_factor) {
+    if (skip_factor) {}   // (sub-fleet pipeline: the backward sweep was launched on the start-solve stream)
+    else if (P.fused && !P.lbs) launch_linfactor(P, st);   // fused start solve (cfnmpc_linfactor.hip); per-stage boxes: stored path
     else hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (P.lbs) {   // per-stage boxes: the row-group forward sweep carries them
@@ -2659,7 +2699,8 @@ void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev) {
         hipLaunchKernelGGL(k_forward_rg, dim3(P.NW), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_rank, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     } else {
-        if (P.forward_div) hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+        if (P.forward_half) hipLaunchKernelGGL(k_forward_half, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+        else if (P.forward_div) hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
         else hipLaunchKernelGGL(k_forward_mid, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     }
     if (ev) (void)hipEventRecord(ev[1], st);
@@ -2667,9 +2708,11 @@ void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev) {
     hipLaunchKernelGGL(k_scatter, dim3((P.B + 255) / 256), dim3(256), 0, st, P);
     if (ev) (void)hipEventRecord(ev[2], st);
 }
+#ifdef CFN_DEV
 void launch_factor_chunk(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor_chunk, dim3(P.NW), dim3(64), 0, st, P);
 }
+#endif
 void launch_factor_only(const Params& P, hipStream_t st) {
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
 }

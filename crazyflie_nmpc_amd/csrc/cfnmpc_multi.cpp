@@ -35,6 +35,9 @@ struct cfnmpc_multi {
 };
 
 #define RC_TRY(x) do { int rc_ = (x); if (rc_ != CFNMPC_OK) return rc_; } while (0)
+// for calls that ENQUEUE transfers on the shards' streams (CFNMPC_ON_HOST_ASYNC): on the first failing shard the earlier
+// shards' copies may still be reading / writing the caller's arrays -- wait for them before the error is returned
+#define RC_TRY_SYNC(m, x) do { int rc_ = (x); if (rc_ != CFNMPC_OK) { (void)sync_all(m); return rc_; } } while (0)
 
 extern "C" {
 
@@ -105,7 +108,7 @@ static int sync_all(cfnmpc_multi* m) {
 
 int cfnmpc_multi_set_x0(cfnmpc_multi* m, const double* x0) {
     if (!m || !x0) return CFNMPC_EINVAL;
-    for (Shard& s : m->sh) RC_TRY(cfnmpc_set_x0(s.s, x0 + (size_t)s.lo * 13, CFNMPC_ON_HOST_ASYNC, s.st));
+    for (Shard& s : m->sh) RC_TRY_SYNC(m, cfnmpc_set_x0(s.s, x0 + (size_t)s.lo * 13, CFNMPC_ON_HOST_ASYNC, s.st));
     return sync_all(m);
 }
 
@@ -113,7 +116,7 @@ int cfnmpc_multi_set_yref(cfnmpc_multi* m, const double* yref, const double* yre
     if (!m || !yref || !yref_e) return CFNMPC_EINVAL;
     // (two arrays through ONE staging buffer per shard: the second put is ordered behind the first on the shard's stream)
     for (Shard& s : m->sh)
-        RC_TRY(cfnmpc_set_yref(s.s, yref + (size_t)s.lo * m->N * 17, yref_e + (size_t)s.lo * 13, CFNMPC_ON_HOST_ASYNC, s.st));
+        RC_TRY_SYNC(m, cfnmpc_set_yref(s.s, yref + (size_t)s.lo * m->N * 17, yref_e + (size_t)s.lo * 13, CFNMPC_ON_HOST_ASYNC, s.st));
     return sync_all(m);
 }
 
@@ -127,7 +130,7 @@ int cfnmpc_multi_set_box_stages(cfnmpc_multi* m, const double* lb, const double*
     if (!m || ((lb == nullptr) != (ub == nullptr))) return CFNMPC_EINVAL;
     for (Shard& s : m->sh) {
         const size_t off = (size_t)s.lo * m->N * 4;
-        RC_TRY(cfnmpc_set_box_stages(s.s, lb ? lb + off : nullptr, ub ? ub + off : nullptr, CFNMPC_ON_HOST_ASYNC, s.st));
+        RC_TRY_SYNC(m, cfnmpc_set_box_stages(s.s, lb ? lb + off : nullptr, ub ? ub + off : nullptr, CFNMPC_ON_HOST_ASYNC, s.st));
     }
     return sync_all(m);
 }
@@ -161,27 +164,27 @@ int cfnmpc_multi_sync(cfnmpc_multi* m) {
 
 int cfnmpc_multi_get_u(cfnmpc_multi* m, int stage, double* u) {
     if (!m || !u) return CFNMPC_EINVAL;
-    for (Shard& s : m->sh) RC_TRY(cfnmpc_get_u(s.s, stage, u + (size_t)s.lo * 4, CFNMPC_ON_HOST_ASYNC, s.st));
+    for (Shard& s : m->sh) RC_TRY_SYNC(m, cfnmpc_get_u(s.s, stage, u + (size_t)s.lo * 4, CFNMPC_ON_HOST_ASYNC, s.st));
     return sync_all(m);
 }
 
 int cfnmpc_multi_get_x(cfnmpc_multi* m, int stage, double* x) {
     if (!m || !x) return CFNMPC_EINVAL;
-    for (Shard& s : m->sh) RC_TRY(cfnmpc_get_x(s.s, stage, x + (size_t)s.lo * 13, CFNMPC_ON_HOST_ASYNC, s.st));
+    for (Shard& s : m->sh) RC_TRY_SYNC(m, cfnmpc_get_x(s.s, stage, x + (size_t)s.lo * 13, CFNMPC_ON_HOST_ASYNC, s.st));
     return sync_all(m);
 }
 
 int cfnmpc_multi_get_cmd(cfnmpc_multi* m, double* cmd_vel, int* motvel) {
     if (!m || !cmd_vel) return CFNMPC_EINVAL;
     for (Shard& s : m->sh)
-        RC_TRY(cfnmpc_get_cmd(s.s, cmd_vel + (size_t)s.lo * 4, motvel ? motvel + (size_t)s.lo * 4 : nullptr, CFNMPC_ON_HOST_ASYNC, s.st));
+        RC_TRY_SYNC(m, cfnmpc_get_cmd(s.s, cmd_vel + (size_t)s.lo * 4, motvel ? motvel + (size_t)s.lo * 4 : nullptr, CFNMPC_ON_HOST_ASYNC, s.st));
     return sync_all(m);
 }
 
 int cfnmpc_multi_get_stats(cfnmpc_multi* m, int* status, int* qp_iter, double* res) {
     if (!m) return CFNMPC_EINVAL;
     for (Shard& s : m->sh)
-        RC_TRY(cfnmpc_get_stats(s.s, status ? status + s.lo : nullptr, qp_iter ? qp_iter + s.lo : nullptr, res ? res + s.lo : nullptr,
+        RC_TRY_SYNC(m, cfnmpc_get_stats(s.s, status ? status + s.lo : nullptr, qp_iter ? qp_iter + s.lo : nullptr, res ? res + s.lo : nullptr,
                                 CFNMPC_ON_HOST_ASYNC, s.st));
     return sync_all(m);
 }

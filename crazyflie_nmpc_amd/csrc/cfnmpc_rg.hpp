@@ -309,18 +309,16 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         // hb' = p' + (P b)' in lane 13
         double pb = 0.0;
         dotbc<13, 0>(pb, Pa, in.bv);          // lanes 0..12: (P b)[i]
-        SFOR(j, 0, 13, { dotbc<1, j>(Pa[j], &is13, pb); });   // lane 13: p'[j] += (P b)[j]
+        rank1bc<13>(Pa, is13, pb);   // lane 13: p'[j] += (P b)[j]
     }
     // (1) W = Pa A (row form, instruction-level sparsity of A), (2) V = Pa B
     double W[13], V[4];
     SFOR(j, 0, 3, { W[j] = Pa[j]; });
     SFOR(j, 3, 13, { W[j] = 0.0; });
-    dot2bc<6, 0>(W[3], W[4], Pa, ar[0], ar[1]);
-    dotbc<6, 0>(W[5], Pa, ar[2]);
-    dot2bc<10, 0>(W[6], W[7], Pa, ar[3], ar[4]);
-    dot2bc<10, 0>(W[8], W[9], Pa, ar[5], ar[6]);
-    dot2bc<13, 0>(W[10], W[11], Pa, ar[7], ar[8]);
-    dotbc<13, 0>(W[12], Pa, ar[9]);
+    // (three / four accumulator chains side by side: a wave alone on its SIMD issues dependent FP64 operations at half rate)
+    dot3bc<6>(W[3], W[4], W[5], Pa, ar[0], ar[1], ar[2]);
+    dot4bc<10>(W[6], W[7], W[8], W[9], Pa, ar[3], ar[4], ar[5], ar[6]);
+    dot3bc<13>(W[10], W[11], W[12], Pa, ar[7], ar[8], ar[9]);
     // (3) Wt = transpose of W over lanes 0..12 through the LDS tile (lane 13 keeps the affine row);
     //     the same round trip hands the columns of B to lanes 0..3.  The tile is written BEFORE V
     //     is formed and S is formed BEFORE the transposed rows are used, so that both LDS
@@ -332,8 +330,7 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         SFOR(a, 0, 4, { sb[a * 16 + t.L] = br[a]; });
     }
     SFOR(a, 0, 4, { V[a] = 0.0; });
-    dot2bc<13, 0>(V[0], V[1], Pa, br[0], br[1]);
-    dot2bc<13, 0>(V[2], V[3], Pa, br[2], br[3]);
+    dot4bc<13>(V[0], V[1], V[2], V[3], Pa, br[0], br[1], br[2], br[3]);
     __syncthreads();
     double bcl[13];   // lanes >= 4 compute don't-care rows of S (never broadcast)
     SFOR(l, 0, 13, { bcl[l] = sb[(t.L & 3) * 16 + l]; });
@@ -345,8 +342,7 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     double Srow[4];
     if (QTAB) SFOR(c, 0, 4, { Srow[c] = qtab[t.L * QT_ROW + 13 + c]; });
     else SFOR(c, 0, 4, { Srow[c] = (t.L == c) ? in.Rh : 0.0; });
-    dot2bc<13, 0>(Srow[0], Srow[1], bcl, V[0], V[1]);
-    dot2bc<13, 0>(Srow[2], Srow[3], bcl, V[2], V[3]);
+    dot4bc<13>(Srow[0], Srow[1], Srow[2], Srow[3], bcl, V[0], V[1], V[2], V[3]);
     SFOR(c, 0, 4, { settle(Srow[c]); });
     if (AS && t.L < 4 && act) {
         gdouble* sr = ZL ? gm(P.cS) + ((size_t)t.inst * P.N + k) * 16 + t.L : blk(P.cS, t, P.N, k, SZ_S4) + t.q * 4 + t.L;
@@ -362,23 +358,19 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     double M[13];
     if (QTAB) SFOR(j, 0, 13, { M[j] = qtab[t.L * QT_ROW + j]; });
     else SFOR(j, 0, 13, { M[j] = (t.L == j) ? wq : 0.0; });
-    if (ABSOLUTE) SFOR(j, 0, 13, { dotbc<1, j>(M[j], &is13, in.qv); });   // lane 13: += q_k[j]
+    if (ABSOLUTE) rank1bc<13>(M, is13, in.qv);   // lane 13: += q_k[j]
     SFOR(j, 0, 3, { M[j] += Wt[j]; });
-    dot2bc<6, 0>(M[3], M[4], Wt, ar[0], ar[1]);
-    dotbc<6, 0>(M[5], Wt, ar[2]);
+    dot3bc<6>(M[3], M[4], M[5], Wt, ar[0], ar[1], ar[2]);
     chol4_pivot<1>(S, ch);
-    dot2bc<10, 0>(M[6], M[7], Wt, ar[3], ar[4]);
-    dot2bc<10, 0>(M[8], M[9], Wt, ar[5], ar[6]);
+    dot4bc<10>(M[6], M[7], M[8], M[9], Wt, ar[3], ar[4], ar[5], ar[6]);
     chol4_pivot<2>(S, ch);
-    dot2bc<13, 0>(M[10], M[11], Wt, ar[7], ar[8]);
-    dotbc<13, 0>(M[12], Wt, ar[9]);
+    dot3bc<13>(M[10], M[11], M[12], Wt, ar[7], ar[8], ar[9]);
     chol4_pivot<3>(S, ch);
     // (6) G' = Wt B ; lane 13: rho = g + B'hb
     double Gp[4];
     SFOR(a, 0, 4, { Gp[a] = 0.0; });
-    dot2bc<13, 0>(Gp[0], Gp[1], Wt, br[0], br[1]);
-    dot2bc<13, 0>(Gp[2], Gp[3], Wt, br[2], br[3]);
-    SFOR(a, 0, 4, { dotbc<1, a>(Gp[a], &is13, in.g); });   // lane 13: += g[a]
+    dot4bc<13>(Gp[0], Gp[1], Gp[2], Gp[3], Wt, br[0], br[1], br[2], br[3]);
+    rank1bc<4>(Gp, is13, in.g);   // lane 13: += g[a]
     if (AS) {
         // active-set solve: the forward sweep evaluates the multipliers of the fixed inputs from the
         // stage's own blocks, B'pi_{k+1} = G dx_k + (B'PB) du_free + rho -- keep G (gain layout),
@@ -399,10 +391,11 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         nGp[a] = -Gp[a];
     });
     // (8) P <- M - G' K  (lane 13: p' <- M_13 - rho' K)
-    SFOR(j, 0, 13, {
-        Pa[j] = M[j];
-        updbc<j>(Pa[j], Kp, nGp);
-    });
+    SFOR(j, 0, 13, { Pa[j] = M[j]; });
+    upd4bc<0, 4>(Pa, Kp, nGp);
+    upd4bc<4, 4>(Pa, Kp, nGp);
+    upd4bc<8, 4>(Pa, Kp, nGp);
+    upd4bc<12, 1>(Pa, Kp, nGp);
     // (9) stores: gain in "lane a holds K[a][.]" form, Sinv, feed-forward
     {
         // lanes 0..12 store their column of the gain, lane 13 the feed-forward: one masked

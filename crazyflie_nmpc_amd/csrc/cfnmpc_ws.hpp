@@ -103,16 +103,20 @@ struct Params {
     // level-synchronous active-set passes (cfnmpc_opts.as_pipeline; k_asp / k_ascommit in cfnmpc_kernels.hip)
     int as_passes;               // 0: monolithic k_as; p > 0: p single-solve launches + one launch for the remaining solves
     int as_grid;                 // wavefronts per pass launch (grid-stride over the work list)
+    int as_sparse_max;           // active-set kernels: one list slot per wave while the list is no longer than this (0: never)
     int *aslist, *ascnt;         // work lists [set 0..2][bin 0..6][compact slots], their lengths [set][bin]
     int *askst, *asst, *asok;    // per compact slot: restart stage of its next solve; 1 = settled (to be committed); last factorisation positive definite
     double *czdx;                // per compact slot: dx_k of its last solve, (N + 1) x 13
     // per-stage, per-input input box (cfnmpc_set_box_stages; NULL: the scalar box u_min / u_max): instance-major
     // [inst][stage][4] like uit, and the compact copies of the constrained-QP kernels
     double *lbs, *ubs, *clbs, *cubs;
+#ifdef CFN_DEV
     // stage-chunked hand-over experiment (cfnmpc_debug_chunked_pair): stage ranges of k_linearise / k_factor_chunk
     int lin_k0, lin_k1, fk_lo, fk_hi;
     double *Ppark;               // cost-to-go between the chunks, [wave][13][64]
+#endif
     int forward_div;             // 1: k_forward (division form: fleets that stream at the HBM rate), 0: k_forward_mid; see forward_body
+    int forward_half;            // 1: k_forward_half (two waves per SIMD) instead of k_forward
     int forward_rg;              // 1: forward sweep of the start solve on the stored blocks (k_forward_rg; small fleets)
     int clist_chunks;            // workgroups per 64-slot group of k_linearise_clist (stage chunks)
     int fused;                   // start solve: 0 = k_linearise + k_factor on stored (A, B, b); 1 = k_linfactor, nothing stored (the QP
@@ -144,13 +148,15 @@ void launch_linearise_list(const Params& P, int chunks, hipStream_t st);
 void launch_linearise_clist(const Params& P, int chunks, int which, hipStream_t st);
 // ev (optional): four events recorded after k_factor / the forward sweep / the compaction / the active-set kernels
 void launch_qp(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr);        // = launch_qp_start + launch_qp_ipm
-void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr);  // factor, forward (+ full step of feasible rows), compact
+void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr, bool skip_factor = false);  // factor, forward (+ full step of feasible rows), compact
 void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev = nullptr);    // constrained instances (+ their full step)
 // partial condensing path (cfnmpc_pcond.hip): pcond -> condensed Riccati -> forward sweep with expand ->
 // interior point on the condensed QP for the constrained instances
 void launch_pcond(const Params& P, hipStream_t st);
 void launch_cfactor(const Params& P, hipStream_t st);
+#ifdef CFN_DEV
 void launch_factor_chunk(const Params& P, hipStream_t st);   // experiment: stages [P.fk_lo, P.fk_hi) of the start solve
+#endif
 void launch_factor_only(const Params& P, hipStream_t st);
 void launch_linfactor(const Params& P, hipStream_t st);    // cfnmpc_linfactor.hip: fused linearisation + backward factorisation
 void launch_cforward(const Params& P, hipStream_t st);   // (in cfnmpc_kernels.hip: k_forward with condensed gains)

@@ -64,14 +64,14 @@ class MixedHorizonFleet:
 
     def set_yref(self, yref, yref_e):
         """yref [B][Nmax][17] (vehicle i uses rows 0..N_i-1), yref_e [B][13]"""
-        p, dev, st, _k = _arg(yref, (self.B, self.Nmax, NY))
-        pe, deve, _st, _k2 = _arg(yref_e, (self.B, NX))
+        p, dev, st, _k = _arg(yref, (self.B, self.Nmax, NY), device=self._device)
+        pe, deve, _st, _k2 = _arg(yref_e, (self.B, NX), device=self._device)
         if dev != deve:
             raise ValueError("yref and yref_e must live on the same side")
         _check(self._L.cfnmpc_fleet_set_yref(self._h, p, pe, dev, st), "cfnmpc_fleet_set_yref")
 
     def set_x0(self, x0):
-        p, dev, st, _k = _arg(x0, (self.B, NX))
+        p, dev, st, _k = _arg(x0, (self.B, NX), device=self._device)
         _check(self._L.cfnmpc_fleet_set_x0(self._h, p, dev, st), "cfnmpc_fleet_set_x0")
 
     def set_weights(self, W=None, WN=None):
@@ -102,8 +102,8 @@ class MixedHorizonFleet:
                 motvel = torch.empty((self.B, 4), dtype=torch.int32, device=cmd_vel.device)
             else:
                 motvel = np.empty((self.B, 4), dtype=np.int32)
-        p, dev, st, _k = _arg(cmd_vel, (self.B, 4))
-        pm, devm, _s, _k2 = _arg(motvel, (self.B, 4), np.int32)
+        p, dev, st, _k = _arg(cmd_vel, (self.B, 4), device=self._device)
+        pm, devm, _s, _k2 = _arg(motvel, (self.B, 4), np.int32, device=self._device)
         assert dev == devm
         _check(self._L.cfnmpc_fleet_get_cmd(self._h, p, pm, dev, st), "cfnmpc_fleet_get_cmd")
         return cmd_vel, motvel
@@ -117,14 +117,14 @@ class MixedHorizonFleet:
     def get_u(self, stage, out=None):
         if out is None:
             out = np.empty((self.B, NU))
-        p, dev, st, _k = _arg(out, (self.B, NU))
+        p, dev, st, _k = _arg(out, (self.B, NU), device=self._device)
         _check(self._L.cfnmpc_fleet_get_u(self._h, int(stage), p, dev, st), "cfnmpc_fleet_get_u")
         return out
 
     def get_x(self, stage, out=None):
         if out is None:
             out = np.empty((self.B, NX))
-        p, dev, st, _k = _arg(out, (self.B, NX))
+        p, dev, st, _k = _arg(out, (self.B, NX), device=self._device)
         _check(self._L.cfnmpc_fleet_get_x(self._h, int(stage), p, dev, st), "cfnmpc_fleet_get_x")
         return out
 
@@ -133,12 +133,12 @@ class MixedHorizonFleet:
         to keep them on the device"""
         if out is not None:
             st, it, rs = out
-            ps, dev, strm, _a = _arg(st, (self.B,), np.int32)
-            pi, _d, _s, _b = _arg(it, (self.B,), np.int32)
-            pr, _d2, _s2, _c = _arg(rs, (self.B,))
+            ps, dev, strm, _a = _arg(st, (self.B,), np.int32, device=self._device)
+            pi, _d, _s, _b = _arg(it, (self.B,), np.int32, device=self._device)
+            pr, _d2, _s2, _c = _arg(rs, (self.B,), device=self._device)
             _check(self._L.cfnmpc_fleet_get_stats(self._h, ps, pi, pr, dev, strm), "cfnmpc_fleet_get_stats")
             return out
         st = np.empty(self.B, dtype=np.int32); it = np.empty(self.B, dtype=np.int32); rs = np.empty(self.B)
         _check(self._L.cfnmpc_fleet_get_stats(self._h, st.ctypes.data_as(C.c_void_p), it.ctypes.data_as(C.c_void_p),
-                                              rs.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_fleet_get_stats")
+                                              rs.ctypes.data_as(C.c_void_p), 0, _launch_stream(None, self._device)), "cfnmpc_fleet_get_stats")
         return st, it, rs

@@ -38,8 +38,9 @@ def aggregate_report(elapsed: float, sums, dist=None, device=None):
     """max-over-ranks of the timed region and sum-over-ranks of additive statistics.
     `dist` is torch.distributed (initialised) or None for a single process."""
     sums = np.asarray(sums, dtype=np.float64)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(elapsed), sums
+    # (a one-rank group still goes through the collectives: that is the smoke test of the backend under torchrun)
     import torch
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     s = torch.tensor(sums, dtype=torch.float64, device=device)

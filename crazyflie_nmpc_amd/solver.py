@@ -80,8 +80,10 @@ def _launch_stream(stream, device=None):
     return C.c_void_p(0)
 
 
-def _arg(a, shape, dtype=np.float64):
-    """-> (pointer, on_device, stream, keepalive)"""
+def _arg(a, shape, dtype=np.float64, device=None):
+    """-> (pointer, on_device, stream, keepalive).  Host arrays travel on the stream the launch calls use (torch's CURRENT
+    stream on the solver's device, _launch_stream): inside `with torch.cuda.stream(s):` a numpy getter then waits for the
+    solve enqueued on s, and a numpy setter cannot overtake it -- pool streams do not synchronise with stream 0."""
     if _is_torch(a):
         import torch
         want = {np.float64: torch.float64, np.int32: torch.int32}[dtype]
@@ -91,7 +93,7 @@ def _arg(a, shape, dtype=np.float64):
     arr = np.ascontiguousarray(a, dtype=dtype)
     if arr.shape != tuple(shape):
         raise ValueError(f"expected shape {shape}, got {arr.shape}")
-    return arr.ctypes.data_as(C.c_void_p), 0, C.c_void_p(0), arr
+    return arr.ctypes.data_as(C.c_void_p), 0, _launch_stream(None, device), arr
 
 
 class BatchSolver:
@@ -122,12 +124,12 @@ class BatchSolver:
 
     # ---- inputs
     def set_x0(self, x0):
-        p, dev, st, _k = _arg(x0, (self.B, NX))
+        p, dev, st, _k = _arg(x0, (self.B, NX), device=self._device)
         _check(self._L.cfnmpc_set_x0(self._h, p, dev, st), "cfnmpc_set_x0")
 
     def set_yref(self, yref, yref_e):
-        p, dev, st, _k = _arg(yref, (self.B, self.N, NY))
-        pe, deve, _st, _k2 = _arg(yref_e, (self.B, NX))
+        p, dev, st, _k = _arg(yref, (self.B, self.N, NY), device=self._device)
+        pe, deve, _st, _k2 = _arg(yref_e, (self.B, NX), device=self._device)
         if dev != deve:
             raise ValueError("yref and yref_e must live on the same side")
         _check(self._L.cfnmpc_set_yref(self._h, p, pe, dev, st), "cfnmpc_set_yref")
@@ -160,10 +162,10 @@ class BatchSolver:
         """Per-stage, per-input box [B][N][4] (acados' "lbu" / "ubu" on individual stages); None, None: back to
         the scalar box."""
         if lb is None and ub is None:
-            _check(self._L.cfnmpc_set_box_stages(self._h, None, None, 0, None), "cfnmpc_set_box_stages")
+            _check(self._L.cfnmpc_set_box_stages(self._h, None, None, 0, _launch_stream(None, self._device)), "cfnmpc_set_box_stages")
             return
-        p, dev, st, _k = _arg(lb, (self.B, self.N, NU))
-        pu, devu, _s, _k2 = _arg(ub, (self.B, self.N, NU))
+        p, dev, st, _k = _arg(lb, (self.B, self.N, NU), device=self._device)
+        pu, devu, _s, _k2 = _arg(ub, (self.B, self.N, NU), device=self._device)
         assert dev == devu
         _check(self._L.cfnmpc_set_box_stages(self._h, p, pu, dev, st), "cfnmpc_set_box_stages")
 
@@ -171,8 +173,8 @@ class BatchSolver:
         _check(self._L.cfnmpc_init_iterate(self._h, mode, _launch_stream(stream, self._device)), "cfnmpc_init_iterate")
 
     def set_iterate(self, x, u):
-        p, dev, st, _k = _arg(x, (self.B, self.N + 1, NX))
-        pu, devu, _s, _k2 = _arg(u, (self.B, self.N, NU))
+        p, dev, st, _k = _arg(x, (self.B, self.N + 1, NX), device=self._device)
+        pu, devu, _s, _k2 = _arg(u, (self.B, self.N, NU), device=self._device)
         assert dev == devu
         _check(self._L.cfnmpc_set_iterate(self._h, p, pu, dev, st), "cfnmpc_set_iterate")
 
@@ -231,20 +233,21 @@ class BatchSolver:
     # ---- outputs
     def get_iterate(self):
         x = np.empty((self.B, self.N + 1, NX)); u = np.empty((self.B, self.N, NU))
-        _check(self._L.cfnmpc_get_iterate(self._h, x.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_get_iterate")
+        _check(self._L.cfnmpc_get_iterate(self._h, x.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), 0,
+                                          _launch_stream(None, self._device)), "cfnmpc_get_iterate")
         return x, u
 
     def get_u(self, stage, out=None):
         if out is None:
             out = np.empty((self.B, NU))
-        p, dev, st, _k = _arg(out, (self.B, NU))
+        p, dev, st, _k = _arg(out, (self.B, NU), device=self._device)
         _check(self._L.cfnmpc_get_u(self._h, int(stage), p, dev, st), "cfnmpc_get_u")
         return out
 
     def get_x(self, stage, out=None):
         if out is None:
             out = np.empty((self.B, NX))
-        p, dev, st, _k = _arg(out, (self.B, NX))
+        p, dev, st, _k = _arg(out, (self.B, NX), device=self._device)
         _check(self._L.cfnmpc_get_x(self._h, int(stage), p, dev, st), "cfnmpc_get_x")
         return out
 
@@ -260,8 +263,8 @@ class BatchSolver:
                 motvel = torch.empty((self.B, 4), dtype=torch.int32, device=cmd_vel.device)
             else:
                 motvel = np.empty((self.B, 4), dtype=np.int32)
-        p, dev, st, _k = _arg(cmd_vel, (self.B, 4))
-        pm, devm, _s, _k2 = _arg(motvel, (self.B, 4), dtype=np.int32)
+        p, dev, st, _k = _arg(cmd_vel, (self.B, 4), device=self._device)
+        pm, devm, _s, _k2 = _arg(motvel, (self.B, 4), dtype=np.int32, device=self._device)
         assert dev == devm
         _check(self._L.cfnmpc_get_cmd(self._h, p, pm, dev, st), "cfnmpc_get_cmd")
         return cmd_vel, motvel
@@ -269,7 +272,7 @@ class BatchSolver:
     def stats(self):
         st = np.empty(self.B, dtype=np.int32); it = np.empty(self.B, dtype=np.int32); rs = np.empty(self.B)
         _check(self._L.cfnmpc_get_stats(self._h, st.ctypes.data_as(C.c_void_p), it.ctypes.data_as(C.c_void_p),
-                                        rs.ctypes.data_as(C.c_void_p), 0, None), "cfnmpc_get_stats")
+                                        rs.ctypes.data_as(C.c_void_p), 0, _launch_stream(None, self._device)), "cfnmpc_get_stats")
         return st, it, rs
 
     def get_linearisation(self):
@@ -306,7 +309,7 @@ def sim(x, u, T=0.06, steps=4, out=None):
         import torch
         if out is None:
             out = torch.empty_like(x)
-        px, _d, st, _k = _arg(x, (B, NX)); pu, _d2, _s, _k2 = _arg(u, (B, NU)); po, _d3, _s3, _k3 = _arg(out, (B, NX))
+        px, _d, st, _k = _arg(x, (B, NX), device=_torch_device()); pu, _d2, _s, _k2 = _arg(u, (B, NU), device=_torch_device()); po, _d3, _s3, _k3 = _arg(out, (B, NX), device=_torch_device())
         _check(L.cfnmpc_sim(B, px, pu, float(T), int(steps), po, 1, st), "cfnmpc_sim")
         return out
     xa = np.ascontiguousarray(x, dtype=np.float64); ua = np.ascontiguousarray(u, dtype=np.float64)

@@ -55,11 +55,13 @@ int acados_free(void);
 
 /* ---- setters (copy-in), acados_mpc.cpp:581-582, 590-594, 599-601, 606-607
  *   constraints: stage 0 "lbx"/"ubx" (13 doubles; the solver pins x0 = lbx and requires
- *                ubx == lbx at solve time), "lbu"/"ubu" (4 doubles, stage 0..N-1): stored per stage
- *                and returns 0; the engine solves with ONE box for all inputs and stages, so the
- *                next acados_solve() applies the stored values if they are uniform and otherwise
- *                returns 1 without solving (the reference's FIXED_U0 pin of stage 0,
- *                acados_mpc.cpp:605-608, is compiled out at :111)
+ *                ubx == lbx at solve time), "lbu"/"ubu" (4 doubles, stage 0..N-1): stored PER STAGE and
+ *                PER INPUT, returns 0; the next acados_solve() applies what is stored -- one box for
+ *                all inputs and stages through cfnmpc_set_box when the values are uniform, the per-stage
+ *                boxes through cfnmpc_set_box_stages otherwise (lb == ub pins an input: the reference's
+ *                FIXED_U0 variant, which fixes stage 0 to the input in flight, acados_mpc.cpp:605-608,
+ *                runs as written; tests/test_gpu_box_stages.py) -- and returns 1 without solving only
+ *                if they are inadmissible (lb > ub or NaN somewhere)
  *   cost:        "yref" (17 doubles for stage < N, 13 for stage N); "W" (17x17 resp. 13x13,
  *                diagonal read from either major order; applies to every stage; state weights
  *                >= 0, input weights > 0, checked as a whole before anything is stored) */

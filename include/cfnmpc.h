@@ -201,7 +201,7 @@ int cfnmpc_set_weights(cfnmpc_solver *s, const double *W /*[17]*/, const double 
 /* ocp_nlp_constraints_model_set(.., k, "lbu"/"ubu", ..) equivalent (acados_mpc.cpp:605-608, compiled
  * out by FIXED_U0 0 at :111) for the case the engine supports: ONE input box [u_min, u_max] for all
  * inputs, stages and instances (generate_c_code.py:133-134).  Takes effect at the next
- * cfnmpc_solve.  Per-stage boxes are not offered. */
+ * cfnmpc_solve.  Per-stage, per-input boxes: cfnmpc_set_box_stages below. */
 int cfnmpc_set_box(cfnmpc_solver *s, double u_min, double u_max);
 /* Per-stage, per-input box: lb, ub [B][N][4] (what "lbu" / "ubu" on INDIVIDUAL stages set in acados -- the reference's
  * FIXED_U0 variant pins stage 0 to the input in flight, lbu = ubu = u1, acados_mpc.cpp:605-608).  lb[i] = ub[i] makes
@@ -282,10 +282,6 @@ int cfnmpc_estimate(int batch, const double *meas, double *filt, const double *u
  * order: A [B][N][13][13], Bm [B][N][13][4], b [B][N][13] (host pointers). */
 int cfnmpc_debug_get_linearisation(cfnmpc_solver *s, double *A, double *Bm, double *b);
 /* runs only the linearisation kernel */
-/* experiment: linearisation + start-solve factorisation alternating in chunks of `chunk` stages
- * (0: the product's two kernels); *ms = average duration of one pair over `reps` repetitions */
-int cfnmpc_debug_chunked_pair(cfnmpc_solver *s, int chunk, int reps, double *ms, void *stream);
-int cfnmpc_debug_checksum(cfnmpc_solver *s, double *out3);
 int cfnmpc_debug_linearise(cfnmpc_solver *s, void *stream);
 /* start solve, backward half only (parity tests of the fused kernel, timing): mode 1 = k_linearise + k_factor, 2 = k_linfactor;
  * `reps` repetitions, *ms (may be NULL) = average duration of one, HIP events on `stream` */

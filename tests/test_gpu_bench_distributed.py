@@ -50,3 +50,21 @@ def test_bench_two_ranks_weak_scaling_line():
     assert d["config"]["total_batch"] == 16384 and d["config"]["batch_per_gpu"] == 8192
     assert "weak_scaling" not in d
     assert d["qp_stats"]["status_ok_frac"] == 1.0
+
+
+def test_bench_one_rank_rccl_smoke():
+    """One rank under torchrun with the nccl backend (= RCCL on ROCm): the process group is initialised with the device id
+    and the report's MAX / SUM all-reduces run on device tensors -- so that the driver's 8-GPU launch is not RCCL's first
+    contact with this code (one all-reduce per report, no data-path collective)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-backend", "nccl",
+           "--batch", "4096", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["total_batch"] == 4096 and d["qp_stats"]["status_ok_frac"] == 1.0
+    assert d["report_collective"] == {"backend": "nccl", "world_size": 1, "device": "cuda"}
+    assert d["value"] > 0

@@ -729,23 +729,18 @@ def test_randomised_options_match_restatement(oracle, cref, seed):
         x = xg[:, 1, :].copy()
 
 
-def test_profile_kernels_and_chunked_pair_experiment(oracle):
+def test_profile_kernels_split_adds_up(oracle):
     """cfnmpc_get_profile_kernels: six per-kernel-group durations of the timed steps that add up to cfnmpc_get_profile's two
-    phases; cfnmpc_debug_chunked_pair (the stage-chunked linearise / factor hand-over experiment of DESIGN.md section 5.9)
-    leaves bitwise the gains, feed-forward terms and checkpoints of the plain kernel pair."""
-    import ctypes as C
+    phases.  (The stage-chunked linearise / factor hand-over experiment of DESIGN.md section 5.9 lives in development builds
+    only -- make DEV=1, csrc/cfnmpc_dev.h, tools/chunked_pair.py check -- and is not part of the shipped library.)"""
     from crazyflie_nmpc_amd import BatchSolver, default_opts
     from crazyflie_nmpc_amd.solver import INIT_HOVER
     B, N = 1500, 50
     x0 = oracle.sample_hover_x0(np.random.default_rng(9), B, scale=1.5)
     yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
-
-    def make():
-        s = BatchSolver(B, default_opts())
-        s.set_x0(x0); s.set_yref(np.repeat(yr[None], B, 0).copy(), np.repeat(ye[None], B, 0).copy()); s.init_iterate(INIT_HOVER)
-        s.solve(2)
-        return s
-    s = make()
+    s = BatchSolver(B, default_opts())
+    s.set_x0(x0); s.set_yref(np.repeat(yr[None], B, 0).copy(), np.repeat(ye[None], B, 0).copy()); s.init_iterate(INIT_HOVER)
+    s.solve(2)
     s.set_profiling(True)
     s.solve(3)
     ms, n = s.get_profile_kernels()
@@ -754,18 +749,8 @@ def test_profile_kernels_and_chunked_pair_experiment(oracle):
     lin, qp, n2 = s.get_profile()
     assert n2 == 2 and lin > 0 and qp > lin * 0.5
     s.set_profiling(False)
-    sums = []
-    for chunk in (0, 7, 1, 50):
-        q = make()
-        t = C.c_double(0)
-        assert q._L.cfnmpc_debug_chunked_pair(q._h, chunk, 2, C.byref(t), None) == 0 and t.value > 0
-        k = np.empty(3)
-        assert q._L.cfnmpc_debug_checksum(q._h, k.ctypes.data_as(C.c_void_p)) == 0
-        sums.append(k)
-        q.solve(1)                      # the solver stays usable
-        assert (q.stats()[0] == 0).all()
-    for k in sums[1:]:
-        assert np.array_equal(k, sums[0]), (k, sums[0])
+    assert not hasattr(s._L, "cfnmpc_debug_chunked_pair")   # experiments are not exported by the product build
+    s.close()
 
 
 def test_reinit_failed_option_recovers_a_lost_instance(oracle):
@@ -826,8 +811,12 @@ def test_calls_without_a_stream_argument_follow_torchs_current_stream(oracle):
             s.set_x0(x); s.init_iterate(INIT_HOVER)
             for _ in range(6):
                 s.set_x0(x); s.solve(1); s.get_u(0, out=u); sim(x, u, T=0.015, steps=1, out=xn); x, xn = xn, x
-            (stream or torch.cuda.current_stream(dev)).synchronize()
+            # NO hand synchronisation: the host-array getters (numpy outputs) travel on the same current stream as the
+            # launches, so they are ordered behind the last solve even on a non-blocking pool stream
+            u1h = s.get_u(1)                       # numpy out
             st = s.stats()[0]
+            xi, ui = s.get_iterate()
+            assert np.array_equal(u1h, ui[:, 1, :])
             out = x.cpu().numpy(), u.cpu().numpy(), st.copy()
             s.close()
         return out
