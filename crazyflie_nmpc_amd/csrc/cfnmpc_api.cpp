@@ -82,10 +82,25 @@ struct DeviceGuard {
 
 constexpr size_t MAX_PROFILED_STEPS = 4096;   // cfnmpc_get_profile resets the count
 constexpr size_t EV_PER_STEP = 7;
-constexpr int AS_COMMIT_BELOW = 36864;        // below: the active-set kernel leaves the roll-out to k_ascommit (measured cross-over between 32768 and 49152 instances)
-constexpr int IPM_LIST_FROM = 16384;          // from here on the fall-back rows are compacted before k_ipm_rest
-constexpr int FORWARD_DIV_FROM = 32768;       // k_forward (the division form) from this fleet size (measured at 16 384 and 65 536; cfnmpc_kernels.hip, forward_body)
-constexpr int FORWARD_RG_BELOW = 8192;        // measured cross-over of the two forward sweeps
+// Kernel choices that depend on how the fleet fills the device, in units of its SIMDs (S = 4 x compute units = wave slots at
+// one wave per SIMD; MI355X: 1024) -- measured per horizon, profiles/r04_thresholds.md (tools/threshold_sweep.py):
+//   * forward sweep on the stored blocks (row groups, B / 4 waves) instead of the matrix-free one (B / 64 waves of N
+//     sequential stages): while B / 4 waves fit about twice on the SIMDs; the row-group sweep streams 240 N doubles per
+//     instance, so long horizons leave it earlier (cross-over 7000 instances at N = 30 and 50, 5500 at N = 100);
+//   * active-set solves + commit kernel instead of the monolithic kernel: while the ~8 % constrained rows make fewer
+//     waves than there are SIMDs by a margin (roll-out = latency chain; equal within noise from 16 S to 36 S at N = 30, 50, 100);
+//   * fall-back rows compacted before the interior point: from 16 S instances;
+//   * k_forward in the division form: from B / 64 waves = S / 2 on (the sweep streams at the HBM rate).
+struct Choice { bool forward_rg, as_commit, ipm_listed, forward_div; };
+inline Choice choose_kernels(int batch, int N, int simds) {
+    const long S = simds > 0 ? simds : 1024;
+    Choice c;
+    c.forward_rg = (long)batch < (N <= 64 ? 8 : 6) * S;
+    c.as_commit = (long)batch < 24 * S;
+    c.ipm_listed = (long)batch >= 16 * S;
+    c.forward_div = (long)batch >= 32 * S;
+    return c;
+}
 
 // `on_device` argument: 0 host (synchronous), 2 host (enqueued only), anything else: device pointer
 inline bool is_host(int on_device) { return on_device == CFNMPC_ON_HOST || on_device == CFNMPC_ON_HOST_ASYNC; }
@@ -230,6 +245,13 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     s->parity = 0;
     s->lbs_keep = s->ubs_keep = nullptr;
     s->reinit_failed = o.reinit_failed ? 1 : 0;
+    int simds = 1024;   // SIMDs of the device the solver is created on
+    {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) simds = 4 * prop.multiProcessorCount;
+    }
+    const Choice pick = choose_kernels(batch, o.N, simds);
     // the shooting intervals of a 64-instance group are independent: spread them over enough
     // workgroups to fill the 1024 SIMDs when the batch alone does not (a single instance then
     // linearises its 50 intervals in parallel instead of one after the other)
@@ -238,12 +260,6 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
         // ceil(N / c) stages each (+ a prologue per workgroup) -- take the c that minimises it (rounding groups c UP past the
         // number of SIMDs would cost a whole second round: 255 groups x 5 chunks = 1275 workgroups ran 35 % slower than x 4)
         const int groups = (batch + 63) / 64;
-        int simds = 1024;
-        {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) simds = 4 * prop.multiProcessorCount;
-        }
         int c = 1;
         if (s->overlap) {
             c = 5;
@@ -283,14 +299,14 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.active_set = o.active_set ? 1 : 0;
     if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise) ||
         (o.reinit_failed && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
-    P.forward_div = batch >= FORWARD_DIV_FROM ? 1 : 0;
+    P.forward_div = pick.forward_div ? 1 : 0;
     // (an explicitly fused start solve stores no stage blocks: the automatic choice then stays with the matrix-free sweep)
-    P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && batch < FORWARD_RG_BELOW && o.start_solve != 2) ? 1 : 0;
+    P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && pick.forward_rg && o.start_solve != 2) ? 1 : 0;
     if (o.as_passes < -3 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
     // internal: 0 = monolithic k_as, -1 = every solve in one launch on the compact z store + commit, -2 = the monolithic
     // kernel's solves + commit, p > 0 = p single-solve passes
     P.as_passes = o.as_passes > 0 ? o.as_passes : (o.as_passes == -2 ? -1 : (o.as_passes == -3 ? -2 : 0));
-    if (o.as_passes == 0 && batch < AS_COMMIT_BELOW && o.start_solve != 2) P.as_passes = -2;   // small fleets: solves + commit kernel (measured); the commit kernel reads stored blocks
+    if (o.as_passes == 0 && pick.as_commit && o.start_solve != 2) P.as_passes = -2;   // small fleets: solves + commit kernel (measured); the commit kernel reads stored blocks
 #ifdef CFN_DEV
     if (const char* e = std::getenv("CFNMPC_AS_PASSES")) {   // (internal encoding)
         const int v = std::atoi(e);
@@ -298,8 +314,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     }
 #endif
     {   // pass launches: two wavefronts per SIMD of this device
-        hipDeviceProp_t prop;
-        P.as_grid = hipGetDeviceProperties(&prop, s->device) == hipSuccess ? 8 * prop.multiProcessorCount : 2048;
+        P.as_grid = 2 * simds;
 #ifdef CFN_DEV
         if (const char* e = std::getenv("CFNMPC_AS_GRID")) { const int v = std::atoi(e); if (v > 0) P.as_grid = v; }
 #endif
@@ -307,7 +322,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     // one fall-back row per wave is as fast as four while those waves fit one per SIMD (1024 rows: 1.6 % of 65 536 instances,
     // 2.5 % fall back at three times the bench's disturbances): only large fleets pay the compaction's extra launch
     P.as_sparse_max = P.as_grid / 2;   // = the SIMDs of the device: one constrained row per wave while they all fit at once
-    P.ipm_listed = batch >= IPM_LIST_FROM ? 1 : 0;
+    P.ipm_listed = pick.ipm_listed ? 1 : 0;
     // start solve: the fused kernel replaces k_linearise + k_factor where nothing but the constrained instances' QP kernels
     // reads the stage blocks afterwards (matrix-free forward sweep, monolithic active-set kernel, no partial condensing,
     // no overlapped preparation); per-stage boxes (cfnmpc_set_box_stages) switch a solver back at launch time

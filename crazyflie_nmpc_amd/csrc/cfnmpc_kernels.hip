@@ -283,10 +283,13 @@ __global__ __launch_bounds__(64) void k_linearise_clist(Params P, int which) {
 // row zero), else from the terminal cost.
 // klo / park / from_park: only the stages [klo, head) of the sweep, cost-to-go taken from / left in `park`
 // ([wave][13][64 lanes]) -- the stage-chunked hand-over experiment (k_factor_chunk); the defaults fold away.
-template <bool ABSOLUTE>
+// QTAB: diagonal weights through the LDS table of factor_stage (frees the ~34 registers of their hoisted selects);
+// DEEP: three rotating stage buffers -- the loads of stage k - 2 are issued before the arithmetic of stage k (the start
+// solve streams 1.75 KB per stage and wave from HBM; with two buffers its waves wait a quarter of their time).
+template <bool ABSOLUTE, bool QTAB = false, bool DEEP = false>
 __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, const int head, const int chk,
                                              double* wt, double* sb, const int klo = 0, gdouble* park = nullptr,
-                                             const bool from_park = false) {
+                                             const bool from_park = false, const double* qtab = nullptr) {
     double Pa[13];
     if (from_park) {
         SFOR(j, 0, 13, { Pa[j] = park[j * 64 + threadIdx.x]; });
@@ -313,15 +316,36 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
     const double is13 = t.L == 13 ? 1.0 : 0.0;
     auto after = [&](int k) {
         if (ABSOLUTE) {
-            // checkpoints of the unconstrained cost-to-go (matrix part only)
-            SFOR(c, 0, N_CHK, {
-                if (k == chk_stage(c)) {
-                    gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + c) * SZ_P;
-                    SFOR(j, 0, 13, { if (t.L < 13) pc[(j * 4 + t.q) * 13 + t.L] = Pa[j]; });
-                }
-            });
+            // checkpoints of the unconstrained cost-to-go (matrix part only); one store block with a run-time checkpoint
+            // index (six specialised blocks keep six hoisted addresses alive through the whole sweep)
+            int cidx = -1;
+            SFOR(c, 0, N_CHK, { if (k == chk_stage(c)) cidx = c; });
+            if (cidx >= 0) {
+                gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + cidx) * SZ_P;
+                SFOR(j, 0, 13, { if (t.L < 13) pc[(j * 4 + t.q) * 13 + t.L] = Pa[j]; });
+            }
         }
     };
+    if constexpr (DEEP) {
+        StageIn<ABSOLUTE> b0, b1, b2;
+        load_stage<ABSOLUTE>(P, t, head - 1, wq, b0);
+        load_stage<ABSOLUTE>(P, t, imax(head - 2, 0), wq, b1);
+        int k = head - 1;
+        while (k >= klo) {
+            load_stage<ABSOLUTE>(P, t, imax(k - 2, 0), wq, b2);
+            ok = factor_stage<ABSOLUTE, false, false, QTAB>(P, t, k, Pa, b0, wq, is13, wt, sb, true, qtab) && ok;
+            after(k);
+            if (--k < klo) break;
+            load_stage<ABSOLUTE>(P, t, imax(k - 2, 0), wq, b0);
+            ok = factor_stage<ABSOLUTE, false, false, QTAB>(P, t, k, Pa, b1, wq, is13, wt, sb, true, qtab) && ok;
+            after(k);
+            if (--k < klo) break;
+            load_stage<ABSOLUTE>(P, t, imax(k - 2, 0), wq, b1);
+            ok = factor_stage<ABSOLUTE, false, false, QTAB>(P, t, k, Pa, b2, wq, is13, wt, sb, true, qtab) && ok;
+            after(k);
+            --k;
+        }
+    } else {
     // two stage buffers used alternately (no hand-over copies): while stage k is computed from
     // one, stage k-1 is being loaded into the other
     StageIn<ABSOLUTE> bufA, bufB;
@@ -329,14 +353,15 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
     int k = head - 1;
     while (k >= klo) {
         load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufB);
-        ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufA, wq, is13, wt, sb) && ok;
+        ok = factor_stage<ABSOLUTE, false, false, QTAB>(P, t, k, Pa, bufA, wq, is13, wt, sb, true, qtab) && ok;
         after(k);
         k--;
         if (k < klo) break;
         load_stage<ABSOLUTE>(P, t, imax(k - 1, 0), wq, bufA);
-        ok = factor_stage<ABSOLUTE>(P, t, k, Pa, bufB, wq, is13, wt, sb) && ok;
+        ok = factor_stage<ABSOLUTE, false, false, QTAB>(P, t, k, Pa, bufB, wq, is13, wt, sb, true, qtab) && ok;
         after(k);
         k--;
+    }
     }
     if (park) SFOR(j, 0, 13, { park[j * 64 + threadIdx.x] = Pa[j]; });
     return ok;
@@ -650,11 +675,21 @@ __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, 
 // =============================================================================================
 // start solve: backward factorisation, forward sweep
 // =============================================================================================
+#ifndef CFN_FACTOR_DEEP
+#define CFN_FACTOR_DEEP 1
+#endif
+// (Round 4, measured: the same sweep at THREE waves per SIMD -- a lean stage of 168 registers: affine row through the LDS tile,
+//  gain by triangular substitutions, M accumulated into the new cost-to-go, scalar base addresses; 5 spilled registers --
+//  passes the parity tests and runs SLOWER: 1.60 - 1.66 against 1.56 - 1.58 ms at 65 536 instances, 0.152 against 0.126 ms at
+//  4096.  Occupancy is not what this kernel lacks; three stage buffers are worth 2.5 %.  profiles/r04_factor_variants.md)
 KALIGN __global__ __launch_bounds__(64, 2) void k_factor(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
+    __shared__ __attribute__((aligned(16))) double qtab[16 * QT_ROW];
     const Lane t = lane_id(P);
-    bool ok = sweep_factor<true>(P, t, P.N, -1, wtile[t.row], btile[t.row]);
+    qtab_fill(P, qtab);
+    __syncthreads();
+    bool ok = sweep_factor<true, true, CFN_FACTOR_DEEP != 0>(P, t, P.N, -1, wtile[t.row], btile[t.row], 0, nullptr, false, qtab);
     ok = row_min(ok ? 1.0 : 0.0) > 0.0;
     if (t.L == 0 && t.valid) gm(P.status)[t.inst] = ok ? 0 : 4;
 }
@@ -2687,10 +2722,11 @@ void launch_linearise_clist(const Params& P, int chunks, int which, hipStream_t 
     hipLaunchKernelGGL(k_linearise_clist, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P, which);
 }
 // ev (optional, cfnmpc_set_profiling): events recorded after k_factor, after the forward sweep, after the compaction
+void launch_factor_only(const Params& P, hipStream_t st);
 void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev, bool skip_factor) {
     if (skip_factor) {}   // (sub-fleet pipeline: the backward sweep was launched on the start-solve stream)
     else if (P.fused && !P.lbs) launch_linfactor(P, st);   // fused start solve (cfnmpc_linfactor.hip); per-stage boxes: stored path
-    else hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
+    else launch_factor_only(P, st);
     if (ev) (void)hipEventRecord(ev[0], st);
     if (P.lbs) {   // per-stage boxes: the row-group forward sweep carries them
         hipLaunchKernelGGL(k_forward_rg_sbox, dim3(P.NW), dim3(64), 0, st, P);

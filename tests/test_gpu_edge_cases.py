@@ -516,25 +516,30 @@ def test_create_rejects_bad_options_and_windows_without_trajectory(oracle):
     assert np.array_equal(ref.get_u(0), s2.get_u(0))
 
 
-@pytest.mark.parametrize("B", [3, 130, 7000, 8257])   # (8257: ragged, the default there is the matrix-free k_forward_mid)
-def test_forward_sweep_variants_agree(oracle, cref, B):
+@pytest.mark.parametrize("B,N", [(3, 50), (130, 50), (7000, 50), (8257, 50),      # (8257: ragged, the default there is the matrix-free sweep)
+                                 (130, 30), (7000, 30), (8200, 30),            # config C5's other horizons: the cross-over
+                                 (130, 100), (6100, 100), (6200, 100)])        # is chosen in waves per SIMD and by N
+def test_forward_sweep_variants_agree(oracle, cref, B, N):
     """cfnmpc_opts.forward_sweep: the matrix-free forward sweep (1, the large-batch kernel) and the
     sweep on the stored blocks (2, the small-batch kernel) give the same closed loops to rounding --
-    and the default picks by batch size; both against the CPU restatement at 1e-8."""
+    and the default picks by how the fleet fills the device (cfnmpc_api.cpp: choose_kernels; below 8 x SIMDs instances
+    for N <= 64, 6 x SIMDs beyond: profiles/r04_thresholds.md); both against the CPU restatement at 1e-8."""
+    import torch
     from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
     from crazyflie_nmpc_amd.solver import INIT_HOVER
     rng = np.random.default_rng(17)
     x0 = oracle.sample_hover_x0(rng, B, scale=1.3)
-    yr, ye = oracle.regulation_yref(50, (0.0, 0.0, 0.4))
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
     yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
-    sol = {fs: BatchSolver(B, default_opts(forward_sweep=fs)) for fs in (0, 1, 2)}
+    sol = {fs: BatchSolver(B, default_opts(N=N, forward_sweep=fs)) for fs in (0, 1, 2)}
     for s in sol.values():
         s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
     nchk = min(B, 64)
-    xr = np.repeat(x0[:nchk, None, :], 51, 1).copy(); ur = np.full((nchk, 50, 4), HOV)
-    opts = cref.default_opts(active_set=1)
+    xr = np.repeat(x0[:nchk, None, :], N + 1, 1).copy(); ur = np.full((nchk, N, 4), HOV)
+    opts = cref.default_opts(N=N, active_set=1)
+    simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     x = x0.copy()
-    for t in range(6):
+    for t in range(6 if N == 50 else 3):
         res = {}
         for fs, s in sol.items():
             s.set_x0(x); s.solve(1)
@@ -543,7 +548,7 @@ def test_forward_sweep_variants_agree(oracle, cref, B):
             res[fs] = s.get_iterate() + (it,)
         assert np.abs(res[1][0] - res[2][0]).max() < 1e-9 and np.abs(res[1][1] - res[2][1]).max() < 1e-9
         assert ((res[1][2] > 0) == (res[2][2] > 0)).all()
-        same = 2 if B < 8192 else 1
+        same = 2 if B < (8 if N <= 64 else 6) * simds else 1
         assert np.array_equal(res[0][0], res[same][0]) and np.array_equal(res[0][1], res[same][1])
         st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x[:nchk].copy(), yref[:nchk], yref_e[:nchk], nthreads=0)
         assert np.abs(res[2][1][:nchk] - ur).max() < 1e-8 and np.abs(res[2][0][:nchk] - xr).max() < 1e-8
@@ -552,6 +557,8 @@ def test_forward_sweep_variants_agree(oracle, cref, B):
             if fs != 2:
                 s.set_iterate(res[2][0], res[2][1])
         x = sim(x, res[2][1][:, 0, :].copy(), T=0.015, steps=1)
+    for s in sol.values():
+        s.close()
 
 
 def test_multi_gpu_fleet_shards_match_single_solver(oracle):

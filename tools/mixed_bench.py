@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--opt", action="append", default=[], help="cfnmpc_opts field = integer value, e.g. --opt as_passes=-1")
     args = ap.parse_args()
     import torch
     from crazyflie_nmpc_amd import sim
@@ -28,7 +29,7 @@ def main():
     B, P = args.batch, 20
     rng = np.random.default_rng(5)
     horizons = rng.choice([30, 50, 100], size=B)
-    fleet = MixedHorizonFleet(horizons)
+    fleet = MixedHorizonFleet(horizons, **{k: int(v) for k, v in (a.split('=') for a in args.opt)})
     fleet.set_regulation(np.tile([0.0, 0.0, 0.4], (B, 1)), 15.7777)
     x = torch.from_numpy(sample_hover_x0(rng, B)).to(dev)
     xn = torch.empty_like(x)
