@@ -25,8 +25,9 @@ def step(f, t):
     f["x"], f["xn"] = f["xn"], f["x"]
     if t % 10 == 9:   # the bench's disturbance, roughly
         f["x"][:, 7:10] += 0.3 * torch.randn((f["x"].shape[0], 3), dtype=torch.float64, device=dev)
-for nsplit in (1, 2):
-    fl = [make(B // nsplit, 7 + i) for i in range(nsplit)]
+for nsplit in (1, 2, 3, 4):
+    per = (B // nsplit) // 64 * 64
+    fl = [make(per if i < nsplit - 1 else B - per * (nsplit - 1), 7 + i) for i in range(nsplit)]
     st = [torch.cuda.Stream(dev) for _ in range(nsplit)]
     def run(n):
         for t in range(n):
@@ -35,5 +36,5 @@ for nsplit in (1, 2):
                     step(f, t)
     run(10); torch.cuda.synchronize()
     t0 = time.time(); run(30); torch.cuda.synchronize(); dt = (time.time() - t0) / 30
-    print(f"start_solve {mode}  {nsplit} stream(s) x {B // nsplit}: {dt * 1e3:.3f} ms per step of the whole fleet = {B / dt / 1e6:.2f} M steps/s", flush=True)
+    print(f"start_solve {mode}  {nsplit} stream(s) x ~{B // nsplit}: {dt * 1e3:.3f} ms per step of the whole fleet = {B / dt / 1e6:.2f} M steps/s", flush=True)
     for f in fl: f["s"].close()
