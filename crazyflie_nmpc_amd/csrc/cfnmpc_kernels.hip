@@ -256,6 +256,12 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
 #undef CFN_DIV
     }
 }
+// (Round 4, measured: the same linearisation at TWO waves per SIMD -- RK points kept as q | v | w only (10 instead of 31 doubles per
+//  point; a column rebuilds R(q) and forms d(R v) from (q, dq) on the fly), columns leaving in pairs through two LDS tiles, the next
+//  state re-fetched instead of carried: 256 registers, 13.6 KB of LDS, parity-green -- needs 9300 instead of 6267 vector instructions
+//  per stage (run-time unit vectors and tile indices, rebuilt rotation matrices) and ran 1.69 - 1.75 ms against 1.19 ms at 65 536
+//  instances (2048 workgroups of 25 stages), 2.05 ms with one workgroup per 64 instances: the second wave did not raise the VALU
+//  occupancy (~54 % either way).  Removed; profiles/r04_linearise_variants.md.)
 KALIGN __global__ __launch_bounds__(64) void k_linearise(Params P) {
     __shared__ double sx[64 * 13];       // one 13-vector per instance (internal order)
     __shared__ double sc[4][64 * 13];    // up to four sensitivity columns, [inst][row] (internal order)
