@@ -561,8 +561,9 @@ __device__ __forceinline__ int as_restart_mono(int jm, int head, int sh) {   // 
     const int jr = (((jm >> sh) + 1) << sh) - 1;
     return (jr + 1 < head && ((jr + 1) >> sh) < AS_PSAVE) ? jr : head - 1;
 }
+template <bool QT = false>
 __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, const int head, const int chk,
-                                                const int kstart, double* wt, double* sb) {
+                                                const int kstart, double* wt, double* sb, const double* qtab = nullptr) {
     const int sh = as_pg_shift(head);
     double Pa[13];
     if (kstart + 1 < head) {
@@ -592,11 +593,11 @@ __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, 
     int k = kstart;
     while (k >= 0) {
         load_stage_as(P, t, imax(k - 1, 0), bufB);
-        ok = factor_stage<true, true>(P, t, k, Pa, bufA, wq, is13, wt, sb) && ok;
+        ok = factor_stage<true, true, false, QT>(P, t, k, Pa, bufA, wq, is13, wt, sb, true, qtab) && ok;
         keep(k);
         if (--k < 0) break;
         load_stage_as(P, t, imax(k - 1, 0), bufA);
-        ok = factor_stage<true, true>(P, t, k, Pa, bufB, wq, is13, wt, sb) && ok;
+        ok = factor_stage<true, true, false, QT>(P, t, k, Pa, bufB, wq, is13, wt, sb, true, qtab) && ok;
         keep(k);
         --k;
     }
@@ -1310,8 +1311,9 @@ __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave
 // CST (fused start solve, Params.fused = 1): the instance's (A, B, b) of ALL stages are already in the wave's compact blocks
 // (k_linearise_clist wrote them there; the home blocks hold none) -- nothing to gather but the 4-vectors and the
 // checkpoint, and the roll-out reads the compact copy over the whole horizon.
-template <int MODE, bool SBOX = false, bool CST = false>
-__device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64], const int vb) {
+template <int MODE, bool SBOX = false, bool CST = false, bool QT = false>
+__device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64], const int vb,
+                                        const double* qtab = nullptr) {
 #ifdef CFN_PROF
     unsigned long long pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, plast = wall_clock64();
     const unsigned long long pstart = plast;
@@ -1444,7 +1446,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             const bool any_try = __any(try_as);
             for (int it = 1; any_try && it <= AS_MAX_SOLVES; it++) {
                 PROF_T(1)
-                as_ok = sweep_factor_as(Q, tc, head, chk, kstart, wt, sb) && as_ok;
+                as_ok = sweep_factor_as<QT>(Q, tc, head, chk, kstart, wt, sb, qtab) && as_ok;
                 PROF_T(2)
                 PROF_SOLVE(kstart + 1)
                 int jw = sweep_forward_as<SBOX, NO_ROLL>(Q, tc, head);
@@ -1866,7 +1868,10 @@ __global__ __launch_bounds__(64) void k_ipm(Params P) {       // MODE 0: used wh
 KALIGN __global__ __launch_bounds__(64) void k_as(Params P) {        // active-set solves
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<1>(P, wtile, btile, blockIdx.x);
+    __shared__ __attribute__((aligned(16))) double qtab[16 * QT_ROW];
+    qtab_fill(P, qtab);
+    __syncthreads();
+    qp_wave<1, false, false, true>(P, wtile, btile, blockIdx.x, qtab);
 }
 __global__ __launch_bounds__(64) void k_ipm_rest(Params P) {  // interior point for what k_as left
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
@@ -1908,7 +1913,10 @@ __global__ __launch_bounds__(64) void k_ipm_rest_cst(Params P) {
 __global__ __launch_bounds__(64) void k_as_solves(Params P) {  // MODE 4: active-set solves, no roll-out
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    qp_wave<4>(P, wtile, btile, blockIdx.x);
+    __shared__ __attribute__((aligned(16))) double qtab[16 * QT_ROW];
+    qtab_fill(P, qtab);
+    __syncthreads();
+    qp_wave<4, false, false, true>(P, wtile, btile, blockIdx.x, qtab);
 }
 __global__ __launch_bounds__(64) void k_as_retry(Params P) {  // MODE 3: rows the commit kernel sent back
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];

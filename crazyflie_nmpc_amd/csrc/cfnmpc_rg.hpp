@@ -340,7 +340,7 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
     // (4) S = R^ + B'V in lanes a < 4, replicated; every lane inverts it redundantly (4x4 Cholesky),
     //     one pivot at a time BETWEEN the blocks of (5) and (6), which hide the pivots' latency
     double Srow[4];
-    if (QTAB) SFOR(c, 0, 4, { Srow[c] = qtab[t.L * QT_ROW + 13 + c]; });
+    if (QTAB && ABSOLUTE && !AS) SFOR(c, 0, 4, { Srow[c] = qtab[t.L * QT_ROW + 13 + c]; });   // (R constant: start solve only)
     else SFOR(c, 0, 4, { Srow[c] = (t.L == c) ? in.Rh : 0.0; });
     dot4bc<13>(Srow[0], Srow[1], Srow[2], Srow[3], bcl, V[0], V[1], V[2], V[3]);
     SFOR(c, 0, 4, { settle(Srow[c]); });
