@@ -244,44 +244,6 @@ class Fleet:
         self.solver.close()
 
 
-def sub_fleet_run(batch, nsub, dev, seed, steps, warmup):
-    """The fleet as `nsub` independent sub-fleets, each with its own solver object and HIP stream, stepping WITHOUT waiting
-    for each other (what cfnmpc_multi_* does with repeated device ids): the latency-bound tail of one sub-fleet's step
-    (active-set solves) runs beside the streaming kernels of the others.  A deployment option, not the headline
-    configuration; measured beside it.  -> dict for the `sensitivity` block."""
-    import torch
-    per = (batch // nsub) // 64 * 64
-    sizes = [per] * (nsub - 1) + [batch - per * (nsub - 1)]
-    streams = [torch.cuda.Stream(dev) for _ in range(nsub)]
-    fleets = []
-    for i, (n, st) in enumerate(zip(sizes, streams)):
-        with torch.cuda.stream(st):
-            fleets.append(Fleet(n, dev, np.random.default_rng(seed + 17 * i), "hover", 1.0, stream=st))
-
-    def run(k):
-        for _ in range(k):
-            for f, st in zip(fleets, streams):
-                with torch.cuda.stream(st):
-                    f.step()
-    run(warmup)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run(steps)
-    torch.cuda.synchronize(dev)
-    el = time.perf_counter() - t0
-    ok = solves = 0.0
-    for f in fleets:
-        st, it, _ = f.solver.stats()
-        ok += float((st == 0).sum()); solves += float(it.sum())
-        f.close()
-    del fleets
-    torch.cuda.empty_cache()
-    return {"value": batch * steps / el, "ms_per_step": el / steps * 1e3, "sub_fleets": sizes, "status_ok_frac": ok / batch,
-            "mean_qp_solves": solves / batch,
-            "note": "every vehicle advances one RTI step per step, as in the headline; sub-fleets run on their own streams and do not "
-                    "wait for each other between steps"}
-
-
 def mixed_horizon_run(batch, dev, rng, steps, warmup, predictor="queued"):
     """Config C5: `batch` vehicles with N in {30, 50, 100} (one cfnmpc_fleet = one solver per horizon
     bucket behind one handle), regulation targets U(-1,1)^2 x U(0.2,1); the plant applies every input 60 ms
@@ -523,7 +485,6 @@ def main():
         extras["config_C2_batch_4096"] = brief(measure(4096, 40, 40, seed_off=6))
         extras["batch_8192 (one GPU's share of 65536 at 8 GPUs)"] = brief(measure(8192, 40, 40, seed_off=7))
         extras["config_C4_figure8_tracking"] = brief(measure(B_rank, 20, ws, workload="figure8", seed_off=8))
-        extras["four_free_running_sub_fleets (own solver + stream each)"] = sub_fleet_run(B_rank, 4, dev, seed + 5000, 20, ws)
         extras["config_C5_mixed_horizons_30_50_100_delay_compensated"] = mixed_horizon_run(B_rank, dev, np.random.default_rng(seed + 9000), 20, ws)
         extras["config_C5_mixed_horizons_30_50_100_delay_compensated"]["predictor"] = (
             "x0 = RK4 prediction over the 60 ms delay THROUGH THE FOUR QUEUED INPUTS (oldest first); the reference's estimator holds the "
