@@ -147,3 +147,38 @@ def test_fused_path_equals_stored_path(oracle, B, kick):
         assert nipm > 0     # the compacted fall-back list (k_ipm_list + second k_linearise_clist) was exercised
     for s in sol:
         s.close()
+
+
+def test_start_solve_option_validation_and_per_stage_boxes(oracle):
+    """start_solve = 2 is refused together with what reads the stored blocks (cond_N2, forward_sweep = 2, as_passes = -3,
+    overlap_linearise); a fused solver that later gets per-stage boxes (cfnmpc_set_box_stages) switches to the stored-block
+    kernels at launch time and equals a stored-block solver with the same boxes."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    for bad in (dict(cond_N2=10), dict(forward_sweep=2), dict(as_passes=-3), dict(overlap_linearise=1), dict(start_solve=4)):
+        kw = dict(start_solve=2); kw.update(bad)
+        with pytest.raises(Exception):
+            BatchSolver(16, default_opts(**kw))
+    B, N = 300, 50
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=3, scale=2.0)
+    lb = np.zeros((B, N, 4)); ub = np.full((B, N, 4), 22.0)
+    ub[:, 3:9, :] = 18.0                       # a tighter box on a few stages
+    lb[:, 0, :] = ub[:, 0, :] = HOV            # and the FIXED_U0 pattern: stage 0 pinned
+    outs = []
+    for mode in (1, 2):
+        s = BatchSolver(B, default_opts(start_solve=mode, as_passes=-1, forward_sweep=1))
+        s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+        s.solve(1)                              # (mode 2: one fused step first)
+        s.set_box_stages(lb, ub)
+        s.set_x0(x0); s.init_iterate(INIT_HOVER); s.solve(2)
+        st, it, _ = s.stats()
+        outs.append((st, it) + s.get_iterate())
+        s.set_box_stages(None, None)            # back to the scalar box: the fused kernels again
+        s.solve(1)
+        assert (s.stats()[0] == 0).mean() > 0.99
+        s.close()
+    (st1, it1, x1, u1), (st2, it2, x2, u2) = outs
+    assert np.array_equal(st1, st2) and (st1 == 0).mean() > 0.99
+    ok = st1 == 0
+    assert np.abs(u1[ok] - u2[ok]).max() < 1e-8 and np.abs(x1[ok] - x2[ok]).max() < 1e-8
+    assert np.abs(u1[ok][:, 0, :] - HOV).max() < 1e-9
