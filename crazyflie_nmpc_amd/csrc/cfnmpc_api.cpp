@@ -171,7 +171,7 @@ bool weights_ok(const double* W, const double* WN) {
 
 extern "C" {
 
-const char* cfnmpc_version(void) { return "cfnmpc 0.7 (gfx950; row-group Riccati with fused DPP broadcast FMAs, lane-per-instance linearisation and matrix-free forward sweep, primal-dual active-set QP solves; options: partial condensing, small-fleet forward sweep; device output stage; multi-GPU shards)"; }
+const char* cfnmpc_version(void) { return "cfnmpc 0.8 (gfx950; row-group Riccati with fused DPP broadcast FMAs, lane-per-instance linearisation and matrix-free forward sweep, primal-dual active-set QP solves; options: fused start solve (linearisation inside the factorisation), partial condensing, small-fleet forward sweep; device output stage; multi-GPU shards)"; }
 
 void cfnmpc_default_opts(cfnmpc_opts* o) {
     // generate_c_code.py:41-42,63-84,109,133-134

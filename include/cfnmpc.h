@@ -162,9 +162,13 @@ typedef struct cfnmpc_opts {
                             the LDS tile of the W transpose) and (A, B, b) never touch HBM; the constrained instances alone
                             are re-linearised straight into the compact store of their QP kernels (k_linearise_clist);
                             3 = validation: the fused kernel for the factorisation, the stored blocks for everything behind it;
-                            0 (default) = by configuration and fleet size (2 where the step streams at the HBM rate; 1 for
-                            small fleets, per-stage boxes, cond_N2, overlap_linearise, as_passes != -1 and forward_sweep = 2,
-                            whose kernels read the stored blocks).  Same results to rounding (tests/test_gpu_linfactor.py). */
+                            0 (default) = 1: measured on MI355X the fused kernel takes the step's HBM traffic from 17.8 to 8.0 GB
+                            and is bound by its vector instructions instead (k_linfactor 2.85 - 2.99 ms against 2.70 - 2.87 ms for
+                            the pair).  2 is refused (CFNMPC_EINVAL) together with what reads the stored
+                            blocks: cond_N2, overlap_linearise, forward_sweep = 2, as_passes other than 0 / -1; it switches the
+                            automatic choices to the matrix-free forward sweep and the monolithic active-set kernel, and a solver
+                            that is given per-stage boxes later runs the stored-block kernels while they are set.  Same results
+                            to rounding (tests/test_gpu_linfactor.py). */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);
