@@ -781,7 +781,10 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
 // the sweep FASTER where it is a latency chain (8192 instances 0.210 -> 0.187 ms, 16 384: 0.228 -> 0.205 ms) and SLOWER
 // where it streams at the HBM rate (65 536 instances, 1024 waves in step: 0.617 -> 0.666 ms, three A/B/A runs on one box),
 // so the launcher picks by fleet size (Params.forward_div).
-template <bool COND, bool FWD_DIV = false>
+// FUSED_PT (round 4, k_forward_mid): nominal slope and directional derivative of an RK point from ONE evaluation with shared
+// sub-expressions (cfnmpc_model.hpp: lf_point, 151 FP64 instructions per point instead of f_expl + jac_point + jvp's ~225) --
+// where the sweep is a latency chain of N stages the shorter stream is the shorter chain.
+template <bool COND, bool FWD_DIV = false, bool FUSED_PT = false>
 __device__ __forceinline__ void forward_body(const Params& P, double* xs, double* cs, int* sflag) {
     // 13-vectors travel through LDS tiles [instance][13] so that every global access of the wave
     // is a contiguous run (as in k_linearise); K, d, u, v are 32-byte runs per lane already.
@@ -875,6 +878,29 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
             jud[2] = 2.0 * KB * (p0 - p1 - p2 + p3);
             jud[3] = 2.0 * KC * (p0 - p1 + p2 - p3);
         }
+        double dxp[13];   // dx_{k+1} + x_{k+1}
+        if constexpr (FUSED_PT) {
+            double rot[4];
+            {
+                const double s1 = uc[0] * uc[0], s2 = uc[1] * uc[1], s3 = uc[2] * uc[2], s4 = uc[3] * uc[3];
+                rot[0] = KT * (s1 + s2 + s3 + s4);
+                rot[1] = KA * (s1 + s2 - s3 - s4);
+                rot[2] = KB * (s1 - s2 - s3 + s4);
+                rot[3] = KC * (s1 - s2 + s3 - s4);
+            }
+            double xq[10], sq[10];
+            SFOR(e, 0, 10, { xq[e] = x[e + 3]; sq[e] = s[e + 3]; });
+            lf_point(xq, sq, rot, jud, kk, dk);
+            SFOR(e, 0, 13, { acc[e] = dk[e]; ks[e] = kk[e]; });
+            SFOR(e, 0, 10, { xq[e] = x[e + 3] + 0.5 * h * kk[e + 3]; sq[e] = s[e + 3] + 0.5 * h * dk[e + 3]; });
+            lf_point(xq, sq, rot, jud, kk, dk);
+            SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; ks[e] += 2.0 * kk[e]; });
+            SFOR(e, 0, 10, { xq[e] = x[e + 3] + 0.5 * h * kk[e + 3]; sq[e] = s[e + 3] + 0.5 * h * dk[e + 3]; });
+            lf_point(xq, sq, rot, jud, kk, dk);
+            SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; ks[e] += 2.0 * kk[e]; });
+            SFOR(e, 0, 10, { xq[e] = x[e + 3] + h * kk[e + 3]; sq[e] = s[e + 3] + h * dk[e + 3]; });
+            lf_point(xq, sq, rot, jud, kk, dk);
+        } else {
         JacPoint J;
         // stage 1
         f_expl<FWD_DIV>(x, uc, kk);
@@ -900,7 +926,7 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
-        double dxp[13];   // dx_{k+1} + x_{k+1}
+        }
         SFOR(i, 0, 13, {
             constexpr int e = ext_of(i);
             const double phi = x[e] + (h / 6.0) * (ks[e] + kk[e]);
@@ -971,10 +997,13 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
     }
 }
 
+#ifndef CFN_FWD_BIG_FUSED
+#define CFN_FWD_BIG_FUSED 0
+#endif
 KALIGN __global__ __launch_bounds__(64) void k_forward(Params P) {   // large fleets (see FWD_DIV above)
     __shared__ double xs[64 * 13], cs[64 * 13];
     __shared__ int sflag[64];
-    forward_body<false, true>(P, xs, cs, sflag);
+    forward_body<false, true, CFN_FWD_BIG_FUSED != 0>(P, xs, cs, sflag);
 }
 // the same at two waves per SIMD (<= 256 registers, a few spills): beside the fused start solve of ANOTHER sub-fleet, whose
 // waves leave half a SIMD's register file each (cfnmpc_opts.sub_fleets)
@@ -983,10 +1012,13 @@ __global__ __launch_bounds__(64, 2) void k_forward_half(Params P) {
     __shared__ int sflag[64];
     forward_body<false, true>(P, xs, cs, sflag);
 }
-__global__ __launch_bounds__(64) void k_forward_mid(Params P) {   // fleets below cfnmpc_api.cpp's FORWARD_DIV_FROM
+#ifndef CFN_FWD_FUSED
+#define CFN_FWD_FUSED 1
+#endif
+__global__ __launch_bounds__(64) void k_forward_mid(Params P) {   // fleets below 32 x SIMDs instances (cfnmpc_api.cpp: choose_kernels)
     __shared__ double xs[64 * 13], cs[64 * 13];
     __shared__ int sflag[64];
-    forward_body<false, false>(P, xs, cs, sflag);
+    forward_body<false, false, CFN_FWD_FUSED != 0>(P, xs, cs, sflag);
 }
 __global__ __launch_bounds__(64) void k_cforward(Params P) {
     __shared__ double xs[64 * 13], cs[64 * 13];

@@ -73,69 +73,6 @@ __device__ __forceinline__ LfLane lf_lane(const int L) {
     return r;
 }
 
-// f(x, u) and (df/dx)(x) s + (df/du) du at one RK point, evaluated TOGETHER (export_ode_model.py:85-97 and its
-// directional derivative, restated with shared sub-expressions: in this mapping a lane integrates one column only, so
-// a Jacobian point kept for several columns -- cfnmpc_model.hpp: jac_point / jvp -- would be built for a single use).
-//   xq[10] = q | v | w of the point, sq[10] = the direction's q | v | w parts (nothing depends on position);
-//   rot[4] = the rotor terms of v_z', w' (functions of u only: constant over the interval), ju[4] = (df/du) du rows 9..12;
-//   kk[13], dk[13]: slopes in EXTERNAL order.  With r = R(q) / 2:  p' = R v,  dp' = R dv + dR v.
-__device__ __forceinline__ void lf_point(const double (&xq)[10], const double (&sq)[10], const double (&rot)[4],
-                                         const double (&ju)[4], double (&kk)[13], double (&dk)[13]) {
-    const double q1 = xq[0], q2 = xq[1], q3 = xq[2], q4 = xq[3], vx = xq[4], vy = xq[5], vz = xq[6];
-    const double wx = xq[7], wy = xq[8], wz = xq[9];
-    const double a = sq[0], b = sq[1], c = sq[2], d = sq[3], sx = sq[4], sy = sq[5], sz = sq[6];
-    const double ox = sq[7], oy = sq[8], oz = sq[9];
-    // r = R / 2
-    const double t11 = q1 * q1 - 0.5;
-    const double r0 = q2 * q2 + t11, r4 = q3 * q3 + t11, r8 = q4 * q4 + t11;
-    const double p14 = q1 * q4, p13 = q1 * q3, p12 = q1 * q2;
-    const double r1 = q2 * q3 - p14, r3 = q2 * q3 + p14;
-    const double r2 = q2 * q4 + p13, r6 = q2 * q4 - p13;
-    const double r5 = q3 * q4 - p12, r7 = q3 * q4 + p12;
-    // dr = dR / 2 (the diagonal entries halved once more: they meet 2 v below)
-    const double e1 = q1 * a;
-    const double h0 = q2 * b + e1, h4 = q3 * c + e1, h8 = q4 * d + e1;
-    const double d23 = q2 * c + q3 * b, d14 = q1 * d + q4 * a;
-    const double d24 = q2 * d + q4 * b, d13 = q1 * c + q3 * a;
-    const double d34 = q3 * d + q4 * c, d12 = q1 * b + q2 * a;
-    const double dr1 = d23 - d14, dr3 = d23 + d14;
-    const double dr2 = d24 + d13, dr6 = d24 - d13;
-    const double dr5 = d34 - d12, dr7 = d34 + d12;
-    const double v2x = 2.0 * vx, v2y = 2.0 * vy, v2z = 2.0 * vz;
-    // position rows
-    kk[0] = r0 * v2x + r1 * v2y + r2 * v2z;
-    kk[1] = r3 * v2x + r4 * v2y + r5 * v2z;
-    kk[2] = r6 * v2x + r7 * v2y + r8 * v2z;
-    dk[0] = 2.0 * (r0 * sx + r1 * sy + r2 * sz + h0 * v2x + dr1 * vy + dr2 * vz);
-    dk[1] = 2.0 * (r3 * sx + r4 * sy + r5 * sz + dr3 * vx + h4 * v2y + dr5 * vz);
-    dk[2] = 2.0 * (r6 * sx + r7 * sy + r8 * sz + dr6 * vx + dr7 * vy + h8 * v2z);
-    // quaternion rows (halved rates)
-    const double hx = 0.5 * wx, hy = 0.5 * wy, hz = 0.5 * wz;
-    const double gx = 0.5 * ox, gy = 0.5 * oy, gz = 0.5 * oz;
-    kk[3] = -(q2 * hx + q3 * hy + q4 * hz);
-    kk[4] = q1 * hx - q4 * hy + q3 * hz;
-    kk[5] = q4 * hx + q1 * hy - q2 * hz;
-    kk[6] = q2 * hy - q3 * hx + q1 * hz;
-    dk[3] = -(b * hx + c * hy + d * hz + q2 * gx + q3 * gy + q4 * gz);
-    dk[4] = a * hx - d * hy + c * hz + q1 * gx - q4 * gy + q3 * gz;
-    dk[5] = d * hx + a * hy - b * hz + q4 * gx + q1 * gy - q2 * gz;
-    dk[6] = b * hy - c * hx + a * hz + q2 * gy - q3 * gx + q1 * gz;
-    // body velocity rows: v' = v x w - g0 R' e_z (+ thrust);  -G0 R[6..8] = -2 G0 r[6..8]
-    kk[7] = vy * wz - vz * wy - (2.0 * G0) * r6;
-    kk[8] = vz * wx - vx * wz - (2.0 * G0) * r7;
-    kk[9] = vx * wy - vy * wx - (2.0 * G0) * r8 + rot[0];
-    dk[7] = sy * wz + vy * oz - sz * wy - vz * oy - (2.0 * G0) * dr6;
-    dk[8] = sz * wx + vz * ox - sx * wz - vx * oz - (2.0 * G0) * dr7;
-    dk[9] = sx * wy + vx * oy - sy * wx - vy * ox - (4.0 * G0) * h8 + ju[0];
-    // body rate rows
-    kk[10] = KWX * (wy * wz) + rot[1];
-    kk[11] = KWY * (wx * wz) + rot[2];
-    kk[12] = KWZ * (wx * wy) + rot[3];
-    dk[10] = KWX * (oy * wz + wy * oz) + ju[1];
-    dk[11] = KWY * (ox * wz + wx * oz) + ju[2];
-    dk[12] = KWZ * (ox * wy + wx * oy) + ju[3];
-}
-
 // Linearisation of one shooting interval in the row mapping: nominal RK4 (classic tableau, one step per interval)
 // and this lane's sensitivity column, RK point by RK point.  col: the lane's column, EXTERNAL order.  The nominal
 // slopes are the same in all 16 lanes of a row: lane 14 hands each point's slope to the row through `sb` (13 doubles)
