@@ -603,172 +603,6 @@ __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, 
     }
     return ok;
 }
-// ---------------------------------------------------------------------------------------------------------------------
-// ROW-SPLIT factor stage (round 4 experiment): ONE instance per wave (the SPARSE mode of the active-set kernels), the four
-// 16-lane rows share the row's factor stage.  See profiles/r04_factor_variants.md: parity-green, no gain.
-struct SplitIn {
-    double aA, aB, aC;   // this row's three columns of A (lanes beyond the stored rows: 0)
-    double bR;           // this row's column of B
-    double br[4];        // all of B's columns (b_eff)
-    double Rh, bv;       // lanes a < 4: R^ of input a; lane i: b_eff[i]
-};
-struct SplitRow {
-    int row, jA, jB, jC;     // this row's columns (internal state indices); row 3: jB = 0, jC = 1 (identity columns), + column 2
-    int sA, sB, sC;          // their slots in the AR block (row 3: sB, sC unused)
-};
-__device__ __forceinline__ SplitRow split_row(const int row) {
-    SplitRow r;
-    r.row = row;
-    r.jA = row < 3 ? 10 + row : 9;  r.jB = row < 3 ? 6 + row : 0;  r.jC = row < 3 ? 3 + row : 1;
-    r.sA = r.jA - 3;                r.sB = row < 3 ? r.jB - 3 : 3;  r.sC = row < 3 ? r.jC - 3 : 0;
-    return r;
-}
-__device__ __forceinline__ double ld_ar_slot(const gdouble* b, const Lane& t, const int slot) {   // run-time slot, masked
-    const int n = ar_n(slot);
-    const double v = b[4 * ar_pre(slot) + t.q * n + imin(t.L, n - 1)];
-    return t.L < n ? v : 0.0;
-}
-__device__ __forceinline__ void load_stage_split(const Params& P, const Lane& t, const SplitRow& r, const int k, SplitIn& in) {
-    const gdouble* ab = blk(P.AR, t, P.N, k, SZ_A);
-    in.aA = ld_ar_slot(ab, t, r.sA);
-    in.aB = ld_ar_slot(ab, t, r.sB);
-    in.aC = ld_ar_slot(ab, t, r.sC);
-    ld_rows4_raw(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
-    in.bR = r.row == 0 ? in.br[0] : (r.row == 1 ? in.br[1] : (r.row == 2 ? in.br[2] : in.br[3]));
-    const int a = t.L & 3;
-    const double c = gm(P.tl)[i4(P, t, k, a)];
-    const double cls = gm(P.tu)[i4(P, t, k, a)];
-    const double ra = t.wu;
-    in.Rh = cls != 0.0 ? AS_BIG * fmax(1.0, ra) : ra;
-    const double cm = t.L < 4 ? c : 0.0;
-    double bv = 0.0;
-    SFOR(aa, 0, 4, { bv += in.br[aa] * bc<aa>(cm); });
-    in.bv = bv;
-}
-__device__ __forceinline__ bool factor_stage_split(const Params& P, const Lane& t, const SplitRow& r, const int k, double (&Pa)[13],
-                                                   const SplitIn& in, const double wq, const double is13,
-                                                   double (*wtile)[WT_TILE], double (*btile)[64]) {
-    double* wt0 = wtile[0]; double* pt = wtile[1];
-    double* sb0 = btile[0]; double* sg = btile[1]; double* ss = btile[2]; double* sk = btile[3];
-    const int Lc = imin(t.L, 13);
-    {
-        double pb = 0.0;
-        dotbc<13, 0>(pb, Pa, in.bv);
-        rank1bc<13>(Pa, is13, pb);
-    }
-    double WA = 0.0, WB = 0.0, WC = 0.0, Vr = 0.0;
-    dotmix4(WA, WB, WC, Vr, Pa, in.aA, in.aB, in.aC, in.bR);
-    if (r.row == 3) { WB = Pa[0]; WC = Pa[1]; }
-    __syncthreads();
-    if (t.L < 13) {
-        wt0[t.L * WT_ROW + r.jA] = WA; wt0[t.L * WT_ROW + r.jB] = WB; wt0[t.L * WT_ROW + r.jC] = WC;
-        if (r.row == 3) wt0[t.L * WT_ROW + 2] = Pa[2];
-        sb0[r.row * 16 + t.L] = in.bR;
-    }
-    if (r.row == 0 && t.L == 13) SFOR(j, 0, 13, { wt0[j * WT_ROW + 13] = Pa[j]; });
-    __syncthreads();
-    double Wt[13], bcl[13];
-    SFOR(l, 0, 13, { Wt[l] = wt0[l * WT_ROW + Lc]; });
-    SFOR(l, 0, 13, { bcl[l] = sb0[(t.L & 3) * 16 + l]; });
-    double Sr = (t.L == r.row) ? in.Rh : 0.0;
-    dotbc<13, 0>(Sr, bcl, Vr);
-    double MA = (t.L == r.jA) ? wq : 0.0, MB = (t.L == r.jB) ? wq : 0.0, MC = (t.L == r.jC) ? wq : 0.0, Gr = 0.0;
-    dotmix4(MA, MB, MC, Gr, Wt, in.aA, in.aB, in.aC, in.bR);
-    double MD = ((t.L == 2) ? wq : 0.0) + Wt[2];
-    if (r.row == 3) { MB = ((t.L == 0) ? wq : 0.0) + Wt[0]; MC = ((t.L == 1) ? wq : 0.0) + Wt[1]; }
-    settle(Sr); settle(Gr);
-    __syncthreads();
-    if (t.L < 4) ss[t.L * 4 + r.row] = Sr;
-    if (t.L < 14) sg[r.row * 16 + t.L] = Gr;
-    __syncthreads();
-    double S[10], Gp[4], Srow[4];
-    SFOR(a, 0, 4, { SFOR(c, a, 4, { S[s4(a, c)] = ss[a * 4 + c]; }); });
-    SFOR(c, 0, 4, { Srow[c] = ss[(t.L & 3) * 4 + c]; });
-    SFOR(a, 0, 4, { Gp[a] = sg[a * 16 + Lc]; });
-    if (r.row == 0) {
-        if (t.L < 4) {
-            gdouble* sr = blk(P.cS, t, P.N, k, SZ_S4) + t.q * 4 + t.L;
-            SFOR(c, 0, 4, { sr[c * 16] = Srow[c]; });
-        }
-        gdouble* gr = blk(P.cGR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
-        gdouble* dst = t.L == 13 ? gm(P.crho) + i4(P, t, k, 0) : gr;
-        if (t.L < 14) SFOR(a, 0, 4, { dst[a] = Gp[a]; });
-    }
-    double Si[10];
-    Chol4 ch;
-    chol4_pivot<0>(S, ch); chol4_pivot<1>(S, ch); chol4_pivot<2>(S, ch); chol4_pivot<3>(S, ch);
-    chol4_finish(ch, Si);
-    const bool ok = ch.ok;
-    double Kp[4];
-    SFOR(a, 0, 4, {
-        double sum = 0.0;
-        SFOR(c, 0, 4, { sum += Gp[c] * Si[s4(c, a)]; });
-        Kp[a] = sum;
-    });
-    __syncthreads();
-    if (r.row == 0 && t.L < 13) SFOR(a, 0, 4, { sk[t.L * 4 + a] = Kp[a]; });
-    __syncthreads();
-    double kA[4], kB[4], kC[4], kD[4];
-    SFOR(a, 0, 4, { kA[a] = sk[r.jA * 4 + a]; kB[a] = sk[r.jB * 4 + a]; kC[a] = sk[r.jC * 4 + a]; kD[a] = sk[2 * 4 + a]; });
-    double PA = MA, PB = MB, PC = MC, PD = MD;
-    SFOR(a, 0, 4, { PA -= Gp[a] * kA[a]; PB -= Gp[a] * kB[a]; PC -= Gp[a] * kC[a]; PD -= Gp[a] * kD[a]; });
-    __syncthreads();
-    if (t.L < 14) {
-        pt[t.L * WT_ROW + r.jA] = PA; pt[t.L * WT_ROW + r.jB] = PB; pt[t.L * WT_ROW + r.jC] = PC;
-        if (r.row == 3) pt[t.L * WT_ROW + 2] = PD;
-    }
-    __syncthreads();
-    SFOR(j, 0, 13, { Pa[j] = pt[Lc * WT_ROW + j]; });
-    if (r.row == 0) {
-        gdouble* kr = blk(P.KR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
-        gdouble* dst = t.L == 13 ? gm(P.d) + i4(P, t, k, 0) : kr;
-        if (t.L < 14) SFOR(a, 0, 4, { dst[a] = Kp[a]; });
-    }
-    return ok;
-}
-__device__ __forceinline__ bool sweep_factor_as_split(const Params& P, const Lane& t, const int head, const int chk,
-                                                      const int kstart, double (*wtile)[WT_TILE], double (*btile)[64]) {
-    const int sh = as_pg_shift(head);
-    const SplitRow r = split_row((int)(threadIdx.x >> 4));
-    double Pa[13];
-    if (kstart + 1 < head) {
-        const gdouble* ps = blk(P.cPs, t, AS_PSAVE, (kstart + 1) >> sh, SZ_PA) + t.q * 14 + imin(t.L, 13);
-        SFOR(j, 0, 13, { Pa[j] = ps[j * 56]; });
-    } else if (chk < 0) {
-        SFOR(j, 0, 13, { Pa[j] = (t.L == j) ? P.WN[ext_of(j)] : 0.0; });
-    } else {
-        const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + chk) * SZ_P;
-        SFOR(j, 0, 13, {
-            const double v = pc[(j * 4 + t.q) * 13 + imin(t.L, 12)];
-            Pa[j] = t.L < 13 ? v : 0.0;
-        });
-    }
-    bool ok = true;
-    double wq = 0.0;
-    SFOR(j, 0, 13, { if (t.L == j) wq = P.W[ext_of(j)]; });
-    const double is13 = t.L == 13 ? 1.0 : 0.0;
-    auto keep = [&](int k) {
-        if (r.row == 0 && k > 0 && (k & ((1 << sh) - 1)) == 0 && (k >> sh) < AS_PSAVE && t.L < 14) {
-            gdouble* ps = blk(P.cPs, t, AS_PSAVE, k >> sh, SZ_PA) + t.q * 14 + t.L;
-            SFOR(j, 0, 13, { ps[j * 56] = Pa[j]; });
-        }
-    };
-    SplitIn bufA, bufB;
-    load_stage_split(P, t, r, kstart, bufA);
-    int k = kstart;
-    while (k >= 0) {
-        load_stage_split(P, t, r, imax(k - 1, 0), bufB);
-        ok = factor_stage_split(P, t, r, k, Pa, bufA, wq, is13, wtile, btile) && ok;
-        keep(k);
-        if (--k < 0) break;
-        load_stage_split(P, t, r, imax(k - 1, 0), bufA);
-        ok = factor_stage_split(P, t, r, k, Pa, bufB, wq, is13, wtile, btile) && ok;
-        keep(k);
-        --k;
-    }
-    return ok;
-}
-
 // forward sweep: du -> P.dva; multipliers of the fixed inputs and re-classification of every input
 // on the way (stage-local: grad = R c + B'pi_{k+1} with B'pi_{k+1} = G dx_k + (B'PB) du_free + rho,
 // pi = P dx + p being the costate of the equality-constrained solve).  Returns the last stage of
@@ -1644,13 +1478,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             const bool any_try = __any(try_as);
             for (int it = 1; any_try && it <= AS_MAX_SOLVES; it++) {
                 PROF_T(1)
-                if (MODE == 4 && sparse) {   // one instance per wave: the four rows share its factor stage (factor_stage_split)
-                    Lane tw = tc;
-                    tw.inst = slot; tw.wave = slot >> 2; tw.q = slot & 3;
-                    as_ok = sweep_factor_as_split(Q, tw, head, chk, kstart, wtile, btile) && as_ok;
-                } else {
-                    as_ok = sweep_factor_as<QT>(Q, tc, head, chk, kstart, wt, sb, qtab) && as_ok;
-                }
+                as_ok = sweep_factor_as<QT>(Q, tc, head, chk, kstart, wt, sb, qtab) && as_ok;
                 PROF_T(2)
                 PROF_SOLVE(kstart + 1)
                 int jw = sweep_forward_as<SBOX, NO_ROLL>(Q, tc, head);
