@@ -1,4 +1,4 @@
-# heavy disturbances with and without the early interior-point pass (development aid)
+# closed-loop throughput under heavy disturbances (development aid; pass cfnmpc_opts overrides in OPTS, e.g. OPTS="as_skip_viol=2.0")
 cd $GRAFT_REPO_ROOT
 python - <<'PY'
 import numpy as np, torch, time, sys, os
@@ -6,13 +6,14 @@ sys.path.insert(0, os.getcwd())
 import bench
 dev = torch.device("cuda", 0)
 for kick in (1.0, 2.0, 3.0):
-    for ov in (0, 1, 0, 1):
-        f = bench.Fleet(65536, dev, np.random.default_rng(3), "hover", kick, ipm_overlap=ov)
+    for rep in (0, 1):
+        kw = {k: float(v) if '.' in v else int(v) for k, v in (a.split('=') for a in os.environ.get('OPTS', '').split())}
+        f = bench.Fleet(65536, dev, np.random.default_rng(3), "hover", kick, **kw)
         for t in range(15): f.step()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for t in range(20): f.step()
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
         st = f.solver.stats()[0]
-        print(f"kick x{kick} ipm_overlap {ov}: {dt * 1e3:.3f} ms/step  {65536 / dt / 1e6:.3f} M steps/s  ok {float((st == 0).mean()):.5f}", flush=True)
+        print(f"kick x{kick} {kw}: {dt * 1e3:.3f} ms/step  {65536 / dt / 1e6:.3f} M steps/s  ok {float((st == 0).mean()):.5f}", flush=True)
         f.close()
 PY
