@@ -1005,6 +1005,7 @@ KALIGN __global__ __launch_bounds__(64) void k_forward(Params P) {   // large fl
     __shared__ int sflag[64];
     forward_body<false, true, CFN_FWD_BIG_FUSED != 0>(P, xs, cs, sflag);
 }
+#ifdef CFN_DEV
 // the same at two waves per SIMD (<= 256 registers, a few spills): beside the fused start solve of ANOTHER sub-fleet, whose
 // waves leave half a SIMD's register file each (cfnmpc_opts.sub_fleets)
 __global__ __launch_bounds__(64, 2) void k_forward_half(Params P) {
@@ -1012,6 +1013,7 @@ __global__ __launch_bounds__(64, 2) void k_forward_half(Params P) {
     __shared__ int sflag[64];
     forward_body<false, true>(P, xs, cs, sflag);
 }
+#endif
 #ifndef CFN_FWD_FUSED
 #define CFN_FWD_FUSED 1
 #endif
@@ -2781,8 +2783,10 @@ void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev, bool skip_
         hipLaunchKernelGGL(k_forward_rg, dim3(P.NW), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_rank, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     } else {
-        if (P.forward_half) hipLaunchKernelGGL(k_forward_half, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
-        else if (P.forward_div) hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+#ifdef CFN_DEV
+        if (P.forward_half) { hipLaunchKernelGGL(k_forward_half, dim3((P.B + 63) / 64), dim3(64), 0, st, P); } else
+#endif
+        if (P.forward_div) hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
         else hipLaunchKernelGGL(k_forward_mid, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     }
     if (ev) (void)hipEventRecord(ev[1], st);

@@ -116,7 +116,9 @@ struct Params {
     double *Ppark;               // cost-to-go between the chunks, [wave][13][64]
 #endif
     int forward_div;             // 1: k_forward (division form: fleets that stream at the HBM rate), 0: k_forward_mid; see forward_body
-    int forward_half;            // 1: k_forward_half (two waves per SIMD) instead of k_forward
+#ifdef CFN_DEV
+    int forward_half;            // 1: k_forward_half (two waves per SIMD) instead of k_forward (sub-fleet experiment)
+#endif
     int forward_rg;              // 1: forward sweep of the start solve on the stored blocks (k_forward_rg; small fleets)
     int clist_chunks;            // workgroups per 64-slot group of k_linearise_clist (stage chunks)
     int fused;                   // start solve: 0 = k_linearise + k_factor on stored (A, B, b); 1 = k_linfactor, nothing stored (the QP

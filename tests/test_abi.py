@@ -67,3 +67,26 @@ def test_headers_are_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_exported_debug_entry_points_are_the_documented_ones():
+    """The shipped library exports no experiment: every cfnmpc_debug_* symbol of libcfnmpc.so is declared in
+    include/cfnmpc.h and named in INTEGRATION.md (kernel-level access for the parity tests); development entry points
+    live in `make DEV=1` builds only (csrc/cfnmpc_dev.h)."""
+    import re
+    import subprocess
+    from crazyflie_nmpc_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b(cfnmpc_debug_\w+)\b", out))
+    header = open(os.path.join(ROOT, "include", "cfnmpc.h")).read()
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    dev = open(os.path.join(ROOT, "crazyflie_nmpc_amd", "csrc", "cfnmpc_dev.h")).read()
+    assert exported, "no debug accessors found (nm output changed?)"
+    for name in exported:
+        assert name in header, name
+        assert name in integ or name.replace("cfnmpc_debug_get_", "cfnmpc_debug_get_") in integ, name
+        assert name not in dev, name
+    for name in re.findall(r"\b(cfnmpc_debug_\w+)\s*\(", dev):
+        assert name not in exported, name
+    # and the library reads no environment variable
+    assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
