@@ -1,25 +1,41 @@
-"""Soak run (development aid): a long closed loop of the bench fleet -- statuses, iterate sanity, device memory, step time
-at the start and at the end.    python tools/soak.py [steps] [workload]"""
-import os, sys, time
+"""Soak test (development aid): the bench's closed loop for many steps with kicks of varying
+strength, checking every instance's status, the input box and the regulation error along the way.
+Kicks beyond ~2x the bench's perturbation throw a few vehicles per 65 536 out of the controller's
+region of attraction (the same instances with either QP method): they end in status 2 / 4, keep
+their last iterate and do not disturb their wave-mates -- which is what the tool then reports."""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-import bench
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-wl = sys.argv[2] if len(sys.argv) > 2 else "hover"
+from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+from crazyflie_nmpc_amd.solver import INIT_HOVER
+from crazyflie_nmpc_amd.synthetic import regulation_row, sample_hover_x0
+B, N, KP = int(os.environ.get('SOAK_B', 65536)), 50, 20
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+rng = np.random.default_rng(99)
 dev = torch.device("cuda", 0)
-f = bench.Fleet(65536, dev, np.random.default_rng(3), wl, 1.0)
-free0 = torch.cuda.mem_get_info()[0]
-bad = 0; tms = []
-for blk in range(steps // 100):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for t in range(100): f.step()
-    torch.cuda.synchronize(); tms.append((time.perf_counter() - t0) * 10)
-    st, it, res = f.solver.stats()
-    x, u = f.solver.get_iterate()
-    nb = int((st != 0).sum()); bad += nb
-    assert np.isfinite(x).all() and np.isfinite(u).all(), blk
-    assert u.min() >= -1e-9 and u.max() <= 22.0 + 1e-9, (u.min(), u.max())
-    if blk % 5 == 0:
-        print(f"steps {blk * 100 + 100}: {tms[-1]:.3f} ms/step, status != 0: {nb}, |pos - target| median {np.median(np.abs(x[:, 0, :3] - x[:, -1, :3])):.3f}, free mem delta {(free0 - torch.cuda.mem_get_info()[0]) / 2**20:.1f} MiB", flush=True)
-print(f"{wl}: {steps} steps, failed row-steps {bad}, ms/step first / last block {tms[0]:.3f} / {tms[-1]:.3f}, min {min(tms):.3f} max {max(tms):.3f}")
-f.close()
+x = torch.from_numpy(sample_hover_x0(rng, B)).to(dev)
+row = regulation_row()
+s = BatchSolver(B, default_opts(active_set=int(os.environ.get('SOAK_AS', 1)), active_horizon=int(os.environ.get('SOAK_AH', 1)), reinit_failed=int(os.environ.get('SOAK_REINIT', 0))))
+s.set_x0(x); s.set_yref(torch.from_numpy(np.tile(row, (B, N, 1))).to(dev), torch.from_numpy(np.tile(row[:13], (B, 1))).to(dev)); s.init_iterate(INIT_HOVER)
+cohort = B // KP
+u0 = torch.empty((B, 4), dtype=torch.float64, device=dev); xn = torch.empty_like(x)
+bad = 0; maxsolves = 0; fallbacks = 0; lost = set()
+for t in range(steps):
+    c0 = (t % KP) * cohort
+    x[c0:c0 + cohort].copy_(torch.from_numpy(sample_hover_x0(rng, cohort, scale=1.0 + (float(os.environ.get('SOAK_HARD', 2.0)) - 1.0) * ((t // KP) % 3 == 2))).to(dev))   # every third round: harder kicks
+    s.set_x0(x); s.solve(1); s.get_u(0, out=u0); sim(x, u0, T=0.015, steps=1, out=xn); x, xn = xn, x
+    if t % 25 == 24 or t == steps - 1:
+        st, it, rs = s.stats()
+        lost |= set(np.nonzero(st != 0)[0].tolist())
+        maxsolves = max(maxsolves, int(it.max())); fallbacks += int((rs > 0).sum())
+        xg, ug = s.get_iterate()
+        ok = np.ones(B, dtype=bool); ok[list(lost)] = False
+        assert np.isfinite(ug[ok]).all()
+        out = ((ug < -1e-8) | (ug > 22 + 1e-8)).any(axis=(1, 2)) & ok
+        if out.any():   # an instance that reports status 0 must have its whole input trajectory inside the box
+            print("  OUT OF BOX with status 0:", np.nonzero(out)[0][:8])
+            bad += int(out.sum())
+        err = float(torch.linalg.norm(x[:, :3] - torch.tensor([0, 0, 0.4], device=dev, dtype=torch.float64), dim=1).max())
+        print(f"step {t + 1}: status!=0 {int((st != 0).sum())}, constrained {int((it > 0).sum())}, max solves {int(it.max())}, interior-point fall-backs {int((rs > 0).sum())}, max position error {err:.3f} m")
+assert bad == 0
+print("soak ok:", steps, "steps, max solves", maxsolves, ", fall-backs seen at the sampled steps", fallbacks, ", vehicles lost (status != 0 at a sampled step):", sorted(lost)[:10])
