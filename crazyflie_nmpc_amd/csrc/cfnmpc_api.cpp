@@ -346,7 +346,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(yref, NW * N * cfn::SZ_Y); ALLOC(yref_e, NW * cfn::SZ_V13);
     ALLOC(AR, NW * N * cfn::SZ_A); ALLOC(BR, NW * N * cfn::SZ_B); ALLOC(b, NW * N * cfn::SZ_V13);
     ALLOC(KR, NW * N * cfn::SZ_K); ALLOC(Sinv, NW * N * cfn::SZ_S);
-    ALLOC(d, NW * 4 * N * 4); ALLOC(Pchk, NW * cfn::N_CHK * cfn::SZ_P);
+    ALLOC(d, NW * 4 * N * 4); ALLOC(Pchk, NW * cfn::N_CHK * cfn::SZ_PP);
     ALLOC(v, NW * 4 * N * 4); ALLOC(tl, NW * 4 * N * 4); ALLOC(tu, NW * 4 * N * 4); ALLOC(ll, NW * 4 * N * 4);
     ALLOC(lu, NW * 4 * N * 4); ALLOC(rg, NW * 4 * N * 4); ALLOC(dva, NW * 4 * N * 4); ALLOC(dvc, NW * 4 * N * 4);
     ALLOC(Rh, NW * 4 * N * 4); ALLOC(g, NW * 4 * N * 4);
@@ -865,7 +865,7 @@ int cfnmpc_debug_checksum(cfnmpc_solver* s, double* out3) {
     DeviceGuard dg(s);
     const cfn::Params& P = s->P;
     HIP_TRY(hipDeviceSynchronize());
-    const size_t n[3] = {(size_t)P.NW * P.N * cfn::SZ_K, (size_t)P.NW * 4 * P.N * 4, (size_t)P.NW * cfn::N_CHK * cfn::SZ_P};
+    const size_t n[3] = {(size_t)P.NW * P.N * cfn::SZ_K, (size_t)P.NW * 4 * P.N * 4, (size_t)P.NW * cfn::N_CHK * cfn::SZ_PP};
     const double* src[3] = {P.KR, P.d, P.Pchk};
     for (int f = 0; f < 3; f++) {
         std::vector<double> h(n[f]);
@@ -929,14 +929,14 @@ int cfnmpc_debug_get_factor(cfnmpc_solver* s, double* K, double* d, double* Pchk
     }
     if (d) HIP_TRY(hipMemcpy(d, P.d, B * N * 4 * 8, hipMemcpyDeviceToHost));
     if (Pchk) {
-        std::vector<double> h(NW * cfn::N_CHK * cfn::SZ_P);
+        std::vector<double> h(NW * cfn::N_CHK * cfn::SZ_PP);   // (packed triangle, cfnmpc_ws.hpp: pchk_at)
         HIP_TRY(hipMemcpy(h.data(), P.Pchk, h.size() * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < B; i++)
             for (int c = 0; c < cfn::N_CHK; c++) {
-                const double* pb = h.data() + ((i / 4) * cfn::N_CHK + c) * cfn::SZ_P;
+                const double* pb = h.data() + ((i / 4) * cfn::N_CHK + c) * cfn::SZ_PP;
                 for (int j = 0; j < 13; j++)
                     for (int r = 0; r < 13; r++)
-                        Pchk[((i * cfn::N_CHK + c) * 13 + cfn::ext_of(r)) * 13 + cfn::ext_of(j)] = pb[(j * 4 + (i % 4)) * 13 + r];
+                        Pchk[((i * cfn::N_CHK + c) * 13 + cfn::ext_of(r)) * 13 + cfn::ext_of(j)] = pb[cfn::pchk_at(j, (int)(i % 4), r)];
             }
     }
     if (status) HIP_TRY(hipMemcpy(status, P.status, B * sizeof(int), hipMemcpyDeviceToHost));

@@ -327,8 +327,8 @@ __device__ __forceinline__ bool sweep_factor(const Params& P, const Lane& t, con
             int cidx = -1;
             SFOR(c, 0, N_CHK, { if (k == chk_stage(c)) cidx = c; });
             if (cidx >= 0) {
-                gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + cidx) * SZ_P;
-                SFOR(j, 0, 13, { if (t.L < 13) pc[(j * 4 + t.q) * 13 + t.L] = Pa[j]; });
+                gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + cidx) * SZ_PP;
+                SFOR(j, 0, 13, { if (t.L <= j) pc[pchk_col(j) + t.q * (j + 1) + t.L] = Pa[j]; });   // (packed: rows 0..j of column j)
             }
         }
     };
@@ -1437,10 +1437,10 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             });
         }
         if (ck >= 0) {
-            const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + ck) * SZ_P;
+            const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + ck) * SZ_PP;   // home: packed; compact copy: full
             gdouble* qc = gm(Q.Pchk) + ((size_t)tc.wave * N_CHK + ck) * SZ_P;
             double pv[13];
-            SFOR(j, 0, 13, { pv[j] = pc[(j * 4 + t.q) * 13 + imin(t.L, 12)]; });
+            SFOR(j, 0, 13, { pv[j] = pc[pchk_at(j, t.q, imin(t.L, 12))]; });
             SFOR(j, 0, 13, { if (t.L < 13) qc[(j * 4 + tc.q) * 13 + t.L] = pv[j]; });
         }
     };
@@ -2059,9 +2059,9 @@ __device__ __forceinline__ bool zsweep_factor(const Params& P, const Params& Q, 
         } else if (chk < 0) {
             SFOR(j, 0, 13, { Pa[j] = (tc.L == j) ? P.WN[ext_of(j)] : 0.0; });
         } else {                    // checkpoint of the unconstrained tail (home block)
-            const gdouble* pc = gm(P.Pchk) + ((size_t)th.wave * N_CHK + chk) * SZ_P;
+            const gdouble* pc = gm(P.Pchk) + ((size_t)th.wave * N_CHK + chk) * SZ_PP;
             SFOR(j, 0, 13, {
-                const double v = pc[(j * 4 + th.q) * 13 + imin(tc.L, 12)];
+                const double v = pc[pchk_at(j, th.q, imin(tc.L, 12))];
                 Pa[j] = tc.L < 13 ? v : 0.0;
             });
         }

@@ -172,8 +172,8 @@ __device__ __forceinline__ bool sweep_linfactor(const Params& P, const Lane& t, 
         int cidx = -1;
         SFOR(c, 0, N_CHK, { if (k == chk_stage(c)) cidx = c; });
         if (cidx >= 0) {
-            gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + cidx) * SZ_P;
-            SFOR(j, 0, 13, { if (t.L < 13) pc[(j * 4 + t.q) * 13 + t.L] = Pa[j]; });
+            gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + cidx) * SZ_PP;
+            SFOR(j, 0, 13, { if (t.L <= j) pc[pchk_col(j) + t.q * (j + 1) + t.L] = Pa[j]; });
         }
     }
     return ok;

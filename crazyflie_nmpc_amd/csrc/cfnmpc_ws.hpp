@@ -46,6 +46,14 @@ constexpr int SZ_S = 4 * 10;   // packed symmetric 4x4: [inst][10]
 constexpr int SZ_S4 = 4 * 16;  // full 4x4, row a in lane a: [c][inst][a]
 constexpr int SZ_Y = 4 * 17;   // yref row: [inst][17] (first 13 in internal order)
 constexpr int SZ_P = 4 * 13 * 13;  // a row-distributed 13x13: [col j][inst][13]
+// checkpoints of the start solve (home blocks): the symmetric matrix packed -- column j keeps its rows 0..j only, [col j][inst][j + 1]
+// (written for every instance and step, read by the constrained ones: 364 instead of 676 doubles per wavefront and checkpoint)
+constexpr int SZ_PP = 4 * 91;
+__host__ __device__ constexpr int pchk_col(int j) { return 2 * j * (j + 1); }                       // start of column j
+__host__ __device__ inline int pchk_at(int j, int q, int r) {                                       // element (r, j), either triangle
+    const int a = r < j ? r : j, b = r < j ? j : r;
+    return 2 * b * (b + 1) + q * (b + 1) + a;
+}
 constexpr int SZ_PA = 4 * 13 * 14; // ... with the affine row (lane 13): [col j][inst][14]
 
 constexpr int N_CHK = 6;  // Riccati checkpoints for the active-horizon QP (stage indices below)
@@ -78,7 +86,7 @@ struct Params {
     double *KR;       // N x SZ_K   gain, lane a < 4 holds K[a][0..12]
     double *Sinv;     // N x SZ_S
     double *d;        // N x SZ_V4
-    double *Pchk;     // N_CHK x SZ_P   cost-to-go of the unconstrained tail at the checkpoints
+    double *Pchk;     // N_CHK x SZ_PP (home: packed) / N_CHK x SZ_P (compact copy cPchk)   cost-to-go of the unconstrained tail at the checkpoints
     // interior-point state, N x SZ_V4 each
     double *v, *tl, *tu, *ll, *lu, *rg, *dva, *dvc, *Rh, *g;
     // compact scratch of the interior-point kernel (same block shapes, indexed by compacted slot)
