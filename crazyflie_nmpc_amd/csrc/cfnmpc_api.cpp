@@ -128,7 +128,7 @@ int put_field(cfnmpc_solver* s, const double* src, int on_device, int S, int E, 
         HIP_TRY(hipMemcpyAsync(s->stage_buf, src, n * sizeof(double), hipMemcpyHostToDevice, st));
         dsrc = s->stage_buf;
     }
-    cfn::launch_put(P.B, S, E, perm13, dsrc, field, st);
+    cfn::launch_put(P.B, S, E, perm13, dsrc, field, st, E == 4 ? P.v4b : 0);
     HIP_TRY(hipGetLastError());
     // the staging buffer is reused: wait, unless the caller orders the next use on the same stream itself
     if (on_device == CFNMPC_ON_HOST) HIP_TRY(hipStreamSynchronize(st));
@@ -146,7 +146,7 @@ int get_field(cfnmpc_solver* s, double* dst, int on_device, int S, int E, int pe
         if (n > s->stage_doubles) return CFNMPC_EINVAL;
         ddst = s->stage_buf;
     }
-    cfn::launch_get(P.B, S, E, perm13, s0, Stot, field, ddst, st);
+    cfn::launch_get(P.B, S, E, perm13, s0, Stot, field, ddst, st, E == 4 ? P.v4b : 0);
     HIP_TRY(hipGetLastError());
     if (host) {
         HIP_TRY(hipMemcpyAsync(dst, ddst, n * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -335,6 +335,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
         P.clist_chunks = o.N >= 10 ? 10 : o.N;
     }
     P.cond_N2 = cond_N2;
+    P.v4b = cond_N2 ? 0 : 1;   // home 4-vectors wave-blocked (the condensed kernels index theirs instance-major)
     P.cond_M = cond_N2 ? o.N / cond_N2 : 0;
     P.cond_rem = cond_N2 ? o.N % cond_N2 : 0;
     // one spare workspace block (index P.NW) parks the idle rows of compacted interior-point waves
@@ -484,12 +485,11 @@ int cfnmpc_set_box_stages(cfnmpc_solver* s, const double* lb, const double* ub, 
         HIP_TRY(hipMemcpy(uk + (size_t)P.NW * 4 * P.N * 4, hi.data(), hi.size() * 8, hipMemcpyHostToDevice));
         s->lbs_keep = lk; s->ubs_keep = uk; P.clbs = cl; P.cubs = cu;
     }
-    // instance-major [inst][stage][4] is the caller's AoS order: plain copies
+    // the caller's AoS order [inst][stage][4] -> the layout of the home 4-vectors (Params.v4b)
     hipStream_t st = (hipStream_t)stream;
-    const hipMemcpyKind kind = !is_host(on_device) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    HIP_TRY(hipMemcpyAsync(s->lbs_keep, lb, n * sizeof(double), kind, st));
-    HIP_TRY(hipMemcpyAsync(s->ubs_keep, ub, n * sizeof(double), kind, st));
-    if (on_device == CFNMPC_ON_HOST) HIP_TRY(hipStreamSynchronize(st));
+    int rcp = put_field(s, lb, on_device, P.N, 4, 0, s->lbs_keep, st);
+    if (rcp == CFNMPC_OK) rcp = put_field(s, ub, on_device, P.N, 4, 0, s->ubs_keep, st);
+    if (rcp != CFNMPC_OK) return rcp;
     P.lbs = s->lbs_keep; P.ubs = s->ubs_keep;
     invalidate_graphs(s);
     return CFNMPC_OK;
@@ -678,7 +678,7 @@ int cfnmpc_step_host(cfnmpc_solver* s, const double* x0, const double* yref, con
     int rc = cfnmpc_solve(s, 1, stream);
     if (rc != CFNMPC_OK) return rc;
     double* o = d + n_in;
-    cfn::launch_get(P.B, P.N, 4, 0, 0, P.N, s->P.uit, o, st);
+    cfn::launch_get(P.B, P.N, 4, 0, 0, P.N, s->P.uit, o, st, P.v4b);
     cfn::launch_get(P.B, P.N + 1, 13, 1, 0, P.N + 1, s->P.xit, o + n_u, st);
     HIP_TRY(hipMemcpyAsync(o + n_u + n_x, s->P.res, B * sizeof(double), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(o + n_u + n_x + n_res, s->P.status, B * sizeof(int), hipMemcpyDeviceToDevice, st));
@@ -927,7 +927,14 @@ int cfnmpc_debug_get_factor(cfnmpc_solver* s, double* K, double* d, double* Pchk
                     for (int a = 0; a < 4; a++) K[((i * N + k) * 4 + a) * 13 + cfn::ext_of(l)] = kb[(l * 4 + (i % 4)) * 4 + a];
             }
     }
-    if (d) HIP_TRY(hipMemcpy(d, P.d, B * N * 4 * 8, hipMemcpyDeviceToHost));
+    if (d) {
+        std::vector<double> h(NW * 4 * N * 4);
+        HIP_TRY(hipMemcpy(h.data(), P.d, h.size() * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < B; i++)
+            for (size_t k = 0; k < N; k++)
+                for (int a = 0; a < 4; a++)
+                    d[(i * N + k) * 4 + a] = h[P.v4b ? (((i / 4) * N + k) * 4 + i % 4) * 4 + a : (i * N + k) * 4 + a];
+    }
     if (Pchk) {
         std::vector<double> h(NW * cfn::N_CHK * cfn::SZ_PP);   // (packed triangle, cfnmpc_ws.hpp: pchk_at)
         HIP_TRY(hipMemcpy(h.data(), P.Pchk, h.size() * 8, hipMemcpyDeviceToHost));

@@ -149,7 +149,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         SFOR(r, 0, 13, { sx[tid + 64 * r] = xr[r]; });
     };
     auto issue_u = [&](int k, double (&u)[4]) {
-        const gdouble* up = gm(P.uit) + ((size_t)inst * N + k) * 4;
+        const gdouble* up = gm(P.uit) + (P.v4b ? (((size_t)(inst >> 2) * N + k) * 4 + (inst & 3)) * 4 : ((size_t)inst * N + k) * 4);
         SFOR(a, 0, 4, { u[a] = up[a]; });
     };
     double xn[13], un[4];  // x_k in EXTERNAL order and u_k on entry to stage k
@@ -730,11 +730,10 @@ __device__ __forceinline__ void keep_row(const Params& P, const Lane& t, const b
         SFOR(j, 0, 4, { xo[j] = blk(P.xit, t, N + 1, imin(k0 + j, N), SZ_V13)[lx]; });
         SFOR(j, 0, 4, { if (t.L < 13 && k0 + j <= N) blk(P.xitn, t, N + 1, k0 + j, SZ_V13)[lx] = xo[j]; });
     }
-    const size_t ibase = (size_t)t.inst * N * 4;
-    for (int e0 = t.L; e0 < N * 4; e0 += 64) {
+    for (int e0 = t.L; e0 < N * 4; e0 += 64) {   // element e = 4 k + a of the row's inputs
         double uo[4];
-        SFOR(j, 0, 4, { uo[j] = gm(P.uit)[ibase + imin(e0 + 16 * j, N * 4 - 1)]; });
-        SFOR(j, 0, 4, { if (e0 + 16 * j < N * 4) gm(P.uitn)[ibase + e0 + 16 * j] = uo[j]; });
+        SFOR(j, 0, 4, { const int e = imin(e0 + 16 * j, N * 4 - 1); uo[j] = gm(P.uit)[i4(P, t, e >> 2, e & 3)]; });
+        SFOR(j, 0, 4, { const int e = e0 + 16 * j; if (e < N * 4) gm(P.uitn)[i4(P, t, e >> 2, e & 3)] = uo[j]; });
     }
 }
 
@@ -799,7 +798,9 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
     const double h = P.dt;
     const double margin = P.ah_margin * (P.u_max - P.u_min);
     const gdouble* kp = gm(P.KR) + w * N * SZ_K + q * 4;
-    const size_t i4b = (size_t)inst * N * 4;
+    // this lane's 4-vectors: element a of stage k at i4b + k * i4s + a (Params.v4b: wave-blocked or instance-major)
+    const size_t i4b = P.v4b ? ((size_t)w * N * 4 + q) * 4 : (size_t)inst * N * 4;
+    const size_t i4s = P.v4b ? 16 : 4;
     // element e = 13 * (local instance) + i of a 13-vector field with `stages` stages per block
     // (wave-uniform 64-bit base + 32-bit byte offset per lane: saddr form of the global access)
     auto el13 = [&](const double* f, int e, int stages, int k) -> gdouble* {
@@ -817,7 +818,7 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
     struct In { double K[4][13], d[4], u[4]; };   // K: column index in INTERNAL order
     auto load = [&](int k, In& in) {
         SFOR(l, 0, 13, { SFOR(a, 0, 4, { in.K[a][l] = kp[(size_t)k * SZ_K + l * 16 + a]; }); });
-        SFOR(a, 0, 4, { in.d[a] = gm(P.d)[i4b + (size_t)k * 4 + a]; in.u[a] = gm(P.uit)[i4b + (size_t)k * 4 + a]; });
+        SFOR(a, 0, 4, { in.d[a] = gm(P.d)[i4b + (size_t)k * i4s + a]; in.u[a] = gm(P.uit)[i4b + (size_t)k * i4s + a]; });
     };
     double dx[13];   // internal order
     {
@@ -859,8 +860,8 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
             nviol += (du[a] < lb || du[a] > ub) ? 1 : 0;
             if (du[a] < lb + margin || du[a] > ub - margin) last_tight = k;
             sawnan = sawnan || !(du[a] == du[a]);
-            gm(P.v)[i4b + (size_t)k * 4 + a] = du[a];
-            gm(P.uitn)[i4b + (size_t)k * 4 + a] = cur.u[a] + du[a];
+            gm(P.v)[i4b + (size_t)k * i4s + a] = du[a];
+            gm(P.uitn)[i4b + (size_t)k * i4s + a] = cur.u[a] + du[a];
         });
         // next stage's inputs (issued here: the gain of stage k is dead, its registers are free)
         const double uc[4] = {cur.u[0], cur.u[1], cur.u[2], cur.u[3]};
@@ -993,7 +994,7 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         }
     }
     if (bad) {
-        for (int k = 0; k < N; k++) SFOR(a, 0, 4, { gm(P.uitn)[i4b + (size_t)k * 4 + a] = gm(P.uit)[i4b + (size_t)k * 4 + a]; });
+        for (int k = 0; k < N; k++) SFOR(a, 0, 4, { gm(P.uitn)[i4b + (size_t)k * i4s + a] = gm(P.uit)[i4b + (size_t)k * i4s + a]; });
     }
 }
 
@@ -1402,6 +1403,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         tc.wave = vb; tc.q = t.row; tc.inst = vb * 4 + t.row;
     }
     Params Q = P;
+    Q.v4b = 0;   // (compact 4-vectors: instance-major, a row's head contiguous)
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
     Q.lbs = P.clbs; Q.ubs = P.cubs;
     const size_t cbase = (size_t)tc.inst * N * 4;  // compact 4-vectors of this row
@@ -2186,6 +2188,7 @@ __device__ __forceinline__ int zsweep_forward(const Params& P, const Params& Q, 
 }
 __device__ __forceinline__ Params compact_params(const Params& P) {
     Params Q = P;
+    Q.v4b = 0;   // (compact 4-vectors: instance-major, a row's head contiguous)
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
     return Q;
 }
@@ -2621,29 +2624,29 @@ __global__ void k_estimate(int B, const double* __restrict__ meas, double* __res
 // AoS [B][S][E] (external order) -> wave-blocked [wave][S][inst 0..3][E]; if perm13 the first 13
 // entries of a row are permuted to the internal state order.  E == 4 fields are instance-major
 // ([inst][S][4]) and handled by the same formula with a different block shape.
-__device__ __forceinline__ size_t blk_index(int i, int s, int e, int S, int E) {
-    if (E == 4) return ((size_t)i * S + s) * 4 + e;
+__device__ __forceinline__ size_t blk_index(int i, int s, int e, int S, int E, int v4b = 0) {
+    if (E == 4 && !v4b) return ((size_t)i * S + s) * 4 + e;   // instance-major 4-vectors (Params.v4b = 0)
     return (((size_t)(i >> 2) * S + s) * 4 + (i & 3)) * E + e;
 }
-__global__ void k_put(int B, int S, int E, int perm13, const double* __restrict__ aos, double* __restrict__ blkp) {
+__global__ void k_put(int B, int S, int E, int perm13, const double* __restrict__ aos, double* __restrict__ blkp, int v4b) {
     const size_t n = (size_t)B * S * E;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(idx % E);
         const int s = (int)((idx / E) % S);
         const int i = (int)(idx / ((size_t)E * S));
         const int ei = (perm13 && e < 13) ? int_of(e) : e;
-        blkp[blk_index(i, s, ei, S, E)] = aos[idx];
+        blkp[blk_index(i, s, ei, S, E, v4b)] = aos[idx];
     }
 }
 __global__ void k_get(int B, int S, int E, int perm13, int s0, int Stot, const double* __restrict__ blkp,
-                      double* __restrict__ aos) {
+                      double* __restrict__ aos, int v4b) {
     const size_t n = (size_t)B * S * E;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int e = (int)(idx % E);
         const int s = (int)((idx / E) % S);
         const int i = (int)(idx / ((size_t)E * S));
         const int ei = (perm13 && e < 13) ? int_of(e) : e;
-        aos[idx] = blkp[blk_index(i, s0 + s, ei, Stot, E)];
+        aos[idx] = blkp[blk_index(i, s0 + s, ei, Stot, E, v4b)];
     }
 }
 // Reference windows of the reference node generated on the device (acados_mpc.cpp:430-516), so
@@ -2706,8 +2709,8 @@ __global__ void k_postproc(Params P, double* __restrict__ cmd_vel, int* __restri
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.B) return;
     const double pi = 3.14159265358979323846;
-    const double* u0 = P.uit + blk_index(i, 0, 0, P.N, 4);
-    const double* u1 = P.uit + blk_index(i, 1, 0, P.N, 4);
+    const double* u0 = P.uit + blk_index(i, 0, 0, P.N, 4, P.v4b);
+    const double* u1 = P.uit + blk_index(i, 1, 0, P.N, 4, P.v4b);
     const double* x4 = P.xit + blk_index(i, 4, 0, P.N + 1, 13);
     double qw = x4[int_of(3)], qx = x4[int_of(4)], qy = x4[int_of(5)], qz = x4[int_of(6)];
     const double nrm = sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
@@ -2740,7 +2743,7 @@ __global__ void k_init_iterate(Params P, int mode) {
             P.xit[blk_index(i, k, int_of(e), P.N + 1, 13)] = (mode == 1) ? x0e : (e == 3 ? 1.0 : 0.0);
         }
     for (int k = 0; k < P.N; k++)
-        for (int e = 0; e < 4; e++) P.uit[blk_index(i, k, e, P.N, 4)] = (mode == 1) ? hov : 0.0;
+        for (int e = 0; e < 4; e++) P.uit[blk_index(i, k, e, P.N, 4, P.v4b)] = (mode == 1) ? hov : 0.0;
 }
 
 // cfnmpc_opts.reinit_failed: an instance whose last step ended in status 4 (factorisation not positive definite / not
@@ -2752,7 +2755,7 @@ __global__ void k_reinit_failed(Params P) {
     for (int k = 0; k <= P.N; k++)
         for (int e = 0; e < 13; e++) P.xit[blk_index(i, k, e, P.N + 1, 13)] = P.x0[blk_index(i, 0, e, 1, 13)];
     for (int k = 0; k < P.N; k++)
-        for (int e = 0; e < 4; e++) P.uit[blk_index(i, k, e, P.N, 4)] = P.yref[blk_index(i, k, 13 + e, P.N, 17)];
+        for (int e = 0; e < 4; e++) P.uit[blk_index(i, k, e, P.N, 4, P.v4b)] = P.yref[blk_index(i, k, 13 + e, P.N, 17)];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2886,11 +2889,11 @@ static inline int grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
-void launch_put(int B, int S, int E, int perm13, const double* aos, double* blkp, hipStream_t st) {
-    hipLaunchKernelGGL(k_put, dim3(grid_for((size_t)B * S * E)), dim3(256), 0, st, B, S, E, perm13, aos, blkp);
+void launch_put(int B, int S, int E, int perm13, const double* aos, double* blkp, hipStream_t st, int v4b) {
+    hipLaunchKernelGGL(k_put, dim3(grid_for((size_t)B * S * E)), dim3(256), 0, st, B, S, E, perm13, aos, blkp, v4b);
 }
-void launch_get(int B, int S, int E, int perm13, int s0, int Stot, const double* blkp, double* aos, hipStream_t st) {
-    hipLaunchKernelGGL(k_get, dim3(grid_for((size_t)B * S * E)), dim3(256), 0, st, B, S, E, perm13, s0, Stot, blkp, aos);
+void launch_get(int B, int S, int E, int perm13, int s0, int Stot, const double* blkp, double* aos, hipStream_t st, int v4b) {
+    hipLaunchKernelGGL(k_get, dim3(grid_for((size_t)B * S * E)), dim3(256), 0, st, B, S, E, perm13, s0, Stot, blkp, aos, v4b);
 }
 void launch_windows(const Params& P, const double* traj, int n_rows, int* mode, int* iter, const double* des,
                     double uss, hipStream_t st) {

@@ -39,7 +39,7 @@ __device__ __forceinline__ void lf_load(const Params& P, const Lane& t, const in
     const int N = P.N;
     const gdouble* xb = blk(P.xit, t, N + 1, k, SZ_V13) + t.q * 13;
     SFOR(e, 3, 13, { in.xr[e - 3] = xb[int_of(e)]; });
-    const gdouble* ub = gm(P.uit) + i4(P, t, k, 0);
+    const gdouble* ub = blk(P.uit, t, P.N, k, SZ_V4) + t.q * 4;
     SFOR(a, 0, 4, { in.u[a] = ub[a]; });
     const int li = imin(t.L, 12), a = t.L & 3;
     in.ua = ub[a];

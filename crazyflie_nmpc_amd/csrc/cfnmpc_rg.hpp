@@ -118,9 +118,13 @@ __device__ __forceinline__ void settle(double& x) { asm volatile("s_nop 1" : "+v
 // makes a value live in every lane at this point (stops the compiler from sinking the load that
 // produced it into a divergent branch)
 __device__ __forceinline__ void pin(double& x) { asm volatile("" : "+v"(x)); }
-// instance-major 4-vectors (interior-point state, inputs): [inst][stage][4]
+// 4-vectors (inputs, feed-forward terms, input steps, interior-point state, per-stage boxes) in P's own layout (Params.v4b):
+// wave-blocked [wave][stage][inst & 3][4] for the home arrays, instance-major [inst][stage][4] for the compact copies
 __device__ __forceinline__ size_t i4(const Params& P, const Lane& t, int k, int a) {
-    return ((size_t)t.inst * P.N + k) * 4 + a;
+    // one address expression for both layouts (the selects are on loop-invariant 32-bit values: a second 64-bit expression
+    // behind a select costs k_factor its two-waves-per-SIMD register budget)
+    const int rb = P.v4b ? t.wave : t.inst, s4 = P.v4b ? 16 : 4, q4 = P.v4b ? t.q * 4 : 0;
+    return ((size_t)rb * P.N + k) * s4 + q4 + a;
 }
 
 // Input box of element idx (instance-major 4-vector index in P's own indexing): the scalar box of cfnmpc_set_box,
@@ -254,7 +258,7 @@ __device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const
     ld_rows4_raw(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
     const int a = t.L & 3;
     if (ABSOLUTE) {
-        const double uk = gm(P.uit)[i4(P, t, k, a)];
+        const double uk = blk(P.uit, t, P.N, k, SZ_V4)[t.q * 4 + a];   // (start solve: home arrays, wave-blocked)
         const gdouble* yb = blk(P.yref, t, P.N, k, SZ_Y);
         const double yr = yb[t.q * 17 + 13 + a];
         const double wa = t.wu;
@@ -402,7 +406,8 @@ __device__ __forceinline__ bool factor_stage(const Params& P, const Lane& t, con
         // region with per-lane addresses
         gdouble* kr = ZL ? gm(P.KR) + ((size_t)t.inst * P.N + k) * 52 + imin(t.L, 12) * 4
                          : blk(P.KR, t, P.N, k, SZ_K) + (imin(t.L, 12) * 4 + t.q) * 4;
-        gdouble* dst = t.L == 13 ? gm(P.d) + i4(P, t, k, 0) : kr;
+        gdouble* dst = t.L == 13 ? ((ABSOLUTE && !AS) ? blk(P.d, t, P.N, k, SZ_V4) + t.q * 4   // (start solve: home array, wave-blocked)
+                                                      : gm(P.d) + i4(P, t, k, 0)) : kr;
         if (t.L < 14 && act) SFOR(a, 0, 4, { dst[a] = Kp[a]; });
         if (!ABSOLUTE && t.L == 0) {  // only the corrector of the interior-point iteration reads it
             gdouble* sv = blk(P.Sinv, t, P.N, k, SZ_S);

@@ -127,6 +127,9 @@ struct Params {
 #ifdef CFN_DEV
     int forward_half;            // 1: k_forward_half (two waves per SIMD) instead of k_forward (sub-fleet experiment)
 #endif
+    int v4b;                     // layout of the HOME 4-vectors (uit, uitn, d, v, lbs, ubs): 1 = wave-blocked [wave][stage][inst & 3][4] (the four
+                                 // instances of a block share one 128-byte line per stage, consumed whole by a wavefront in either mapping),
+                                 // 0 = instance-major [inst][stage][4] (the compact copies always; the home arrays of the partial-condensing path)
     int forward_rg;              // 1: forward sweep of the start solve on the stored blocks (k_forward_rg; small fleets)
     int clist_chunks;            // workgroups per 64-slot group of k_linearise_clist (stage chunks)
     int fused;                   // start solve: 0 = k_linearise + k_factor on stored (A, B, b); 1 = k_linfactor, nothing stored (the QP
@@ -177,8 +180,8 @@ void launch_estimate(int B, const double* meas, double* filt, const double* u, d
 void launch_sim(int B, const double* x, const double* u, double T, int steps, double* xn, hipStream_t st);
 // AoS [B][S][E] (external order) <-> wave-blocked vectors; perm13: first 13 entries of each
 // row are states and are permuted to the internal order.
-void launch_put(int B, int S, int E, int perm13, const double* aos, double* blk, hipStream_t st);
-void launch_get(int B, int S, int E, int perm13, int s0, int Stot, const double* blk, double* aos, hipStream_t st);
+void launch_put(int B, int S, int E, int perm13, const double* aos, double* blk, hipStream_t st, int v4b = 0);   // v4b: E = 4 fields in the wave-blocked layout (Params.v4b)
+void launch_get(int B, int S, int E, int perm13, int s0, int Stot, const double* blk, double* aos, hipStream_t st, int v4b = 0);
 void launch_windows(const Params& P, const double* traj, int n_rows, int* mode, int* iter, const double* des,
                     double uss, hipStream_t st);
 void launch_init_iterate(const Params& P, int mode, hipStream_t st);
