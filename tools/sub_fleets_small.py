@@ -25,7 +25,7 @@ def step(f, t):
     if t % 10 == 9:   # the bench's disturbance, roughly
         f["x"][:, 7:10] += 0.3 * torch.randn((f["x"].shape[0], 3), dtype=torch.float64, device=dev)
 for B in [int(a) for a in sys.argv[1:]] or [4096, 8192, 16384]:
-    for nsplit in (1, 2, 4, 1, 2, 4):
+    for nsplit in [int(a) for a in os.environ.get("NSPLIT", "1,2,4,1,2,4").split(",")]:
         per = B // nsplit
         fl = [make(per, 7 + i) for i in range(nsplit)]
         st = [torch.cuda.Stream(dev) for _ in range(nsplit)]
