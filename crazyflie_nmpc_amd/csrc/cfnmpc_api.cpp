@@ -89,16 +89,14 @@ constexpr size_t EV_PER_STEP = 7;
 //     instance, so long horizons leave it earlier (cross-over 7000 instances at N = 30 and 50, 5500 at N = 100);
 //   * active-set solves + commit kernel instead of the monolithic kernel: while the ~8 % constrained rows make fewer
 //     waves than there are SIMDs by a margin (roll-out = latency chain; equal within noise from 16 S to 36 S at N = 30, 50, 100);
-//   * fall-back rows compacted before the interior point: from 16 S instances;
-//   * k_forward in the division form: from B / 64 waves = S / 2 on (the sweep streams at the HBM rate).
-struct Choice { bool forward_rg, as_commit, ipm_listed, forward_div; };
+//   * fall-back rows compacted before the interior point: from 16 S instances.
+struct Choice { bool forward_rg, as_commit, ipm_listed; };
 inline Choice choose_kernels(int batch, int N, int simds) {
     const long S = simds > 0 ? simds : 1024;
     Choice c;
     c.forward_rg = (long)batch < (N <= 64 ? 8 : 6) * S;
     c.as_commit = (long)batch < 24 * S;
     c.ipm_listed = (long)batch >= 16 * S;
-    c.forward_div = (long)batch >= 32 * S;
     return c;
 }
 
@@ -299,7 +297,6 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.active_set = o.active_set ? 1 : 0;
     if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise) ||
         (o.reinit_failed && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
-    P.forward_div = pick.forward_div ? 1 : 0;
     // (an explicitly fused start solve stores no stage blocks: the automatic choice then stays with the matrix-free sweep)
     P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && pick.forward_rg && o.start_solve != 2) ? 1 : 0;
     if (o.as_passes < -3 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }

@@ -775,15 +775,13 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
 // COND (cfnmpc_opts.cond_N2, partial condensing): the gains of a block's stages are rows of the
 // CONDENSED feedback law, which acts on the state step at the START of the block (dxb); rolling the
 // interior states through the stage dynamics is the `expand` step of partial condensing.
-// FWD_DIV: the model's rotor / gyroscopic terms in the survey's literal form (four FP64 divisions per evaluation) instead
-// of the folded constants -- same function, rounding apart.  Measured on MI355X: the shorter instruction stream makes
-// the sweep FASTER where it is a latency chain (8192 instances 0.210 -> 0.187 ms, 16 384: 0.228 -> 0.205 ms) and SLOWER
-// where it streams at the HBM rate (65 536 instances, 1024 waves in step: 0.617 -> 0.666 ms, three A/B/A runs on one box),
-// so the launcher picks by fleet size (Params.forward_div).
-// FUSED_PT (round 4, k_forward_mid): nominal slope and directional derivative of an RK point from ONE evaluation with shared
-// sub-expressions (cfnmpc_model.hpp: lf_point, 151 FP64 instructions per point instead of f_expl + jac_point + jvp's ~225) --
-// where the sweep is a latency chain of N stages the shorter stream is the shorter chain.
-template <bool COND, bool FWD_DIV = false, bool FUSED_PT = false>
+// FUSED_PT (round 4): nominal slope and directional derivative of an RK point from ONE evaluation with shared
+// sub-expressions (cfnmpc_model.hpp: lf_point, 151 FP64 instructions per point instead of f_expl + jac_point + jvp's ~225).
+// Where the sweep is a latency chain of N stages the shorter stream is the shorter chain (8192 - 24 576 instances: -6 %); since
+// the home 4-vectors are wave-blocked it is also the faster form where the sweep streams at the HBM rate (32 768 instances
+// 0.281 -> 0.254 ms, 65 536: equal), so every matrix-free sweep uses it.  (Rounds 2 - 3 kept a second form with the model's
+// rotor terms as four FP64 divisions for the large fleets; removed.)
+template <bool COND, bool FUSED_PT = false>
 __device__ __forceinline__ void forward_body(const Params& P, double* xs, double* cs, int* sflag) {
     // 13-vectors travel through LDS tiles [instance][13] so that every global access of the wave
     // is a contiguous run (as in k_linearise); K, d, u, v are 32-byte runs per lane already.
@@ -904,26 +902,26 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         } else {
         JacPoint J;
         // stage 1
-        f_expl<FWD_DIV>(x, uc, kk);
+        f_expl(x, uc, kk);
         jac_point(x, J);
         jvp<true, true>(J, s, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
         SFOR(e, 0, 13, { acc[e] = dk[e]; ks[e] = kk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
         // stage 2
-        f_expl<FWD_DIV>(xt, uc, kk);
+        f_expl(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
         SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; ks[e] = ks[e] + 2 * kk[e]; xt[e] = x[e] + 0.5 * h * kk[e]; st[e] = s[e] + 0.5 * h * dk[e]; });
         // stage 3
-        f_expl<FWD_DIV>(xt, uc, kk);
+        f_expl(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
         SFOR(e, 0, 13, { acc[e] += 2.0 * dk[e]; ks[e] = ks[e] + 2 * kk[e]; xt[e] = x[e] + h * kk[e]; st[e] = s[e] + h * dk[e]; });
         // stage 4 (the nominal slope too: b_k = Phi(x_k, u_k) - x_{k+1} is formed here, as k_linearise
         // forms it, instead of being read back)
-        f_expl<FWD_DIV>(xt, uc, kk);
+        f_expl(xt, uc, kk);
         jac_point(xt, J);
         jvp<true, true>(J, st, dk);
         SFOR(i, 0, 4, { dk[9 + i] += jud[i]; });
@@ -998,13 +996,10 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
     }
 }
 
-#ifndef CFN_FWD_BIG_FUSED
-#define CFN_FWD_BIG_FUSED 0
-#endif
-KALIGN __global__ __launch_bounds__(64) void k_forward(Params P) {   // large fleets (see FWD_DIV above)
+KALIGN __global__ __launch_bounds__(64) void k_forward(Params P) {   // matrix-free forward sweep of the start solve
     __shared__ double xs[64 * 13], cs[64 * 13];
     __shared__ int sflag[64];
-    forward_body<false, true, CFN_FWD_BIG_FUSED != 0>(P, xs, cs, sflag);
+    forward_body<false, true>(P, xs, cs, sflag);
 }
 #ifdef CFN_DEV
 // the same at two waves per SIMD (<= 256 registers, a few spills): beside the fused start solve of ANOTHER sub-fleet, whose
@@ -1015,14 +1010,6 @@ __global__ __launch_bounds__(64, 2) void k_forward_half(Params P) {
     forward_body<false, true>(P, xs, cs, sflag);
 }
 #endif
-#ifndef CFN_FWD_FUSED
-#define CFN_FWD_FUSED 1
-#endif
-__global__ __launch_bounds__(64) void k_forward_mid(Params P) {   // fleets below 32 x SIMDs instances (cfnmpc_api.cpp: choose_kernels)
-    __shared__ double xs[64 * 13], cs[64 * 13];
-    __shared__ int sflag[64];
-    forward_body<false, false, CFN_FWD_FUSED != 0>(P, xs, cs, sflag);
-}
 __global__ __launch_bounds__(64) void k_cforward(Params P) {
     __shared__ double xs[64 * 13], cs[64 * 13];
     __shared__ int sflag[64];
@@ -2789,8 +2776,7 @@ void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev, bool skip_
 #ifdef CFN_DEV
         if (P.forward_half) { hipLaunchKernelGGL(k_forward_half, dim3((P.B + 63) / 64), dim3(64), 0, st, P); } else
 #endif
-        if (P.forward_div) hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
-        else hipLaunchKernelGGL(k_forward_mid, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     }
     if (ev) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_compact, dim3(N_BIN), dim3(256), 0, st, P);

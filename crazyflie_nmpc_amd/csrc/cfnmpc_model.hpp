@@ -62,7 +62,6 @@ __host__ __device__ constexpr int s4(int i, int j) {
 }
 
 // ---- continuous dynamics ----------------------------------------------------------------
-template <bool DIV = false>
 __device__ __forceinline__ void f_expl(const double* __restrict__ x, const double* __restrict__ u,
                                        double* __restrict__ dx) {
     const double q1 = x[3], q2 = x[4], q3 = x[5], q4 = x[6];
@@ -81,13 +80,6 @@ __device__ __forceinline__ void f_expl(const double* __restrict__ x, const doubl
     // (rotor terms and gyroscopic couplings with the constants folded at compile time -- KT = Ct / mq, KA = -Ct l / Ixx, ...,
     //  KWX = -(Izz - Iyy) / Ixx, ...: the same products jvp() differentiates; a division by mq / Ixx / Iyy / Izz per
     //  evaluation cost k_linearise 16 FP64 divisions per shooting interval)
-    if (DIV) {   // the survey's expressions literally (A.2)
-        dx[9] = vbx * wy - vby * wx - G0 * (2 * q1 * q1 + 2 * q4 * q4 - 1) + (CT * (w1 * w1 + w2 * w2 + w3 * w3 + w4 * w4)) / MQ;
-        dx[10] = -(CT * ARM * (w1 * w1 + w2 * w2 - w3 * w3 - w4 * w4) - IYY * wy * wz + IZZ * wy * wz) / IXX;
-        dx[11] = -(CT * ARM * (w1 * w1 - w2 * w2 - w3 * w3 + w4 * w4) + IXX * wx * wz - IZZ * wx * wz) / IYY;
-        dx[12] = -(CD * (w1 * w1 - w2 * w2 + w3 * w3 - w4 * w4) - IXX * wx * wy + IYY * wx * wy) / IZZ;
-        return;
-    }
     const double s1 = w1 * w1, s2 = w2 * w2, s3 = w3 * w3, s4 = w4 * w4;
     dx[9] = vbx * wy - vby * wx - G0 * (2 * q1 * q1 + 2 * q4 * q4 - 1) + KT * (s1 + s2 + s3 + s4);
     dx[10] = KA * (s1 + s2 - s3 - s4) + KWX * (wy * wz);

@@ -123,7 +123,6 @@ struct Params {
     int lin_k0, lin_k1, fk_lo, fk_hi;
     double *Ppark;               // cost-to-go between the chunks, [wave][13][64]
 #endif
-    int forward_div;             // 1: k_forward (division form: fleets that stream at the HBM rate), 0: k_forward_mid; see forward_body
 #ifdef CFN_DEV
     int forward_half;            // 1: k_forward_half (two waves per SIMD) instead of k_forward (sub-fleet experiment)
 #endif

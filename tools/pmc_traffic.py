@@ -34,7 +34,7 @@ def main():
         r, w = 2.0 * rd.get(k, 0.0) * 1024.0, wr.get(k, 0.0) * 1024.0
         kernels[k] = {"read_bytes": r, "write_bytes": w, "total_bytes": r + w}
     qp = sum(v["total_bytes"] for k, v in kernels.items() if k.split("<")[0] in (
-        "cfn::k_factor", "cfn::k_forward", "cfn::k_forward_mid", "cfn::k_forward_rg", "cfn::k_rank", "cfn::k_ipm_list",
+        "cfn::k_factor", "cfn::k_forward", "cfn::k_forward_rg", "cfn::k_rank", "cfn::k_ipm_list",
         "cfn::k_as_solves", "cfn::k_ascommit", "cfn::k_ascommit1", "cfn::k_as_retry", "cfn::k_compact", "cfn::k_scatter", "cfn::k_as", "cfn::k_ipm_rest", "cfn::k_ipm",
         "cfn::k_pcond", "cfn::k_cfactor", "cfn::k_cforward", "cfn::k_cipm",
         "cfn::k_linfactor", "cfn::k_linearise_clist", "cfn::k_as_cst", "cfn::k_ipm_rest_cst", "cfn::k_ipm_cst", "cfn::k_forward_half"))
