@@ -182,3 +182,30 @@ def test_start_solve_option_validation_and_per_stage_boxes(oracle):
     ok = st1 == 0
     assert np.abs(u1[ok] - u2[ok]).max() < 1e-8 and np.abs(x1[ok] - x2[ok]).max() < 1e-8
     assert np.abs(u1[ok][:, 0, :] - HOV).max() < 1e-9
+
+
+def test_get_factor_rows_are_the_instances_own(oracle):
+    """cfnmpc_debug_get_factor decodes the wave-blocked device layouts (gains [wave][stage][col][inst & 3][4], feed-forward
+    terms in the home 4-vector layout, packed checkpoint triangles): every row of a ragged fleet must equal what a solver
+    holding that instance alone returns."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    B, N = 7, 50
+    rng = np.random.default_rng(11)
+    x0, yref, yref_e = _inputs(oracle, B, N, seed=12, scale=1.5)
+    xi, ui = _rough_iterate(rng, x0, N)
+    s = BatchSolver(B, default_opts(N=N))
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.set_iterate(xi, ui)
+    s.start_factor(1)
+    K, d, P, st = s.get_factor()
+    s.close()
+    assert (st == 0).all()
+    for i in (0, 3, 4, 6):
+        s1 = BatchSolver(1, default_opts(N=N))
+        s1.set_x0(x0[i:i + 1]); s1.set_yref(yref[i:i + 1], yref_e[i:i + 1]); s1.set_iterate(xi[i:i + 1], ui[i:i + 1])
+        s1.start_factor(1)
+        K1, d1, P1, st1 = s1.get_factor()
+        s1.close()
+        assert np.array_equal(K[i], K1[0]) and np.array_equal(d[i], d1[0]) and np.array_equal(P[i], P1[0]), i
+        assert np.abs(d1).max() > 1e-3
+    # the checkpoints come back symmetric (one triangle is stored)
+    assert np.array_equal(P, np.swapaxes(P, 2, 3))
