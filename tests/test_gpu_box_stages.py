@@ -144,3 +144,33 @@ def test_fleet_per_stage_boxes_reach_every_bucket(oracle):
     f.set_x0(x0); f.init_iterate(INIT_HOVER); f.solve(1)
     assert np.abs(f.get_u(0) - pin).max() > 0.1          # the pin is gone
     f.close()
+
+
+def test_box_stages_device_arrays_equal_host_arrays(oracle):
+    """per-instance, per-stage boxes handed over as DEVICE tensors (transposed on the device into the home 4-vector layout)
+    give bitwise the host-array result on a ragged fleet"""
+    import torch
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 9, 50
+    rng = np.random.default_rng(21)
+    x0 = oracle.sample_hover_x0(rng, B, scale=2.0)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    lb = rng.uniform(0.0, 6.0, (B, N, 4)); ub = rng.uniform(17.0, 22.0, (B, N, 4))    # every instance and stage its own box
+    out = []
+    for dev_arrays in (False, True):
+        s = BatchSolver(B, default_opts())
+        s.set_x0(x0); s.set_yref(np.repeat(yr[None], B, 0).copy(), np.repeat(ye[None], B, 0).copy()); s.init_iterate(INIT_HOVER)
+        if dev_arrays:
+            s.set_box_stages(torch.from_numpy(lb).cuda(), torch.from_numpy(ub).cuda())
+        else:
+            s.set_box_stages(lb, ub)
+        s.solve(3)
+        st, it, _ = s.stats()
+        out.append((st, it) + s.get_iterate())
+        s.close()
+    (st1, it1, x1, u1), (st2, it2, x2, u2) = out
+    assert (st1 == 0).all() and np.array_equal(st1, st2) and np.array_equal(it1, it2)
+    assert (it1 > 0).any()
+    assert np.array_equal(u1, u2) and np.array_equal(x1, x2)
+    assert (u1 >= lb - 1e-9).all() and (u1 <= ub + 1e-9).all()
