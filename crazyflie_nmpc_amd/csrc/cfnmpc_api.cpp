@@ -88,14 +88,15 @@ constexpr size_t EV_PER_STEP = 7;
 //     sequential stages): while B / 4 waves fit about twice on the SIMDs; the row-group sweep streams 240 N doubles per
 //     instance, so long horizons leave it earlier (cross-over 7000 instances at N = 30 and 50, 5500 at N = 100);
 //   * active-set solves + commit kernel instead of the monolithic kernel: while the ~8 % constrained rows make fewer
-//     waves than there are SIMDs by a margin (roll-out = latency chain; equal within noise from 16 S to 36 S at N = 30, 50, 100);
+//     waves than there are SIMDs by a margin (roll-out = latency chain); re-measured after the 4-vector layout change:
+//     N = 50: -3.5 % at 24 S, -0.5 % at 32 S, equal at 48 S; N = 100: -3.6 % up to 32 S, equal at 48 S; N = 30: +4.7 % from 24 S on;
 //   * fall-back rows compacted before the interior point: from 16 S instances.
 struct Choice { bool forward_rg, as_commit, ipm_listed; };
 inline Choice choose_kernels(int batch, int N, int simds) {
     const long S = simds > 0 ? simds : 1024;
     Choice c;
     c.forward_rg = (long)batch < (N <= 64 ? 8 : 6) * S;
-    c.as_commit = (long)batch < 24 * S;
+    c.as_commit = (long)batch < (N <= 40 ? 20 : 36) * S;
     c.ipm_listed = (long)batch >= 16 * S;
     return c;
 }
