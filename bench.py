@@ -244,8 +244,8 @@ class Fleet:
         self.solver.close()
 
 
-def mixed_horizon_run(batch, dev, rng, steps, warmup, predictor="queued"):
-    """Config C5: `batch` vehicles with N in {30, 50, 100} (one cfnmpc_fleet = one solver per horizon
+class MixedFleetLoop:
+    """Config C5 closed loop on this rank's GPU: vehicles with N in {30, 50, 100} (one cfnmpc_fleet = one solver per horizon
     bucket behind one handle), regulation targets U(-1,1)^2 x U(0.2,1); the plant applies every input 60 ms
     = 4 sampling periods after it was computed (the communication delay the reference compensates,
     acados_mpc.cpp:624, launch/acados_predictor.launch:62) and x0 is the prediction of the state over that
@@ -258,49 +258,66 @@ def mixed_horizon_run(batch, dev, rng, steps, warmup, predictor="queued"):
     which then set the duration of the whole fleet's step: 15 - 24 ms instead of 5.8 ms, measured).
     predictor = "latest": the REFERENCE's protocol instead -- x0 = one crazyflie_acados_sim_solve over the whole 60 ms with the
     latest input held (acados_estimator.cpp:573-593: sim_in_set "T" = delay, "x", "u" = the last published motor speeds), same
-    plant; reported with how long that loop stays healthy (`steps_until_ok_frac_below_0.99`).  -> dict for the `sensitivity` block."""
-    import torch
-    from crazyflie_nmpc_amd import sim
-    from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
-    from crazyflie_nmpc_amd.solver import INIT_HOVER
-    from crazyflie_nmpc_amd.synthetic import HOV_W, sample_hover_x0
-    horizons = rng.choice([30, 50, 100], size=batch)
-    fleet = MixedHorizonFleet(horizons)
-    tgt = np.concatenate([rng.uniform(-1, 1, (batch, 2)), rng.uniform(0.2, 1.0, (batch, 1))], axis=1)
-    fleet.set_regulation(tgt, HOV_W)
-    off = np.concatenate([tgt - [0.0, 0.0, 0.4], np.zeros((batch, 10))], axis=1)
-    x = torch.from_numpy(sample_hover_x0(rng, batch) + off).to(dev)
-    xn, xp = torch.empty_like(x), torch.empty_like(x)
-    u0 = torch.full((batch, 4), HOV_W, dtype=torch.float64, device=dev)
-    uq = [u0.clone() for _ in range(4)]           # inputs in flight: computed at t - 4 .. t - 1
-    cohort = (batch + KICK_PERIOD - 1) // KICK_PERIOD
-    kicks = torch.from_numpy(sample_hover_x0(rng, cohort * KICK_PERIOD).reshape(KICK_PERIOD, cohort, 13)).to(dev)
-    offd = torch.from_numpy(off).to(dev)
-    fleet.set_x0(x); fleet.init_iterate(INIT_HOVER)
-    t = 0
+    plant.  `horizons` [n] are this rank's vehicles (for N > 1 GPUs: its part of parallel.shard_by_horizon)."""
 
-    def step():
-        nonlocal x, xn, t
-        c0 = (t % KICK_PERIOD) * cohort
-        c1 = min(c0 + cohort, batch)
-        nonlocal xp
+    def __init__(self, horizons, dev, rng, predictor="queued", **opt_kw):
+        import torch
+        from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
+        from crazyflie_nmpc_amd.solver import INIT_HOVER
+        from crazyflie_nmpc_amd.synthetic import HOV_W, sample_hover_x0
+        self.horizons = np.ascontiguousarray(horizons, dtype=np.int32)
+        self.n = n = len(self.horizons)
+        self.dev, self.predictor, self.hov = dev, predictor, HOV_W
+        self.fleet = MixedHorizonFleet(self.horizons, **opt_kw)
+        tgt = np.concatenate([rng.uniform(-1, 1, (n, 2)), rng.uniform(0.2, 1.0, (n, 1))], axis=1)
+        self.fleet.set_regulation(tgt, HOV_W)
+        off = np.concatenate([tgt - [0.0, 0.0, 0.4], np.zeros((n, 10))], axis=1)
+        self.x = torch.from_numpy(sample_hover_x0(rng, n) + off).to(dev)
+        self.xn, self.xp = torch.empty_like(self.x), torch.empty_like(self.x)
+        self.u0 = torch.full((n, 4), HOV_W, dtype=torch.float64, device=dev)
+        self.uq = [self.u0.clone() for _ in range(4)]           # inputs in flight: computed at t - 4 .. t - 1
+        self.cohort = (n + KICK_PERIOD - 1) // KICK_PERIOD
+        self.kicks = torch.from_numpy(sample_hover_x0(rng, self.cohort * KICK_PERIOD).reshape(KICK_PERIOD, self.cohort, 13)).to(dev)
+        self.offd = torch.from_numpy(off).to(dev)
+        self.fleet.set_x0(self.x); self.fleet.init_iterate(INIT_HOVER)
+        self.t = 0
+
+    def step(self):
+        from crazyflie_nmpc_amd import sim
+        t, x, uq = self.t, self.x, self.uq
+        c0 = (t % KICK_PERIOD) * self.cohort
+        c1 = min(c0 + self.cohort, self.n)
         if c1 > c0:   # a kicked vehicle is a fresh one: new state, hover inputs in flight
-            x[c0:c1].copy_(kicks[t % KICK_PERIOD, : c1 - c0] + offd[c0:c1])
+            x[c0:c1].copy_(self.kicks[t % KICK_PERIOD, : c1 - c0] + self.offd[c0:c1])
             for q in uq:
-                q[c0:c1] = HOV_W
-        if predictor == "latest":   # the reference's predictor: the latest input held over the delay, RK4 with 4 sub-steps (App. D-8)
-            sim(x, uq[(t + 3) % 4], T=0.06, steps=4, out=xp)
+                q[c0:c1] = self.hov
+        if self.predictor == "latest":   # the reference's predictor: the latest input held over the delay, RK4 with 4 sub-steps (App. D-8)
+            sim(x, uq[(t + 3) % 4], T=0.06, steps=4, out=self.xp)
         else:
-            sim(x, uq[t % 4], T=0.015, steps=1, out=xp)   # delay compensation: through the four inputs in flight
+            sim(x, uq[t % 4], T=0.015, steps=1, out=self.xp)   # delay compensation: through the four inputs in flight
             for j in (1, 2, 3):
-                sim(xp, uq[(t + j) % 4], T=0.015, steps=1, out=xn)
-                xp, xn = xn, xp
-        fleet.set_x0(xp); fleet.solve(1); fleet.get_u(0, u0)
-        sim(x, uq[t % 4], T=0.015, steps=1, out=xn)   # the plant sees the inputs computed 4 periods ago
-        uq[t % 4].copy_(u0)
-        x, xn = xn, x
-        t += 1
+                sim(self.xp, uq[(t + j) % 4], T=0.015, steps=1, out=self.xn)
+                self.xp, self.xn = self.xn, self.xp
+        self.fleet.set_x0(self.xp); self.fleet.solve(1); self.fleet.get_u(0, self.u0)
+        sim(x, uq[t % 4], T=0.015, steps=1, out=self.xn)   # the plant sees the inputs computed 4 periods ago
+        uq[t % 4].copy_(self.u0)
+        self.x, self.xn = self.xn, x
+        self.t = t + 1
 
+    def stats(self):
+        return self.fleet.stats()
+
+    def close(self):
+        self.fleet.close()
+
+
+def mixed_horizon_run(batch, dev, rng, steps, warmup, predictor="queued"):
+    """Config C5 on one GPU for the `sensitivity` block (see MixedFleetLoop).  predictor = "latest" (the reference's protocol)
+    is reported with how long that loop stays healthy (`steps_until_ok_frac_below_0.99`)."""
+    import torch
+    horizons = rng.choice([30, 50, 100], size=batch)
+    loop = MixedFleetLoop(horizons, dev, rng, predictor)
+    step = loop.step
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
@@ -309,7 +326,7 @@ def mixed_horizon_run(batch, dev, rng, steps, warmup, predictor="queued"):
         step()
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
-    st, it, _ = fleet.stats()
+    st, it, _ = loop.stats()
     out = {"value": batch * steps / el, "stage_steps_per_s": float(horizons.sum()) * steps / el, "ms_per_step": el / steps * 1e3,
            "frac_constrained": float((it > 0).mean()), "mean_qp_solves": float(it.mean()), "status_ok_frac": float((st == 0).mean()),
            "buckets": {int(n): int((horizons == n).sum()) for n in (30, 50, 100)}}
@@ -322,13 +339,13 @@ def mixed_horizon_run(batch, dev, rng, steps, warmup, predictor="queued"):
             for _ in range(5):
                 step()
             survived += 5
-            st2 = fleet.stats()[0]
-            if float((st2 == 0).mean()) < 0.99 or not bool(torch.isfinite(x).all()) or float(x[:, :3].abs().max()) > 50.0:
+            st2 = loop.stats()[0]
+            if float((st2 == 0).mean()) < 0.99 or not bool(torch.isfinite(loop.x).all()) or float(loop.x[:, :3].abs().max()) > 50.0:
                 break
         out["steps_until_ok_frac_below_0.99"] = survived if survived < 400 else ">= 400"
-        out["status_ok_frac_at_the_end"] = float((fleet.stats()[0] == 0).mean())
-    fleet.close()
-    del fleet
+        out["status_ok_frac_at_the_end"] = float((loop.stats()[0] == 0).mean())
+    loop.close()
+    del loop
     torch.cuda.empty_cache()
     return out
 
@@ -361,6 +378,24 @@ def timed_run(fleet, steps, warmup, barrier):
                                         constrained=float((it > 0).sum()), heads=float(heads.sum()), kms=kms)
 
 
+def _relaunch_under_torchrun(n, backend, ndev):
+    """exec torch.distributed.run with the same argv: --nnodes=1, one rank per GPU, rendezvous on 127.0.0.1 (the container's
+    hostname may not resolve).  Refuses (non-zero exit) when RCCL would need more devices than are visible."""
+    if backend == "nccl" and ndev < n:
+        raise SystemExit(f"bench.py: --gpus {n} with the nccl (RCCL) backend needs {n} visible HIP devices, found {ndev} "
+                         "(--dist-backend gloo lets ranks share devices for functional checks only)")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+    os.execv(sys.executable, cmd)
+
+
 def main():
     if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-baseline-child":
         return _cpu_baseline_child(int(sys.argv[2]))
@@ -385,25 +420,38 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (default); gloo only for functional checks of the N > 1 path on "
                          "a box with fewer GPUs than ranks (ranks then share devices)")
-    ap.add_argument("--workload", choices=["hover", "figure8"], default="hover",
+    ap.add_argument("--workload", choices=["hover", "figure8", "mixed"], default="hover",
                     help="hover = config C3 (the metric's configuration); figure8 = config C4 tracking with "
-                         "device-side reference windows")
+                         "device-side reference windows; mixed = config C5: horizons N in {30, 50, 100}, delay-compensated x0, "
+                         "vehicles dealt out over the GPUs by horizon bucket so that sum N is balanced (parallel.shard_by_horizon)")
+    ap.add_argument("--predictor", choices=["queued", "latest"], default="queued",
+                    help="--workload mixed: delay compensation through the four queued inputs (default) or the reference's "
+                         "latest-input-held predictor (acados_estimator.cpp:573-593)")
     ap.add_argument("--overlap", type=int, default=None, help="cfnmpc_opts.overlap_linearise (default: library default)")
     ap.add_argument("--ah-margin", type=float, default=None)
     ap.add_argument("--ah-extra", type=int, default=None)
     ap.add_argument("--start-solve", type=int, default=None, help="cfnmpc_opts.start_solve (0 auto, 1 k_linearise + k_factor on stored blocks, "
                     "2 fused k_linfactor, 3 fused factorisation + stored blocks)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the engine has no CPU path)")
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` WITHOUT a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py <same
+        # argv>` (one rank per GPU; rank 0's JSON line goes to the same stdout) -- `--gpus N` means N GPUs whoever starts it
+        _relaunch_under_torchrun(args.gpus, args.dist_backend, torch.cuda.device_count())
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:   # never print a line whose n_gpus differs from what was asked for
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or plain `python bench.py --gpus N`)")
     ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} with the nccl (RCCL) backend needs {world} visible HIP devices, found {ndev} "
+                         "(--dist-backend gloo lets ranks share devices for functional checks only)")
     if args.dist_backend == "nccl" and local_rank >= ndev:
         raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
     dev = torch.device("cuda", local_rank % ndev)
@@ -455,6 +503,66 @@ def main():
                     ms_lin=sums[5] / world, ms_qp=sums[6] / world, ok_frac=sums[0] / tot, mean_qp_solves=sums[2] / tot,
                     frac_constrained=sums[3] / tot, mean_head=sums[4] / tot, batch_rank=batch_rank,
                     kms=[float(v) / world for v in sums[8:14]])
+
+    if args.workload == "mixed":
+        # config C5 across the GPUs (SURVEY.md section 8e "Partitioning": bucket by N, then balance the buckets over the GPUs
+        # by sum N_i): ONE fleet-wide horizon draw (same on every rank), dealt out by parallel.shard_by_horizon; every rank runs
+        # its vehicles as one cfnmpc_fleet (a solver per horizon bucket).  No data-path collective; the report travels as usual.
+        total = args.batch if scaling == "strong" else args.batch * world
+        hz_all = np.random.default_rng(parallel.BASE_SEED + 5005).choice([30, 50, 100], size=total)
+        mine = parallel.shard_by_horizon(hz_all, world)[rank]
+        hz = hz_all[mine]
+        loop = MixedFleetLoop(hz, dev, np.random.default_rng(seed + 9000), args.predictor, **opt_kw)
+        torch.cuda.synchronize(dev)
+        for _ in range(args.warmup):
+            loop.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loop.step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        st, it, _rs = loop.stats()
+        loop.close()
+        slots = np.zeros((world, 4))          # per-rank: sum N, bucket sizes -- one slot per rank, summed over ranks = gathered
+        slots[rank] = [float(hz.sum())] + [float((hz == n).sum()) for n in (30, 50, 100)]
+        sums = [float((st == 0).sum()), float(it.sum()), float((it > 0).sum()), float(len(hz)), float(hz.sum())] + slots.ravel().tolist()
+        elapsed, sums = parallel.aggregate_report(elapsed, sums, dist, red_dev)
+        if rank == 0:
+            tot, sumN = sums[3], sums[4]
+            per_rank = sums[5:].reshape(world, 4)
+            alg = float(sum(alg_bytes_step(int(n)) * per_rank[:, 1 + j].sum() for j, n in enumerate((30, 50, 100))))
+            ms = elapsed / args.steps * 1e3
+            out = {
+                "metric": "NMPC RTI steps/sec (batch=65536, N=50, nx=13, nu=4)", "value": tot * args.steps / elapsed, "unit": "RTI steps/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+                "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "stage_steps_per_s": sumN * args.steps / elapsed,
+                "config": {"workload": "C5 mixed horizons N in {30, 50, 100}, delay-compensated x0 (60 ms, predictor: "
+                                       + ("the four queued inputs, oldest first" if args.predictor == "queued" else
+                                          "the reference's: latest input held, acados_estimator.cpp:573-593")
+                                       + f"), closed loop through the RK4 plant, staggered kicks (1/{KICK_PERIOD} of the fleet per step)",
+                           "total_batch": int(tot), "horizons": {str(n): int(per_rank[:, 1 + j].sum()) for j, n in enumerate((30, 50, 100))},
+                           "nx": 13, "nu": 4,
+                           "sharding": (f"{scaling} scaling: {int(tot)} vehicles bucketed by horizon and dealt out over {world} GPU(s) so that sum N "
+                                        "is balanced (parallel.shard_by_horizon), one solver per bucket and rank, no data-path collective"),
+                           "per_rank": [{"rank": r, "sum_N": int(per_rank[r, 0]), "vehicles": int(per_rank[r, 1:].sum()),
+                                         "buckets": {str(n): int(per_rank[r, 1 + j]) for j, n in enumerate((30, 50, 100))}} for r in range(world)],
+                           "sum_N_imbalance": float((per_rank[:, 0].max() - per_rank[:, 0].min()) / per_rank[:, 0].mean())},
+                # no per-kernel events here: the buckets' steps run concurrently on forked streams, so the model is set against the
+                # wall clock of the whole closed-loop step (plant, predictor, row gathers included)
+                "roofline": {"bound": "hbm", "kernel": "whole closed-loop step (wall clock; buckets run concurrently on forked streams)",
+                             "achieved": alg / world / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                             "frac": alg / world / (ms * 1e-3) / HBM_PEAK, "traffic": None, "alg_bytes_per_step_all_gpus": alg},
+                "qp_stats": {"status_ok_frac": sums[0] / tot, "mean_qp_solves": sums[1] / tot, "frac_constrained": sums[2] / tot},
+            }
+            if dist is not None:
+                out["report_collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "device": red_dev.type}
+            print(json.dumps(out))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if scaling == "strong":
         lo, hi = parallel.shard_range(args.batch, rank, world)

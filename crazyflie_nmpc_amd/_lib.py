@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("CFNMPC_LIB") or os.path.join(_HERE, "libcfnmpc.so")  
 
 # every symbol include/cfnmpc.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "cfnmpc_default_opts", "cfnmpc_create", "cfnmpc_free", "cfnmpc_batch", "cfnmpc_horizon",
+    "cfnmpc_default_opts", "cfnmpc_default_opts_v", "cfnmpc_opts_size", "cfnmpc_abi_version", "cfnmpc_create", "cfnmpc_free", "cfnmpc_batch", "cfnmpc_horizon",
     "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_set_weights", "cfnmpc_set_box", "cfnmpc_get_cmd", "cfnmpc_set_yref_windows", "cfnmpc_init_iterate",
     "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_step_host", "cfnmpc_get_u", "cfnmpc_get_x",
     "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_estimate", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise", "cfnmpc_debug_start_factor", "cfnmpc_debug_get_factor",
@@ -23,12 +23,14 @@ SYMBOLS = [
     "cfnmpc_multi_create", "cfnmpc_multi_free", "cfnmpc_multi_batch", "cfnmpc_multi_num_shards", "cfnmpc_multi_shard",
     "cfnmpc_multi_set_x0", "cfnmpc_multi_set_yref", "cfnmpc_multi_set_weights", "cfnmpc_multi_init_iterate", "cfnmpc_multi_solve",
     "cfnmpc_multi_sync", "cfnmpc_multi_set_box", "cfnmpc_multi_set_box_stages", "cfnmpc_multi_get_u", "cfnmpc_multi_get_x", "cfnmpc_multi_get_cmd", "cfnmpc_multi_get_stats",
+    "cfnmpc_multi_create_horizons", "cfnmpc_multi_shard_fleet", "cfnmpc_shard_by_horizon",
 ]
+ABI_VERSION = 5   # CFNMPC_ABI_VERSION of the include/cfnmpc.h this binding was written against
 
 
 class Opts(C.Structure):
     """struct cfnmpc_opts"""
-    _fields_ = [("N", C.c_int), ("dt", C.c_double), ("W", C.c_double * NY), ("WN", C.c_double * NYN),
+    _fields_ = [("struct_size", C.c_int), ("N", C.c_int), ("dt", C.c_double), ("W", C.c_double * NY), ("WN", C.c_double * NYN),
                 ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
                 ("lam0_min", C.c_double), ("mu0_scale", C.c_double), ("active_horizon", C.c_int), ("ah_margin", C.c_double),
@@ -56,8 +58,17 @@ def lib():
         pass
     L = C.CDLL(LIB_PATH)
     vp, ip, dbl, i32 = C.c_void_p, C.c_int, C.c_double, C.c_int
+    # ABI guard (include/cfnmpc.h): this binding's struct must be the library's before anything is written through it
+    if not hasattr(L, "cfnmpc_opts_size") or L.cfnmpc_opts_size() != C.sizeof(Opts) or L.cfnmpc_abi_version() != ABI_VERSION:
+        have = (L.cfnmpc_opts_size(), L.cfnmpc_abi_version()) if hasattr(L, "cfnmpc_opts_size") else "no ABI guard (older library)"
+        raise ImportError(f"{LIB_PATH}: cfnmpc_opts size / ABI version {have} do not match this binding's "
+                          f"({C.sizeof(Opts)}, {ABI_VERSION}): rebuild the library (make -C crazyflie_nmpc_amd/csrc)")
     L.cfnmpc_default_opts.argtypes = [C.POINTER(Opts)]
     L.cfnmpc_default_opts.restype = None
+    L.cfnmpc_default_opts_v.argtypes = [C.POINTER(Opts), i32]
+    L.cfnmpc_multi_create_horizons.argtypes = [C.POINTER(vp), i32, vp, i32, vp, C.POINTER(Opts)]
+    L.cfnmpc_multi_shard_fleet.argtypes = [vp, i32, C.POINTER(vp), vp, vp, vp, C.POINTER(vp)]
+    L.cfnmpc_shard_by_horizon.argtypes = [i32, vp, i32, vp]
     L.cfnmpc_create.argtypes = [C.POINTER(vp), i32, C.POINTER(Opts)]
     L.cfnmpc_free.argtypes = [vp]
     L.cfnmpc_batch.argtypes = [vp]

@@ -67,7 +67,7 @@ sim_out* crazyflie_sim_out = nullptr;
 int acados_create(void) {
     if (g) return 0;
     Shim* h = new Shim();
-    cfnmpc_default_opts(&h->opts);
+    if (CFNMPC_DEFAULT_OPTS(&h->opts) != CFNMPC_OK) { delete h; return 1; }   // shim and engine built from different headers
     if (cfnmpc_create(&h->s, 1, &h->opts) != CFNMPC_OK) {
         delete h;
         return 1;

@@ -176,6 +176,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     // generate_c_code.py:41-42,63-84,109,133-134
     static const double W[CFNMPC_NY] = {120.0, 100.0, 100.0, 1e-3, 1e-3, 1e-3, 1e-3, 0.7, 1.0,
                                         4.0,   1e-5,  1e-5,  10.0, 0.06, 0.06, 0.06, 0.06};
+    o->struct_size = (int)sizeof(cfnmpc_opts);
     o->N = 50;
     o->dt = 0.75 / 50;
     for (int i = 0; i < CFNMPC_NY; i++) o->W[i] = W[i];
@@ -204,8 +205,22 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->start_solve = 0;
 }
 
+int cfnmpc_default_opts_v(cfnmpc_opts* o, int sizeof_opts) {
+    if (!o || sizeof_opts != (int)sizeof(cfnmpc_opts)) return CFNMPC_EINVAL;   // nothing is written into a struct of another size
+    cfnmpc_default_opts(o);
+    return CFNMPC_OK;
+}
+int cfnmpc_opts_size(void) { return (int)sizeof(cfnmpc_opts); }
+int cfnmpc_abi_version(void) { return CFNMPC_ABI_VERSION; }
+
 int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     if (!out || batch <= 0) return CFNMPC_EINVAL;
+    // ABI guard: the first field is the size the caller's filler saw -- read BEFORE the struct is copied
+    if (opts && opts->struct_size != (int)sizeof(cfnmpc_opts)) {
+        std::fprintf(stderr, "cfnmpc: cfnmpc_opts of %d bytes handed to a library built for %d (ABI %d): rebuild against include/cfnmpc.h\n",
+                     opts->struct_size, (int)sizeof(cfnmpc_opts), CFNMPC_ABI_VERSION);
+        return CFNMPC_EINVAL;
+    }
     cfnmpc_opts o;
     if (opts) o = *opts; else cfnmpc_default_opts(&o);
     if (o.N < 5 || o.N > 4096 || !(o.dt > 0) || !(o.u_max > o.u_min) || o.max_iter < 0 ||

@@ -109,6 +109,7 @@ extern "C" {
 int cfnmpc_fleet_create(cfnmpc_fleet** out, int batch, const int* N_per_instance, const cfnmpc_opts* opts) {
     if (!out || batch < 1 || !N_per_instance) return CFNMPC_EINVAL;
     *out = nullptr;
+    if (opts && opts->struct_size != (int)sizeof(cfnmpc_opts)) return CFNMPC_EINVAL;   // ABI guard (include/cfnmpc.h)
     cfnmpc_opts o;
     if (opts) o = *opts; else cfnmpc_default_opts(&o);
     const int cond_N2_req = o.cond_N2;

@@ -21,17 +21,18 @@ def shard_range(total: int, rank: int, world: int):
 
 
 def shard_by_horizon(horizons, world: int):
-    """Mixed-horizon batches (config C5): bucket by N (wave-homogeneous), then deal buckets out
-    so that sum(N_i) -- the cost model -- is balanced.  Returns a list of index arrays per rank."""
-    horizons = np.asarray(horizons)
-    order = np.argsort(-horizons, kind="stable")
-    load = np.zeros(world)
-    out = [[] for _ in range(world)]
-    for i in order:
-        r = int(np.argmin(load))
-        out[r].append(int(i))
-        load[r] += horizons[i]
-    return [np.array(sorted(ix), dtype=np.int64) for ix in out]
+    """Mixed-horizon batches (config C5): bucket by N (wave-homogeneous), then deal the buckets out so that sum(N_i) -- the
+    cost model of a step -- is balanced (SURVEY.md section 8e "Partitioning").  The partitioner is the library's
+    (cfnmpc_shard_by_horizon, host code: the same one cfnmpc_multi_create_horizons uses for its shards), so bench.py's ranks
+    and an in-process MultiGpuFleet split a fleet identically.  Returns a list of ascending index arrays, one per rank."""
+    import ctypes as C
+    from . import _lib
+    hz = np.ascontiguousarray(horizons, dtype=np.int32)
+    of = np.empty(len(hz), dtype=np.int32)
+    rc = _lib.lib().cfnmpc_shard_by_horizon(len(hz), hz.ctypes.data_as(C.c_void_p), int(world), of.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise ValueError(f"cfnmpc_shard_by_horizon failed with code {rc} (horizons must be >= 1, world >= 1)")
+    return [np.nonzero(of == r)[0].astype(np.int64) for r in range(int(world))]
 
 
 def aggregate_report(elapsed: float, sums, dist=None, device=None):
@@ -55,7 +56,9 @@ class MultiGpuFleet:
     the whole fleet.  (bench.py keeps the one-process-per-GPU form the driver launches; this is the
     deployment form for a single controller process.)"""
 
-    def __init__(self, total_batch, device_ids, opts=None):
+    def __init__(self, total_batch, device_ids, opts=None, horizons=None):
+        """horizons [total_batch] (optional): one horizon per vehicle -- config C5; the shards are then cfnmpc_fleets over the
+        index sets of shard_by_horizon, host arrays use the fleet layouts (yref [B][Nmax][17], boxes [B][Nmax][4])."""
         import ctypes as C
         from . import _lib
         from .solver import _check, default_opts
@@ -63,11 +66,20 @@ class MultiGpuFleet:
         self._L = _lib.lib()
         self.B = int(total_batch)
         self.opts = opts if opts is not None else default_opts()
-        self.N = int(self.opts.N)
         ids = np.ascontiguousarray(device_ids, dtype=np.int32)
         h = C.c_void_p()
-        _check(self._L.cfnmpc_multi_create(C.byref(h), len(ids), ids.ctypes.data_as(C.c_void_p), self.B, C.byref(self.opts)),
-               "cfnmpc_multi_create")
+        self.mixed = horizons is not None
+        if self.mixed:
+            self.horizons = np.ascontiguousarray(horizons, dtype=np.int32)
+            assert self.horizons.shape == (self.B,)
+            self.N = int(self.horizons.max())       # row stride of yref / boxes
+            _check(self._L.cfnmpc_multi_create_horizons(C.byref(h), len(ids), ids.ctypes.data_as(C.c_void_p), self.B,
+                                                        self.horizons.ctypes.data_as(C.c_void_p), C.byref(self.opts)),
+                   "cfnmpc_multi_create_horizons")
+        else:
+            self.N = int(self.opts.N)
+            _check(self._L.cfnmpc_multi_create(C.byref(h), len(ids), ids.ctypes.data_as(C.c_void_p), self.B, C.byref(self.opts)),
+                   "cfnmpc_multi_create")
         self._h = h
 
     def close(self):
@@ -82,9 +94,17 @@ class MultiGpuFleet:
             pass
 
     def shards(self):
-        """-> [(lo, hi, device)]"""
+        """-> [(lo, hi, device)]; mixed horizons: [(vehicle indices, device)]"""
         C = self._C
         out = []
+        if self.mixed:
+            for i in range(self._L.cfnmpc_multi_num_shards(self._h)):
+                cnt, dev = C.c_int(0), C.c_int(0)
+                self._check(self._L.cfnmpc_multi_shard_fleet(self._h, i, None, C.byref(cnt), None, C.byref(dev), None), "cfnmpc_multi_shard_fleet")
+                idx = np.empty(cnt.value, dtype=np.int32)
+                self._check(self._L.cfnmpc_multi_shard_fleet(self._h, i, None, None, idx.ctypes.data_as(C.c_void_p), None, None), "cfnmpc_multi_shard_fleet")
+                out.append((idx, dev.value))
+            return out
         for i in range(self._L.cfnmpc_multi_num_shards(self._h)):
             lo, hi, dev = C.c_int(0), C.c_int(0), C.c_int(0)
             self._check(self._L.cfnmpc_multi_shard(self._h, i, None, C.byref(lo), C.byref(hi), C.byref(dev), None), "cfnmpc_multi_shard")

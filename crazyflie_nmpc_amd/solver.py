@@ -31,7 +31,7 @@ def _check(rc, what):
 
 def default_opts(**kw) -> Opts:
     o = Opts()
-    _lib.lib().cfnmpc_default_opts(C.byref(o))
+    _check(_lib.lib().cfnmpc_default_opts_v(C.byref(o), C.sizeof(o)), "cfnmpc_default_opts_v")
     for k, v in kw.items():
         if k in ("W", "WN"):
             arr = getattr(o, k)

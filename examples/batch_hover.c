@@ -32,7 +32,10 @@ int main(int argc, char **argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 1024;
     const int steps = argc > 2 ? atoi(argv[2]) : 40;
     cfnmpc_opts o;
-    cfnmpc_default_opts(&o); /* the generator's constants: N = 50, dt = 15 ms, W, box 0..22 kRPM */
+    if (CFNMPC_DEFAULT_OPTS(&o) != CFNMPC_OK) { /* the generator's constants: N = 50, dt = 15 ms, W, box 0..22 kRPM */
+        fprintf(stderr, "libcfnmpc.so was built for another cfnmpc_opts (ABI %d, this header: %d)\n", cfnmpc_abi_version(), CFNMPC_ABI_VERSION);
+        return 1;
+    }
     const int N = o.N;
     const double hov = 15.777730167256925; /* sqrt(mq g0 / (4 Ct)), generate_c_code.py:59 */
     const double target[3] = {0.0, 0.0, 0.4};

@@ -51,9 +51,20 @@ extern "C" {
 
 typedef struct cfnmpc_solver cfnmpc_solver;
 
+/* ABI guard.  cfnmpc_opts has grown with every round; a caller built against an older header (or a hand-written binding
+ * that stops short of the last field) must be refused instead of being written past:
+ *   - CFNMPC_ABI_VERSION changes whenever cfnmpc_opts or a signature below changes; cfnmpc_abi_version() returns the
+ *     LIBRARY's value, cfnmpc_opts_size() its sizeof(cfnmpc_opts);
+ *   - cfnmpc_default_opts_v(opts, sizeof *opts) fills `opts` only if the caller's size is the library's (CFNMPC_EINVAL
+ *     otherwise, nothing written) -- what C callers and bindings should use; CFNMPC_DEFAULT_OPTS(&o) spells it;
+ *   - every cfnmpc_opts starts with its own size (set by cfnmpc_default_opts*), and cfnmpc_create / cfnmpc_fleet_create /
+ *     cfnmpc_multi_create* refuse (CFNMPC_EINVAL) an object whose struct_size is not the library's. */
+#define CFNMPC_ABI_VERSION 5
+
 /* Replaces the constants baked into the generated solver by
  * crazyflie_controller/scripts/crazyflie_full_model/generate_c_code.py:41-146. */
 typedef struct cfnmpc_opts {
+    int struct_size;     /* sizeof(cfnmpc_opts) as the filler saw it (ABI guard above); do not change             */
     int N;               /* horizon length, generate_c_code.py:42 (50); 5 <= N <= 4096 (FP64 Riccati: with an
                             iterate far from the reference over the whole horizon the costate grows with N and
                             the stationarity residual with it -- 1e-12 at N = 50, 2e-10 at 200, 3.5e-7 at 4096) */
@@ -97,7 +108,8 @@ typedef struct cfnmpc_opts {
                             as the directional derivative of the RK4 map: fewest bytes, B / 64 wavefronts);
                             2 = on the stored (A, B, b), four instances per wavefront (16 x more wavefronts, a
                             shorter dependent chain per stage: faster while the fleet is too small to fill the
-                            GPU); 0 (default) = by batch size (2 below 8192 instances: measured cross-over).  Same results to
+                            GPU); 0 (default) = by fleet size in waves per SIMD (2 below 8 S instances, S = the device's
+                            SIMD count, 1024 on MI355X: measured cross-over, profiles/r04_thresholds.md).  Same results to
                             rounding.                                                                        */
     int cond_N2;         /* QP: partial condensing (PARTIAL_CONDENSING_HPIPM, generate_c_code.py:140; acados'
                             qp_solver_cond_N, which the generator leaves at its default): 0 or N (default 0) =
@@ -131,8 +143,8 @@ typedef struct cfnmpc_opts {
                             over the instances that have not settled yet (work lists re-binned by remaining sweep
                             length between the launches, two wavefronts per SIMD), one launch for the remaining
                             12 - p solves, then the commit kernel;
-                            0 (default): -3 up to 32 768 instances (+1 .. 2.5 % there), -1 beyond -- measured on
-                            MI355X, DESIGN.md section 5.5: the phase is bound by the bytes of the home blocks and by
+                            0 (default): -3 below 36 S instances (20 S for N <= 40; S = the device's SIMD count, 1024 on MI355X),
+                            -1 beyond -- measured on MI355X, profiles/r04_thresholds.md, DESIGN.md section 5.5: the phase is bound by the bytes of the home blocks and by
                             the hardest instance's chain of solves, not by occupancy, and -2 / p > 0 are slower at
                             every fleet size; kept as options.  Same solves in every mode; results agree to rounding. */
     double ipm_clip_viol; /* QP, interior point: CLIPPED START when the unconstrained minimiser leaves the box by more than
@@ -171,7 +183,11 @@ typedef struct cfnmpc_opts {
                             to rounding (tests/test_gpu_linfactor.py). */
 } cfnmpc_opts;
 
-void cfnmpc_default_opts(cfnmpc_opts *opts);
+void cfnmpc_default_opts(cfnmpc_opts *opts);   /* unchecked: the caller's struct MUST be this header's */
+int cfnmpc_default_opts_v(cfnmpc_opts *opts, int sizeof_opts);
+int cfnmpc_opts_size(void);
+int cfnmpc_abi_version(void);
+#define CFNMPC_DEFAULT_OPTS(o) cfnmpc_default_opts_v((o), (int)sizeof(cfnmpc_opts))
 
 /* acados_create() / acados_free() equivalents (acados_mpc.cpp:225,418) for B instances on the
  * calling thread's current HIP device. */
@@ -348,6 +364,19 @@ int cfnmpc_fleet_get_stats(cfnmpc_fleet *f, int *status, int *qp_iter, double *r
 typedef struct cfnmpc_multi cfnmpc_multi;
 int cfnmpc_multi_create(cfnmpc_multi **out, int n_shards, const int *device_ids /*[n_shards]*/, int total_batch,
                         const cfnmpc_opts *opts);
+/* Mixed horizons across GPUs (BASELINE.json config C5 "8 x MI355X, divergent-length stress"; SURVEY.md section 8e: "first
+ * bucket by N, then balance buckets across GPUs by sum N_i"): one horizon PER VEHICLE; the vehicles are dealt out over the
+ * shards by cfnmpc_shard_by_horizon, every shard is a cfnmpc_fleet (one solver per horizon bucket) over its -- NOT
+ * contiguous -- index set.  Host arrays cover the whole fleet in the caller's order with the fleet layouts (yref
+ * [B][Nmax][17], boxes [B][Nmax][4], get_u: stage < min N).  cfnmpc_multi_shard does not apply (CFNMPC_EINVAL); use
+ * cfnmpc_multi_shard_fleet: the shard's fleet, its vehicle count and their indices [count] in the caller's order. */
+int cfnmpc_multi_create_horizons(cfnmpc_multi **out, int n_shards, const int *device_ids /*[n_shards]*/, int total_batch,
+                                 const int *N_per_instance /*[total_batch]*/, const cfnmpc_opts *opts);
+int cfnmpc_multi_shard_fleet(const cfnmpc_multi *m, int shard, cfnmpc_fleet **fleet, int *count, int *index, int *device, void **stream);
+/* The partitioner itself (pure host code, no device needed; also what bench.py's ranks use for `--workload mixed`):
+ * vehicles in order of decreasing horizon, each to the shard with the smallest sum N so far (ties: lowest shard).
+ * shard_of [batch] receives the shard of every vehicle; sum N of any two shards differs by at most one vehicle's horizon. */
+int cfnmpc_shard_by_horizon(int batch, const int *N_per_instance, int n_shards, int *shard_of);
 int cfnmpc_multi_free(cfnmpc_multi *m);
 int cfnmpc_multi_batch(const cfnmpc_multi *m);
 int cfnmpc_multi_num_shards(const cfnmpc_multi *m);

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"^[ \t]*#.*$", "", src, flags=re.M)      # preprocessor lines (function-like macros are not exported symbols)
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", src)
     return sorted(set(n for n in names if not n.isupper()))
 
@@ -84,9 +85,72 @@ def test_exported_debug_entry_points_are_the_documented_ones():
     assert exported, "no debug accessors found (nm output changed?)"
     for name in exported:
         assert name in header, name
-        assert name in integ or name.replace("cfnmpc_debug_get_", "cfnmpc_debug_get_") in integ, name
+        assert name in integ, name
         assert name not in dev, name
     for name in re.findall(r"\b(cfnmpc_debug_\w+)\s*\(", dev):
         assert name not in exported, name
     # and the library reads no environment variable
     assert "getenv" not in subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+
+
+def _header_opts_fields():
+    """[(name, ctype, array length or 0)] parsed out of `typedef struct cfnmpc_opts { ... }` in include/cfnmpc.h"""
+    src = open(os.path.join(ROOT, "include", "cfnmpc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef struct cfnmpc_opts \{(.*?)\} cfnmpc_opts;", src, flags=re.S).group(1)
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (CFNMPC_\w+) (\d+)", src)}
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ctype, rest = decl.split(None, 1)
+        for item in rest.split(","):
+            m = re.fullmatch(r"\s*(\w+)\s*(?:\[(\w+)\])?\s*", item)
+            out.append((m.group(1), ctype, consts.get(m.group(2), 0) if m.group(2) else 0))
+    return out
+
+
+def test_opts_struct_header_binding_and_documented_stub_agree():
+    """cfnmpc_opts grows with the engine: the header, the ctypes binding (_lib.Opts) and the stub printed in INTEGRATION.md
+    section 3.3 must list the same fields in the same order with the same types, and the library must report that size."""
+    from crazyflie_nmpc_amd import _lib
+    hdr = _header_opts_fields()
+    kinds = {"int": ctypes.c_int, "double": ctypes.c_double}
+    want = [(n, kinds[t] * ln if ln else kinds[t]) for n, t, ln in hdr]
+    have = list(_lib.Opts._fields_)
+    assert [n for n, _ in want] == [n for n, _ in have]
+    for (n, tw), (_n, th) in zip(want, have):
+        assert ctypes.sizeof(tw) == ctypes.sizeof(th) and (tw is th or getattr(tw, "_length_", 0) == getattr(th, "_length_", 0)), n
+    assert hdr[0][0] == "struct_size"
+    L = _lib.lib()
+    assert L.cfnmpc_opts_size() == ctypes.sizeof(_lib.Opts)
+    abi = int(re.search(r"#define CFNMPC_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "cfnmpc.h")).read()).group(1))
+    assert L.cfnmpc_abi_version() == abi == _lib.ABI_VERSION
+    # the documented stub: same names, same order, same types
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blk = doc[doc.index("class Opts(C.Structure)"):]
+    blk = blk[:blk.index("]\n") + 1]
+    doc_fields = re.findall(r'\("(\w+)", C\.c_(int|double)(?:\*(\d+))?\)', blk)
+    assert [(n, t, int(ln or 0)) for n, t, ln in doc_fields] == hdr
+    assert f"cfnmpc_abi_version() == {abi}" in doc
+
+
+def test_abi_guard_refuses_foreign_opts_structs():
+    """A caller whose cfnmpc_opts is not the library's gets CFNMPC_EINVAL and nothing is written into its object."""
+    from crazyflie_nmpc_amd import _lib
+    L = _lib.lib()
+    buf = (ctypes.c_ubyte * 1024)(*([0xAB] * 1024))
+    short = ctypes.sizeof(_lib.Opts) - 40          # the size round 4's documented stub had
+    assert L.cfnmpc_default_opts_v(ctypes.cast(buf, ctypes.POINTER(_lib.Opts)), short) == -1
+    assert bytes(buf) == b"\xab" * 1024
+    o = _lib.Opts()
+    assert L.cfnmpc_default_opts_v(ctypes.byref(o), ctypes.sizeof(o)) == 0 and o.struct_size == ctypes.sizeof(o) and o.N == 50
+    # create refuses a struct whose leading size is foreign BEFORE it looks for a device (EINVAL, not EHIP)
+    o.struct_size = short
+    h = ctypes.c_void_p()
+    assert L.cfnmpc_create(ctypes.byref(h), 4, ctypes.byref(o)) == -1 and not h.value
+    hz = (ctypes.c_int * 4)(30, 50, 50, 100)
+    assert L.cfnmpc_fleet_create(ctypes.byref(h), 4, hz, ctypes.byref(o)) == -1
+    ids = (ctypes.c_int * 2)(0, 0)
+    assert L.cfnmpc_multi_create(ctypes.byref(h), 2, ids, 4, ctypes.byref(o)) in (-1, -2)

@@ -615,6 +615,71 @@ def test_multi_gpu_fleet_shards_match_single_solver(oracle):
         assert (m2.stats()[0] == 0).all()
 
 
+def test_multi_gpu_mixed_horizon_fleet_matches_single_fleet(oracle):
+    """cfnmpc_multi_create_horizons (config C5 across GPUs from one process): one horizon per vehicle, the vehicles dealt out
+    over the shards by the library's partitioner (= parallel.shard_by_horizon), every shard a cfnmpc_fleet over a
+    NON-contiguous index set.  Per vehicle the results equal ONE MixedHorizonFleet over the whole fleet bitwise (full-horizon
+    sweeps: a vehicle's arithmetic does not depend on its neighbours), through every host-array call of the boundary."""
+    import torch
+    from crazyflie_nmpc_amd import default_opts, parallel, sim
+    from crazyflie_nmpc_amd.fleet import MixedHorizonFleet
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B = 523
+    rng = np.random.default_rng(77)
+    hz = rng.choice([30, 50, 100], size=B)
+    x = oracle.sample_hover_x0(rng, B, scale=1.4)
+    tgt = np.concatenate([rng.uniform(-0.3, 0.3, (B, 2)), rng.uniform(0.3, 0.6, (B, 1))], axis=1)
+    m = parallel.MultiGpuFleet(B, [0, 0, 0], default_opts(active_horizon=0), horizons=hz)
+    f = MixedHorizonFleet(hz, active_horizon=0)
+    sh = m.shards()
+    want = parallel.shard_by_horizon(hz, 3)
+    assert len(sh) == 3 and all(np.array_equal(ix, w) for (ix, _d), w in zip(sh, want))
+    loads = [int(hz[ix].sum()) for ix, _ in sh]
+    assert max(loads) - min(loads) <= 100
+    f.set_regulation(tgt, HOV)
+    rows = np.stack([np.concatenate([tgt[i], [1, 0, 0, 0, 0, 0, 0, 0, 0, 0], [HOV] * 4]) for i in range(B)])
+    m.set_yref(np.repeat(rows[:, None, :], 100, 1).copy(), rows[:, :13].copy())
+    for o in (m, f):
+        o.set_x0(x); o.init_iterate(INIT_HOVER)
+    seen = 0
+    for t in range(3):
+        m.set_x0(x); f.set_x0(x)
+        m.solve(1); f.solve(1)
+        m.sync()
+        st, it, rs = m.stats(); st1, it1, rs1 = f.stats()
+        assert (st == 0).all() and np.array_equal(it, it1) and np.array_equal(rs, rs1)
+        seen += int((it > 0).sum())
+        assert np.array_equal(m.get_u(0), f.get_u(0)) and np.array_equal(m.get_u(29), f.get_u(29))
+        assert np.array_equal(m.get_x(4), f.get_x(4)) and np.array_equal(m.get_x(30), f.get_x(30))
+        c, mv = m.get_cmd(); c1, mv1 = f.get_cmd()
+        assert np.array_equal(c, c1) and np.array_equal(mv, mv1)
+        x = sim(x, m.get_u(0), T=0.015, steps=1)
+    assert seen > 0
+    with pytest.raises(Exception):
+        m.get_u(30)                      # stage >= the shortest horizon
+    lb = np.zeros((B, 100, 4)); ub = np.full((B, 100, 4), 22.0)
+    lb[:, 0] = ub[:, 0] = rng.uniform(13.0, 18.0, (B, 4))
+    for step in (0, 1, 2):
+        for o in (m, f):
+            if step == 0:
+                o.set_box(1.0, 19.0)
+            elif step == 1:
+                o.set_box_stages(lb, ub)
+            else:
+                o.set_box_stages(None, None)
+            o.set_x0(x); o.solve(1)
+        m.sync()
+        assert np.array_equal(m.get_u(0), f.get_u(0)) and np.array_equal(m.stats()[1], f.stats()[1])
+        if step == 1:
+            assert np.abs(m.get_u(0) - lb[:, 0]).max() < 1e-12
+    m.close(); f.close()
+    if torch.cuda.device_count() > 1:
+        m2 = parallel.MultiGpuFleet(B, [0, 1], default_opts(), horizons=hz)
+        m2.set_yref(np.repeat(rows[:, None, :], 100, 1).copy(), rows[:, :13].copy())
+        m2.set_x0(x); m2.init_iterate(INIT_HOVER); m2.solve(1); m2.sync()
+        assert (m2.stats()[0] == 0).all()
+
+
 def test_fleet_output_stage_and_box(oracle, cref):
     """cfnmpc_fleet_get_cmd / cfnmpc_fleet_set_box: a mixed-horizon fleet's output stage equals the
     host mirror on the fleet's own u0 / u1 / x4 (host and device pointers), and a narrower input box
