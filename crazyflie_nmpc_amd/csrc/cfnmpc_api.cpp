@@ -52,6 +52,7 @@ struct cfnmpc_solver {
     int parity;                  // which of the two argument sets the NEXT step uses
     int reinit_failed;           // cfnmpc_opts.reinit_failed
     double *lbs_keep, *ubs_keep; // per-stage boxes (cfnmpc_set_box_stages), allocated at the first call
+    double* box_blk[4];          // ... the four blocks behind them (home lb / ub, compact lb / ub); a failed attempt keeps what it got
 };
 
 namespace {
@@ -258,6 +259,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     s->gvalid[0] = s->gvalid[1] = false;
     s->parity = 0;
     s->lbs_keep = s->ubs_keep = nullptr;
+    for (double*& q : s->box_blk) q = nullptr;
     s->reinit_failed = o.reinit_failed ? 1 : 0;
     int simds = 1024;   // SIMDs of the device the solver is created on
     {
@@ -486,23 +488,29 @@ int cfnmpc_set_box_stages(cfnmpc_solver* s, const double* lb, const double* ub, 
         // allocated and initialised as a whole before any pointer is committed: a failure half-way (ENOMEM, a failed copy)
         // leaves the solver on the scalar box with nothing dangling (the blocks stay owned by s->allocs until cfnmpc_free)
         const size_t cnt = ((size_t)P.NW + 1) * 4 * P.N * 4;
-        double *lk = nullptr, *uk = nullptr, *cl = nullptr, *cu = nullptr;
-        int rc = dev_alloc(s, &lk, cnt);
-        if (rc == CFNMPC_OK) rc = dev_alloc(s, &uk, cnt);
-        if (rc == CFNMPC_OK) rc = dev_alloc(s, &cl, cnt);
-        if (rc == CFNMPC_OK) rc = dev_alloc(s, &cu, cnt);
+        // (blocks a failed earlier attempt did get are kept in s->box_blk and reused: a retry allocates only what is missing)
+        int rc = CFNMPC_OK;
+        for (int q = 0; q < 4 && rc == CFNMPC_OK; q++)
+            if (!s->box_blk[q]) rc = dev_alloc(s, &s->box_blk[q], cnt);
         if (rc != CFNMPC_OK) return rc;
+        double *lk = s->box_blk[0], *uk = s->box_blk[1], *cl = s->box_blk[2], *cu = s->box_blk[3];
         // rows of the spare block (parked rows of compacted waves): a wide finite box
         std::vector<double> lo(4 * (size_t)P.N * 4, -1e30), hi(4 * (size_t)P.N * 4, 1e30);
         HIP_TRY(hipMemcpy(lk + (size_t)P.NW * 4 * P.N * 4, lo.data(), lo.size() * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(uk + (size_t)P.NW * 4 * P.N * 4, hi.data(), hi.size() * 8, hipMemcpyHostToDevice));
         s->lbs_keep = lk; s->ubs_keep = uk; P.clbs = cl; P.cubs = cu;
     }
-    // the caller's AoS order [inst][stage][4] -> the layout of the home 4-vectors (Params.v4b)
+    // the caller's AoS order [inst][stage][4] -> the layout of the home 4-vectors (Params.v4b).  Both arrays are STAGED first
+    // (in the compact box buffers: scratch of the QP kernels, rewritten by every solve that uses them) and the home pair is
+    // overwritten only after both puts succeeded -- a failure leaves the previous lb AND ub in force, never a mixed box.
     hipStream_t st = (hipStream_t)stream;
-    int rcp = put_field(s, lb, on_device, P.N, 4, 0, s->lbs_keep, st);
-    if (rcp == CFNMPC_OK) rcp = put_field(s, ub, on_device, P.N, 4, 0, s->ubs_keep, st);
+    int rcp = put_field(s, lb, on_device, P.N, 4, 0, P.clbs, st);
+    if (rcp == CFNMPC_OK) rcp = put_field(s, ub, on_device, P.N, 4, 0, P.cubs, st);
     if (rcp != CFNMPC_OK) return rcp;
+    const size_t bytes = (size_t)P.NW * 4 * P.N * 4 * sizeof(double);   // (the spare block behind it keeps its wide box)
+    HIP_TRY(hipMemcpyAsync(s->lbs_keep, P.clbs, bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->ubs_keep, P.cubs, bytes, hipMemcpyDeviceToDevice, st));
+    if (on_device == CFNMPC_ON_HOST) HIP_TRY(hipStreamSynchronize(st));   // synchronous form: complete when the call returns
     P.lbs = s->lbs_keep; P.ubs = s->ubs_keep;
     invalidate_graphs(s);
     return CFNMPC_OK;
@@ -895,13 +903,16 @@ int cfnmpc_debug_checksum(cfnmpc_solver* s, double* out3) {
 // `reps` repetitions timed with HIP events on `stream` (*ms = average per repetition; may be NULL).
 int cfnmpc_debug_start_factor(cfnmpc_solver* s, int mode, int reps, double* ms, void* stream) {
     if (!s || (mode != 1 && mode != 2) || reps < 1) return CFNMPC_EINVAL;
+    // k_factor / k_linfactor address the home 4-vectors in the wave-blocked layout (Params.v4b): a partial-condensing solver
+    // keeps them instance-major and never runs these kernels -- refuse instead of reading and writing in the wrong layout
+    if (s->P.cond_N2 || !s->P.v4b) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, st));
-    for (int r = 0; r < reps; r++) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess) return CFNMPC_EHIP;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return CFNMPC_EHIP; }
+    bool ok = hipEventRecord(e0, st) == hipSuccess;
+    for (int r = 0; ok && r < reps; r++) {
         if (mode == 1) {
             cfn::launch_linearise(s->P, s->chunks_all, st);
             cfn::launch_factor_only(s->P, st);
@@ -909,13 +920,12 @@ int cfnmpc_debug_start_factor(cfnmpc_solver* s, int mode, int reps, double* ms, 
             cfn::launch_linfactor(s->P, st);
         }
     }
-    HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;
-    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
-    if (ms) *ms = (double)t / reps;
+    ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t, e0, e1) == hipSuccess;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (!ok) return CFNMPC_EHIP;
+    if (ms) *ms = (double)t / reps;
     HIP_TRY(hipGetLastError());
     s->lin_valid = mode == 1;
     return CFNMPC_OK;
@@ -925,7 +935,7 @@ int cfnmpc_debug_start_factor(cfnmpc_solver* s, int mode, int reps, double* ms, 
 // pointers, any may be NULL): gains K [B][N][4][13], feed-forward d [B][N][4], cost-to-go checkpoints Pchk [B][6][13][13]
 // (stages 4, 8, 12, 16, 24, 32; only those below N are written by the kernels), status [B].
 int cfnmpc_debug_get_factor(cfnmpc_solver* s, double* K, double* d, double* Pchk, int* status) {
-    if (!s) return CFNMPC_EINVAL;
+    if (!s || s->P.cond_N2 || !s->P.v4b) return CFNMPC_EINVAL;   // (as cfnmpc_debug_start_factor)
     DeviceGuard dg(s);
     const cfn::Params& P = s->P;
     const size_t NW = P.NW, N = P.N, B = P.B;
@@ -953,6 +963,7 @@ int cfnmpc_debug_get_factor(cfnmpc_solver* s, double* K, double* d, double* Pchk
         HIP_TRY(hipMemcpy(h.data(), P.Pchk, h.size() * 8, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < B; i++)
             for (int c = 0; c < cfn::N_CHK; c++) {
+                if (cfn::chk_stage(c) >= (int)N) continue;   // no kernel fills a checkpoint at or behind the horizon's end: the caller's block stays untouched
                 const double* pb = h.data() + ((i / 4) * cfn::N_CHK + c) * cfn::SZ_PP;
                 for (int j = 0; j < 13; j++)
                     for (int r = 0; r < 13; r++)

@@ -38,6 +38,7 @@
 //   k_sim / k_estimate : RK4 plant step / predictor (acados_estimator.cpp:573-593).
 //   k_put / k_get / k_init_iterate / k_windows : layout glue and reference windows for the C-ABI.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 
 #include "cfnmpc_rg.hpp"
 
@@ -119,6 +120,9 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     const int per = (kb - ka + gridDim.y - 1) / gridDim.y;
     const int k0 = ka + blockIdx.y * per, k1 = imin(kb, k0 + per);
     if (k0 >= k1) return;
+    // CSTORE: list slots of this group that own a row (the lanes behind the list's end linearise the spare instance; their
+    // results must not land in real compact slots -- for which = 1 those belong to rows of the FIRST list)
+    const int n_live = CSTORE ? gm(P.nipm)[which ? 40 : 0] - (int)blockIdx.x * 64 : 64;
 
     // address of element (local instance li, lane i) of a field with `stages` stages per block, SZ
     // doubles per (block, stage), NS lanes per instance starting at `pre4` inside the block.
@@ -207,7 +211,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         SFOR(r, 0, NS, {                                                                                \
             const int e = tl + 64 * r;                                                                  \
             const int li = CFN_DIV(e, NS), i = e - li * (NS);                                          \
-            *el(field, li, i, N, k, SZ, pre4, NS, false) = tv[r];                                       \
+            if (!CSTORE || li < n_live) *el(field, li, i, N, k, SZ, pre4, NS, false) = tv[r];            \
         });                                                                                             \
     }
         CFN_STORE(CSTORE ? P.cbv : P.b, SZ_V13, 0, 13, 0);
@@ -2789,6 +2793,9 @@ void launch_factor_chunk(const Params& P, hipStream_t st) {
 }
 #endif
 void launch_factor_only(const Params& P, hipStream_t st) {
+    // the start-solve kernels index the home 4-vectors in the wave-blocked layout unconditionally (cfnmpc_rg.hpp: load_stage,
+    // factor_stage); solvers without it (partial condensing) have no path that leads here -- refuse rather than corrupt
+    if (!P.v4b) { std::fprintf(stderr, "cfnmpc: k_factor needs the wave-blocked 4-vector layout (not a cond_N2 solver)\n"); return; }
     hipLaunchKernelGGL(k_factor, dim3(P.NW), dim3(64), 0, st, P);
 }
 void launch_cforward(const Params& P, hipStream_t st) {

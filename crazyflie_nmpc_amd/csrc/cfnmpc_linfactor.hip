@@ -22,6 +22,7 @@
 // Readers of (A, B) behind the start solve (only the constrained instances' QP kernels on the default path) get them from
 // k_linearise_clist, which re-linearises those instances straight into their compact store (cfnmpc_kernels.hip).
 #include <hip/hip_runtime.h>
+#include <cstdio>
 
 #include "cfnmpc_rg.hpp"
 
@@ -193,6 +194,7 @@ KALIGN __global__ __launch_bounds__(64, 2) void k_linfactor(Params P) {
 }
 
 void launch_linfactor(const Params& P, hipStream_t st) {
+    if (!P.v4b) { std::fprintf(stderr, "cfnmpc: k_linfactor needs the wave-blocked 4-vector layout (not a cond_N2 solver)\n"); return; }
     hipLaunchKernelGGL(k_linfactor, dim3(P.NW), dim3(64), 0, st, P);
 }
 

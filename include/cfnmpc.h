@@ -226,7 +226,10 @@ int cfnmpc_set_box(cfnmpc_solver *s, double u_min, double u_max);
 /* Per-stage, per-input box: lb, ub [B][N][4] (what "lbu" / "ubu" on INDIVIDUAL stages set in acados -- the reference's
  * FIXED_U0 variant pins stage 0 to the input in flight, lbu = ubu = u1, acados_mpc.cpp:605-608).  lb[i] = ub[i] makes
  * that input an equality (the active-set solves keep it fixed whatever its multiplier's sign; the interior-point
- * fall-back needs lb < ub).  NULL, NULL returns to the scalar box of cfnmpc_set_box.  Steps with per-stage boxes run
+ * fall-back needs lb < ub).  HOST arrays are validated (lb <= ub everywhere, no NaN: CFNMPC_EINVAL, nothing changed); DEVICE
+ * arrays are taken as they are -- the caller guarantees lb <= ub (an inverted box ends in status 4 for that vehicle).  The
+ * call is atomic: on any failure the previous boxes (both arrays) stay in force.  NULL, NULL returns to the scalar box of
+ * cfnmpc_set_box.  Steps with per-stage boxes run
  * the row-group forward sweep and the monolithic QP kernels (instantiated for them); not with cond_N2. */
 int cfnmpc_set_box_stages(cfnmpc_solver *s, const double *lb, const double *ub, int on_device, void *stream);
 

@@ -184,3 +184,28 @@ def test_condensed_randomised_horizons_blocks_and_options(oracle, cref, seed):
         assert np.abs(ug - ur)[ok].max() < 5e-6 and np.abs(xg - xr)[ok].max() < 5e-6, (seed, Nh, N2, B)
         xr[:] = xg; ur[:] = ug
         x = xg[:, 1, :].copy()
+
+
+def test_start_solve_accessors_refuse_condensed_solvers():
+    """cfnmpc_debug_start_factor / _get_factor run kernels that index the home 4-vectors in the wave-blocked layout; a
+    partial-condensing solver keeps them instance-major and must be refused (CFNMPC_EINVAL), not silently mis-addressed.
+    On a short horizon the accessor leaves the checkpoints no kernel fills (stage >= N) untouched."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts
+    from crazyflie_nmpc_amd.solver import CfnmpcError, INIT_HOVER
+    from crazyflie_nmpc_amd.synthetic import regulation_row, sample_hover_x0
+    s = BatchSolver(9, default_opts(cond_N2=10))
+    with pytest.raises(CfnmpcError):
+        s.start_factor(1)
+    with pytest.raises(CfnmpcError):
+        s.get_factor()
+    s.close()
+    B, N = 9, 20
+    s = BatchSolver(B, default_opts(N=N))
+    row = regulation_row()
+    s.set_yref(np.tile(row, (B, N, 1)), np.tile(row[:13], (B, 1)))
+    s.set_x0(sample_hover_x0(np.random.default_rng(3), B)); s.init_iterate(INIT_HOVER)
+    s.start_factor(1)
+    K, d, Pc, st = s.get_factor()          # Pc starts as zeros in the wrapper
+    assert (st == 0).all() and np.isfinite(K).all()
+    assert np.abs(Pc[:, :4]).max() > 0 and not Pc[:, 4:].any()     # checkpoints at stages 4, 8, 12, 16 | 24, 32 >= N
+    s.close()
