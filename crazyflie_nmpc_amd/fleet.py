@@ -57,6 +57,21 @@ class MixedHorizonFleet:
             out.append((n.value, idx))
         return out
 
+    def bucket_iterates(self):
+        """-> [(N, fleet indices, x [count][N+1][13], u [count][N][4])] per bucket: the persistent iterates (nlp_out of
+        acados_mpc.cpp:77) through the buckets' own solvers (cfnmpc_fleet_bucket + cfnmpc_get_iterate), host arrays"""
+        out = []
+        for b in range(self._L.cfnmpc_fleet_num_buckets(self._h)):
+            n, c, sv = C.c_int(0), C.c_int(0), C.c_void_p()
+            _check(self._L.cfnmpc_fleet_bucket(self._h, b, C.byref(n), C.byref(c), C.byref(sv), None), "cfnmpc_fleet_bucket")
+            idx = np.empty(c.value, dtype=np.int32)
+            _check(self._L.cfnmpc_fleet_bucket(self._h, b, None, None, None, idx.ctypes.data_as(C.c_void_p)), "cfnmpc_fleet_bucket")
+            x = np.empty((c.value, n.value + 1, NX)); u = np.empty((c.value, n.value, NU))
+            _check(self._L.cfnmpc_get_iterate(sv, x.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), 0,
+                                              _launch_stream(None, self._device)), "cfnmpc_get_iterate")
+            out.append((n.value, idx, x, u))
+        return out
+
     def set_regulation(self, xyz, uss):
         """xyz [B][3]: Regulation reference of every vehicle (acados_mpc.cpp:435-454)."""
         rows = np.stack([regulation_row(xyz[i], uss) for i in range(self.B)])
