@@ -417,6 +417,7 @@ def main():
     ap.add_argument("--forward-sweep", type=int, default=None, help="cfnmpc_opts.forward_sweep (0 auto, 1 matrix-free, 2 row groups)")
     ap.add_argument("--as-passes", type=int, default=None, help="cfnmpc_opts.as_passes (scheduling of the active-set solves: 0 auto, -1 monolithic, "
                                                                 "-3 solves + commit kernel, -2 / 1..12 instance-contiguous store / level-synchronous passes)")
+    ap.add_argument("--as-warm", type=int, default=None, help="cfnmpc_opts.as_warm (warm start of the active set from the previous RTI step)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (default); gloo only for functional checks of the N > 1 path on "
                          "a box with fewer GPUs than ranks (ranks then share devices)")
@@ -478,7 +479,7 @@ def main():
     opt_kw = dict(active_horizon=args.active_horizon, active_set=args.active_set)
     for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2),
                  ("step_graph", args.step_graph), ("forward_sweep", args.forward_sweep), ("as_passes", args.as_passes),
-                 ("start_solve", args.start_solve)):
+                 ("start_solve", args.start_solve), ("as_warm", args.as_warm)):
         if v is not None:
             opt_kw[k] = v
 

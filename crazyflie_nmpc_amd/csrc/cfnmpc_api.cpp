@@ -204,6 +204,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->as_skip_viol = 4.0;
     o->reinit_failed = 0;
     o->start_solve = 0;
+    o->as_warm = 0;
 }
 
 int cfnmpc_default_opts_v(cfnmpc_opts* o, int sizeof_opts) {
@@ -313,6 +314,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.ah_margin = o.ah_margin;
     P.ah_extra = o.ah_extra;
     P.active_set = o.active_set ? 1 : 0;
+    P.as_warm = (o.as_warm && o.active_set) ? 1 : 0;
     if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise) ||
         (o.reinit_failed && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
     // (an explicitly fused start solve stores no stage blocks: the automatic choice then stays with the matrix-free sweep)
@@ -377,6 +379,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * 32); ALLOC(rank, NW * 4); ALLOC(done, NW * 4);
     ALLOC(ascnt, 32); ALLOC(askst, NW * 4); ALLOC(asst, NW * 4); ALLOC(asok, NW * 4);
     ALLOC(czdx, NW * 4 * (N + 1) * 13);
+    if (P.as_warm) { ALLOC(wcls, NW * 4 * N * 4); ALLOC(wvalid, NW * 4); }
     if (P.as_passes != 0) ALLOC(aslist, (size_t)3 * 7 * NW * 4);
     if (cond_N2) ALLOC(cb, NW * 4 * (size_t)cond_N2 * cfn::cb_size(cfn::cond_mmax(P)));
     if (s->overlap) {
@@ -543,6 +546,7 @@ int cfnmpc_init_iterate(cfnmpc_solver* s, int mode, void* stream) {
     DeviceGuard dg(s);
     cfn::launch_init_iterate(s->P, mode, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    if (s->P.as_warm) HIP_TRY(hipMemsetAsync(s->P.wvalid, 0, sizeof(int) * (size_t)s->P.B, (hipStream_t)stream));   // a new iterate: no set to start from
     s->lin_valid = false;
     return CFNMPC_OK;
 }
@@ -551,6 +555,7 @@ int cfnmpc_set_iterate(cfnmpc_solver* s, const double* x, const double* u, int o
     if (!s || !x || !u) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
     s->lin_valid = false;
+    if (s->P.as_warm) HIP_TRY(hipMemsetAsync(s->P.wvalid, 0, sizeof(int) * (size_t)s->P.B, (hipStream_t)stream));
     int rc = put_field(s, x, on_device, s->P.N + 1, 13, 1, s->P.xit, (hipStream_t)stream);
     if (rc != CFNMPC_OK) return rc;
     return put_field(s, u, on_device, s->P.N, 4, 0, s->P.uit, (hipStream_t)stream);

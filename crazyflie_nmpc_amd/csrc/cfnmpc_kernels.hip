@@ -966,6 +966,7 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         gm(P.iters)[inst] = 0;
         gm(P.res)[inst] = bad ? nan("") : 0.0;
         gm(P.head)[inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
+        if (P.as_warm && !infeasible) gm(P.wvalid)[inst] = 0;   // an unconstrained step ends the instance's run of constrained ones
     }
     {   // first half of the stable compaction: per-group bin counts and ranks.  Bin = head class
         // (largest first) x difficulty (number of violated inputs of the unconstrained minimiser:
@@ -1103,6 +1104,7 @@ __device__ __forceinline__ void forward_rg_body(const Params& P) {
         gm(P.iters)[t.inst] = 0;
         gm(P.res)[t.inst] = bad ? nan("") : 0.0;
         gm(P.head)[t.inst] = head;
+        if (P.as_warm && !infeasible) gm(P.wvalid)[t.inst] = 0;
         // compaction bin (head class x difficulty), ranked per 64-instance group by k_rank
         gm(P.rank)[t.inst] = infeasible ? head_cls(P, head) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
     }
@@ -1448,20 +1450,28 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         bool as_done = false;
         int as_iters = 0;
         if (MODE != 2 && P.active_set) {
-            // initial classification from the unconstrained minimiser
+            // initial classification from the unconstrained minimiser; WARM (cfnmpc_opts.as_warm): a row whose previous RTI step
+            // ended in a settled active-set solve starts from the union of that solve's final set and today's violations (the
+            // reference never shifts its iterate, acados_mpc.cpp:581-611, so the classes are taken stage for stage).  Any start
+            // ends in the same place: a stationary classification is the exact solution.
+            const bool warm = P.as_warm && t.valid && gm(P.wvalid)[t.inst] != 0;
+            const gbyte* wc = gm(P.wcls) + (size_t)(warm ? t.inst : 0) * N * 4;
             for (int e0 = t.L; e0 < head * 4; e0 += 64) {
                 double uk[4], vv[4], blo[4], bhi[4];
+                int wprev[4];
                 SFOR(j, 0, 4, {
                     const size_t idx = cbase + imin(e0 + 16 * j, head * 4 - 1);
                     uk[j] = gm(Q.uit)[idx];
                     vv[j] = gm(Q.v)[idx];
                     box_at<SBOX>(Q, idx, blo[j], bhi[j]);
+                    wprev[j] = warm ? (int)wc[imin(e0 + 16 * j, head * 4 - 1)] : 0;
                 });
                 SFOR(j, 0, 4, {
                     const int e = e0 + 16 * j;
                     if (e < head * 4) {
                         const double lb = blo[j] - uk[j], ub = bhi[j] - uk[j];
                         double cls = vv[j] < lb ? 1.0 : (vv[j] > ub ? 2.0 : 0.0);
+                        if (cls == 0.0 && wprev[j] != 0) cls = (double)wprev[j];
                         if (SBOX && !(blo[j] < bhi[j])) cls = 1.0;   // lb = ub: fixed from the start
                         gm(Q.tu)[cbase + e] = cls;
                         gm(Q.tl)[cbase + e] = cls == 1.0 ? lb - vv[j] : (cls == 2.0 ? ub - vv[j] : 0.0);
@@ -1485,6 +1495,17 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 const bool fine = row_min(as_ok ? 1.0 : 0.0) > 0.0;
                 if (try_as && !as_done && !changed && fine) { as_done = true; as_iters = it; }
                 if (!__any(try_as && !as_done && fine)) break;
+            }
+            if (P.as_warm && t.valid) {   // what the next RTI step of this row may start from
+                if (as_done) {
+                    gbyte* wo = gm(P.wcls) + (size_t)t.inst * N * 4;
+                    for (int e0 = t.L; e0 < N * 4; e0 += 64) {
+                        double cl[4];
+                        SFOR(j, 0, 4, { cl[j] = gm(Q.tu)[cbase + imin(e0 + 16 * j, head * 4 - 1)]; });
+                        SFOR(j, 0, 4, { const int e = e0 + 16 * j; if (e < N * 4) wo[e] = e < head * 4 ? (unsigned char)(int)cl[j] : (unsigned char)0; });
+                    }
+                }
+                if (t.L == 0) gm(P.wvalid)[t.inst] = as_done ? 1 : 0;
             }
             if (NO_ROLL) {   // hand over to the commit kernel: settled flag, solve count, the head the solves covered
                 if (t.L == 0 && t.valid) {

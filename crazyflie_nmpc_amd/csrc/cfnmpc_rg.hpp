@@ -106,6 +106,8 @@ typedef __attribute__((address_space(1))) int gint;
 __device__ __forceinline__ gdouble* gm(double* p) { return (gdouble*)(unsigned long long)p; }
 __device__ __forceinline__ const gdouble* gm(const double* p) { return (const gdouble*)(unsigned long long)p; }
 __device__ __forceinline__ gint* gm(int* p) { return (gint*)(unsigned long long)p; }
+typedef __attribute__((address_space(1))) unsigned char gbyte;
+__device__ __forceinline__ gbyte* gm(unsigned char* p) { return (gbyte*)(unsigned long long)p; }
 // (wave, stage) block of a field
 __device__ __forceinline__ gdouble* blk(double* f, const Lane& t, int nst, int k, int sz) {
     return gm(f) + ((size_t)t.wave * nst + k) * sz;

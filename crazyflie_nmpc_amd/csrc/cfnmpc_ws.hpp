@@ -97,6 +97,12 @@ struct Params {
     double *cGR, *cS, *crho;
     double *cPs;     // AS_PSAVE x SZ_PA per compact block: cost-to-go (with affine row) of the stages 1..31
     int active_set;  // 1: try the primal-dual active-set solve before the interior-point iteration
+    // warm start of the active set (cfnmpc_opts.as_warm): per instance the classification its last SETTLED active-set solve ended
+    // with (wcls [inst][N * 4] bytes: 0 free, 1 lower, 2 upper; 0 behind that solve's head) and whether the instance's previous RTI
+    // step ended that way (wvalid [inst]: the forward sweep clears it for feasible instances, the QP kernels set / clear it)
+    int as_warm;
+    unsigned char* wcls;
+    int* wvalid;
     int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
     double *res, *viol;          // per instance
     int ipm_listed;              // 1: k_ipm_rest works on ilist2 (fleets whose fall-back rows may exceed one wave per SIMD); 0: on ilist, filtered

@@ -59,7 +59,7 @@ typedef struct cfnmpc_solver cfnmpc_solver;
  *     otherwise, nothing written) -- what C callers and bindings should use; CFNMPC_DEFAULT_OPTS(&o) spells it;
  *   - every cfnmpc_opts starts with its own size (set by cfnmpc_default_opts*), and cfnmpc_create / cfnmpc_fleet_create /
  *     cfnmpc_multi_create* refuse (CFNMPC_EINVAL) an object whose struct_size is not the library's. */
-#define CFNMPC_ABI_VERSION 5
+#define CFNMPC_ABI_VERSION 6
 
 /* Replaces the constants baked into the generated solver by
  * crazyflie_controller/scripts/crazyflie_full_model/generate_c_code.py:41-146. */
@@ -181,6 +181,16 @@ typedef struct cfnmpc_opts {
                             automatic choices to the matrix-free forward sweep and the monolithic active-set kernel, and a solver
                             that is given per-stage boxes later runs the stored-block kernels while they are set.  Same results
                             to rounding (tests/test_gpu_linfactor.py). */
+    int as_warm;         /* QP, active_set = 1: 1 = WARM START of the active set.  An instance whose previous RTI step ended in a
+                            settled active-set solve starts its first solve from the union of that solve's final set and the
+                            violations of today's unconstrained minimiser, instead of the violations alone (consecutive steps of
+                            a constrained vehicle share most of their active set, and the reference never shifts its iterate --
+                            acados_mpc.cpp:581-611 -- so the classes are taken stage for stage).  Exactness is untouched: whatever
+                            the start, the iteration ends in a stationary classification, i.e. the KKT point of the strictly
+                            convex QP; only the number of solves changes.  The state (4 N bytes + a flag per instance) is cleared by
+                            cfnmpc_init_iterate / cfnmpc_set_iterate.  Read by the monolithic and the solves + commit kernels
+                            (as_passes 0 / -1 / -3); the level-synchronous variants ignore it.  Default 0: see DESIGN.md section 5.5
+                            for the measured solve histograms. */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);   /* unchecked: the caller's struct MUST be this header's */

@@ -599,14 +599,16 @@ def riccati_ipm(qp: StageQP, **opts):
     return dict(dx=xs, du=v, lam_l=ll, lam_u=lu, **info)
 
 
-def pdas_dense(qp: StageQP, max_solves=12):
+def pdas_dense(qp: StageQP, max_solves=12, warm_cls=None):
     """Primal-dual active-set solve of the condensed QP (dense algebra) -- the CPU statement of the
     engine's `active_set` path (include/cfnmpc.h): classify every input from
     the unconstrained minimiser (below / above its bound = active, else free), solve the QP with
     the active inputs fixed, re-classify (a free input that leaves the box becomes active; a lower-
     active one stays while its multiplier H v + h > 0, an upper-active one while it is < 0), stop
     when the classification is stationary -- which is the KKT system of the strictly convex QP.
-    Returns dict(dx, du, solves, converged); solves = 0 if the unconstrained minimiser is feasible."""
+    Returns dict(dx, du, solves, converged, cls); solves = 0 if the unconstrained minimiser is feasible.
+    warm_cls (N, 4) of 0 free / 1 lower / 2 upper (cfnmpc_opts.as_warm): the final classification of the instance's previous
+    RTI step; the first solve then starts from its union with today's violations.  cls = the final classification."""
     H, h, Gam, g = condense(qp)
     n = H.shape[0]
     lb = qp.lb.reshape(-1)
@@ -616,6 +618,10 @@ def pdas_dense(qp: StageQP, max_solves=12):
     eq = ~(lb < ub)                      # lb = ub (per-stage boxes, cfnmpc_set_box_stages): an equality, fixed whatever
     lo, up = (v0 < lb) | eq, (v0 > ub) & ~eq   # the sign of its multiplier
     solves, converged = 0, True
+    if (lo.any() or up.any()) and warm_cls is not None:
+        w = np.asarray(warm_cls).reshape(-1)
+        inside = ~(lo | up)
+        lo, up = lo | (inside & (w == 1)), up | (inside & (w == 2))
     if lo.any() or up.any():
         converged = False
         while solves < max_solves:
@@ -633,7 +639,8 @@ def pdas_dense(qp: StageQP, max_solves=12):
                 break
             lo, up = lo2, up2
     dx = (Gam @ v + g).reshape(qp.N + 1, NX)
-    return dict(dx=dx, du=v.reshape(qp.N, NU), solves=solves, converged=converged)
+    cls = np.where(lo, 1, np.where(up, 2, 0)).astype(np.uint8).reshape(qp.N, NU)
+    return dict(dx=dx, du=v.reshape(qp.N, NU), solves=solves, converged=converged, cls=cls)
 
 
 def _steplen(tl, tu, ll, lu, dtl, dtu, dll, dlu):

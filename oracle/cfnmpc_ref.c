@@ -54,6 +54,8 @@ typedef struct {
     double clip_margin; /* ... clipped to this fraction of the box width inside the bounds       */
     double as_skip_viol; /* active_set: beyond this many box widths the active-set solves are skipped
                          (cfnmpc_opts.as_skip_viol; 0: never)                                    */
+    int as_warm;      /* active_set: warm start of the classification from the instance's previous RTI step
+                         (cfnmpc_opts.as_warm; needs the per-instance state of cfo_rti_step_w)     */
 } cfo_opts;
 
 void cfo_default_opts(cfo_opts *o) {
@@ -75,6 +77,7 @@ void cfo_default_opts(cfo_opts *o) {
     o->clip_viol = 2.0;
     o->clip_margin = 0.05;
     o->as_skip_viol = 4.0;
+    o->as_warm = 0;
 }
 
 /* ---------------------------------------------------------------- dynamics */
@@ -223,6 +226,10 @@ typedef struct {
     double *K, *Sinv, *d;              /* [N][52] [N][16] [N][4] */
     double *v, *tl, *tu, *ll, *lu, *rg; /* [N][4] each */
     double *dva, *dvc, *x;              /* [N][4] [N][4] [(N+1)][13] */
+    /* warm start of the active set (cfo_opts.as_warm): this instance's state, or NULL -- the classes its last SETTLED
+     * active-set solve ended with ([N][4]: 0 free, 1 lower, 2 upper) and whether its previous RTI step ended that way */
+    unsigned char *wcls;
+    int *wvalid;
 } qp_t;
 
 static size_t qp_doubles(int N) {
@@ -231,6 +238,8 @@ static size_t qp_doubles(int N) {
 
 static void qp_carve(qp_t *qp, int N, double *m) {
     qp->N = N;
+    qp->wcls = NULL;
+    qp->wvalid = NULL;
     qp->A = m; m += (size_t)N * 169;
     qp->B = m; m += (size_t)N * 52;
     qp->b = m; m += (size_t)N * 13;
@@ -414,8 +423,12 @@ static int as_solve(qp_t *qp) {
     double *g = Rhat + n, *c = g + n, *beff = c + n, *dx = beff + (size_t)N * NX;
     int *cls = (int *)malloc(sizeof(int) * n);
     int solves = 0, done = 0;
+    /* WARM: the union of the previous step's final set and today's violations (the engine's qp_wave does the same; any
+     * start ends in a stationary classification = the exact solution, only the number of solves differs) */
+    const int warm = qp->wvalid && *qp->wvalid;
     for (int i = 0; i < n; i++) {
         cls[i] = v0[i] < qp->lb[i] ? 1 : (v0[i] > qp->ub[i] ? 2 : 0);
+        if (warm && cls[i] == 0 && qp->wcls[i]) cls[i] = qp->wcls[i];
         c[i] = cls[i] == 1 ? qp->lb[i] - v0[i] : (cls[i] == 2 ? qp->ub[i] - v0[i] : 0.0);
         g[i] = 0.0;
     }
@@ -482,6 +495,10 @@ static int as_solve(qp_t *qp) {
         }
     }
     if (done) for (int i = 0; i < n; i++) v0[i] += du[i];
+    if (qp->wvalid) {
+        if (done) for (int i = 0; i < n; i++) qp->wcls[i] = (unsigned char)cls[i];
+        *qp->wvalid = done;
+    }
     free(cls);
     free(Rhat);
     return done ? solves : 0;
@@ -511,8 +528,9 @@ static int ipm_solve(qp_t *qp, const cfo_opts *o, int *iters_out, double *res_ou
         if (qp->lb[i] - v[i] > viol) viol = qp->lb[i] - v[i];
         if (v[i] - qp->ub[i] > viol) viol = v[i] - qp->ub[i];
     }
-    if (feas) { free(Rhat); *res_out = 0.0; return 0; }
-    if (!(viol == viol)) { free(Rhat); *res_out = NAN; return 4; }
+    if (feas) { if (qp->wvalid) *qp->wvalid = 0; free(Rhat); *res_out = 0.0; return 0; }
+    if (!(viol == viol)) { if (qp->wvalid) *qp->wvalid = 0; free(Rhat); *res_out = NAN; return 4; }
+    if (qp->wvalid && !(o->active_set && !(o->as_skip_viol > 0.0 && viol > o->as_skip_viol * (o->u_max - o->u_min)))) *qp->wvalid = 0;
     if (o->active_set && !(o->as_skip_viol > 0.0 && viol > o->as_skip_viol * (o->u_max - o->u_min))) {
         const int solves = as_solve(qp);
         if (solves > 0) {
@@ -685,9 +703,19 @@ static void linearise(qp_t *qp, const cfo_opts *o, const double *xit, const doub
  *   x0 [B][13], yref [B][N][17], yref_e [B][13]
  *   status [B] (0 ok, 2 maxiter, 4 QP failure), iters [B], res [B] (QP max-norm residual)
  *   nthreads <= 0 -> all OpenMP threads.  Returns number of threads used. */
+int cfo_rti_step_w(const cfo_opts *o, int B, double *x_it, double *u_it, const double *x0,
+                   const double *yref, const double *yref_e, int *status, int *iters, double *res,
+                   int nthreads, unsigned char *wcls, int *wvalid);
 int cfo_rti_step(const cfo_opts *o, int B, double *x_it, double *u_it, const double *x0,
                  const double *yref, const double *yref_e, int *status, int *iters, double *res,
                  int nthreads) {
+    return cfo_rti_step_w(o, B, x_it, u_it, x0, yref, yref_e, status, iters, res, nthreads, NULL, NULL);
+}
+/* ... with the persistent warm-start state of the active set: wcls [B][N][4] bytes, wvalid [B] (both zero-initialised by
+ * the caller before the first step; used when o->as_warm, may be NULL otherwise) */
+int cfo_rti_step_w(const cfo_opts *o, int B, double *x_it, double *u_it, const double *x0,
+                   const double *yref, const double *yref_e, int *status, int *iters, double *res,
+                   int nthreads, unsigned char *wcls, int *wvalid) {
     const int N = o->N;
     int used = 1;
 #ifdef _OPENMP
@@ -707,6 +735,9 @@ int cfo_rti_step(const cfo_opts *o, int B, double *x_it, double *u_it, const dou
             linearise(&qp, o, xi, ui, x0 + (size_t)n * NX, yref + (size_t)n * N * NY, yref_e + (size_t)n * NX);
             int it = 0;
             double rs = 0;
+            const int use_w = o->as_warm && wcls && wvalid;
+            qp.wcls = use_w ? wcls + (size_t)n * N * NU : NULL;
+            qp.wvalid = use_w ? wvalid + n : NULL;
             const int st = ipm_solve(&qp, o, &it, &rs);
             for (int i = 0; i < (N + 1) * NX; i++) xi[i] += qp.x[i];
             for (int i = 0; i < N * NU; i++) ui[i] += qp.v[i];
@@ -798,11 +829,15 @@ int cfo_closed_loop(const cfo_opts *o, int B, double *x, const double *yref, con
         qp_t qp;
         qp_carve(&qp, N, mem);
         double *xi = mem + qp_doubles(N), *ui = xi + (size_t)(N + 1) * NX;
+        unsigned char *wc = (unsigned char *)calloc((size_t)N * NU, 1);
+        int wv = 0;
+        if (o->as_warm) { qp.wcls = wc; qp.wvalid = &wv; }
 #ifdef _OPENMP
 #pragma omp for schedule(static)
 #endif
         for (int n = 0; n < B; n++) {
             double *xp = x + (size_t)n * NX;
+            wv = 0;
             for (int k = 0; k <= N; k++) memcpy(xi + (size_t)k * NX, xp, sizeof(double) * NX);
             for (int i = 0; i < N * NU; i++) ui[i] = hov;
             for (int t = 0; t < steps; t++) {
@@ -821,6 +856,7 @@ int cfo_closed_loop(const cfo_opts *o, int B, double *x, const double *yref, con
                 memcpy(xp, xn, sizeof xn);
             }
         }
+        free(wc);
         free(mem);
     }
     *seconds = now_s() - t_begin;

@@ -20,7 +20,7 @@ class Opts(C.Structure):
                 ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
                 ("lam0_min", C.c_double), ("mu0_scale", C.c_double), ("active_set", C.c_int),
-                ("clip_viol", C.c_double), ("clip_margin", C.c_double), ("as_skip_viol", C.c_double)]
+                ("clip_viol", C.c_double), ("clip_margin", C.c_double), ("as_skip_viol", C.c_double), ("as_warm", C.c_int)]
 
 
 def _host_tag():
@@ -75,6 +75,7 @@ def lib():
         build()   # (no-op when the library is current AND was built on this host)
         _lib = C.CDLL(_SO)
         _lib.cfo_rti_step.restype = C.c_int
+        _lib.cfo_rti_step_w.restype = C.c_int
         _lib.cfo_closed_loop.restype = C.c_int
         _lib.cfo_qp_solve.restype = C.c_int
     return _lib
@@ -126,12 +127,24 @@ def sim(x, u, T=0.06, steps=4):
     return xn
 
 
-def rti_step(opts, x_it, u_it, x0, yref, yref_e, nthreads=1):
-    """In-place RTI step on C-contiguous float64 arrays.  Returns (status, iters, res, threads)."""
+def warm_state(B, N):
+    """(wcls [B][N][4] uint8, wvalid [B] int32), zeroed: the persistent state of cfo_opts.as_warm for rti_step(warm=...)"""
+    return np.zeros((B, N, NU), dtype=np.uint8), np.zeros(B, dtype=np.int32)
+
+
+def rti_step(opts, x_it, u_it, x0, yref, yref_e, nthreads=1, warm=None):
+    """In-place RTI step on C-contiguous float64 arrays.  Returns (status, iters, res, threads).
+    warm = warm_state(B, N), kept by the caller from step to step (used when opts.as_warm)."""
     B = x0.shape[0]
     for a in (x_it, u_it, x0, yref, yref_e):
         assert a.dtype == np.float64 and a.flags.c_contiguous
     status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32); res = np.empty(B)
+    if warm is not None:
+        wc, wv = warm
+        assert wc.dtype == np.uint8 and wc.shape == (B, opts.N, NU) and wv.dtype == np.int32 and wv.shape == (B,)
+        used = lib().cfo_rti_step_w(C.byref(opts), C.c_int(B), _p(x_it), _p(u_it), _p(x0), _p(yref), _p(yref_e),
+                                    _p(status), _p(iters), _p(res), C.c_int(nthreads), _p(wc), _p(wv))
+        return status, iters, res, used
     used = lib().cfo_rti_step(C.byref(opts), C.c_int(B), _p(x_it), _p(u_it), _p(x0), _p(yref), _p(yref_e),
                               _p(status), _p(iters), _p(res), C.c_int(nthreads))
     return status, iters, res, used

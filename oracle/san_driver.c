@@ -10,18 +10,25 @@ typedef struct {
     double tau, thr0, lam0_min, mu0_scale;
     int active_set;
     double clip_viol, clip_margin, as_skip_viol;
+    int as_warm;
 } cfo_opts;
 void cfo_default_opts(cfo_opts *o);
 int cfo_rti_step(const cfo_opts *o, int B, double *x_it, double *u_it, const double *x0, const double *yref,
                  const double *yref_e, int *status, int *iters, double *res, int nthreads);
+int cfo_rti_step_w(const cfo_opts *o, int B, double *x_it, double *u_it, const double *x0, const double *yref,
+                   const double *yref_e, int *status, int *iters, double *res, int nthreads, unsigned char *wcls, int *wvalid);
 void cfo_sim(int B, const double *x, const double *u, double T, int steps, double *xn);
 
-static int run(int active_set) {
+static int run(int active_set, int as_warm) {
     enum { B = 6, NX = 13, NU = 4, NY = 17 };
     cfo_opts o;
     cfo_default_opts(&o);
     o.active_set = active_set;
+    o.as_warm = as_warm;
     const int N = o.N;
+    unsigned char *wcls = calloc((size_t)B * N * NU, 1);
+    int wvalid[B];
+    memset(wvalid, 0, sizeof wvalid);
     double *xit = malloc(sizeof(double) * B * (N + 1) * NX), *uit = malloc(sizeof(double) * B * N * NU);
     double *yref = malloc(sizeof(double) * B * N * NY), yref_e[B * NX], x0[B * NX], xn[B * NX], u0[B * NU], res[B];
     int status[B], iters[B];
@@ -46,7 +53,8 @@ static int run(int active_set) {
     }
     int constrained = 0;
     for (int t = 0; t < 5; t++) {
-        cfo_rti_step(&o, B, xit, uit, x0, yref, yref_e, status, iters, res, 2);
+        if (as_warm) cfo_rti_step_w(&o, B, xit, uit, x0, yref, yref_e, status, iters, res, 2, wcls, wvalid);
+        else cfo_rti_step(&o, B, xit, uit, x0, yref, yref_e, status, iters, res, 2);
         for (int i = 0; i < B; i++) {
             if (status[i] != 0) { fprintf(stderr, "status %d\n", status[i]); return 2; }
             constrained += iters[i] > 0;
@@ -55,12 +63,12 @@ static int run(int active_set) {
         cfo_sim(B, x0, u0, 0.015, 1, xn);
         memcpy(x0, xn, sizeof xn);
     }
-    printf("sanitizer run ok (active_set = %d), %d constrained solves\n", active_set, constrained);
-    free(xit); free(uit); free(yref);
+    printf("sanitizer run ok (active_set = %d, as_warm = %d), %d constrained solves\n", active_set, as_warm, constrained);
+    free(xit); free(uit); free(yref); free(wcls);
     return constrained > 0 ? 0 : 3;
 }
 
 int main(void) {
-    const int a = run(0), b = run(1);   /* interior point, active-set solves */
-    return a ? a : b;
+    const int a = run(0, 0), b = run(1, 0), c = run(1, 1);   /* interior point, active-set solves, ... warm-started */
+    return a ? a : (b ? b : c);
 }

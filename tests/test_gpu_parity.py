@@ -242,3 +242,53 @@ def test_active_set_under_heavy_saturation(oracle, cref, scale, init):
         x = sim(x, s.get_u(0), T=0.015, steps=1)
         ur[:] = ug; xr[:] = xg
     assert n_con > B // 2
+
+
+@pytest.mark.parametrize("active_horizon", [0, 1])
+def test_warm_started_active_set_matches_restatement(oracle, cref, active_horizon):
+    """cfnmpc_opts.as_warm: 20 closed-loop steps with 2x kicks (most vehicles constrained for several consecutive steps), the
+    engine and the C restatement both starting each first solve from the union of the previous step's final set and today's
+    violations.  Full-horizon sweeps: the solve counts agree vehicle by vehicle and step by step (the two implementations
+    walk through the same classifications); active-horizon sweeps: same solutions.  And the warm-started engine reaches the
+    iterates of the cold-started one (exactness does not depend on the start)."""
+    from crazyflie_nmpc_amd import BatchSolver, sim, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 192, 50
+    rng = np.random.default_rng(99)
+    x = oracle.sample_hover_x0(rng, B, scale=2.0)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    opts = cref.default_opts(active_set=1, as_warm=1)
+    warm = cref.warm_state(B, N)
+    xr = np.repeat(x[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    s = BatchSolver(B, default_opts(active_horizon=active_horizon, as_warm=1))
+    c = BatchSolver(B, default_opts(active_horizon=active_horizon))
+    for q in (s, c):
+        q.set_x0(x); q.set_yref(yref, yref_e); q.init_iterate(INIT_HOVER)
+    kicks = oracle.sample_hover_x0(rng, 10 * 20, scale=2.0).reshape(20, 10, 13)
+    warm_rows = n_constrained = 0
+    for t in range(20):
+        x[(t % 20) * 10 % B:(t % 20) * 10 % B + 10] = kicks[t]
+        s.set_x0(x); s.solve(1)
+        xc, uc = s.get_iterate()          # the cold engine and the restatement continue from the warm engine's iterate
+        c.set_x0(x); c.solve(1)
+        st, it, _ = s.stats(); st_c, it_c, _ = c.stats()
+        warm_rows += int((warm[1] != 0).sum())
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0, warm=warm)
+        xg, ug = s.get_iterate()
+        xk, uk = c.get_iterate()
+        ok = (st == 0) & (st_r == 0) & (st_c == 0)
+        assert ok.mean() > 0.97 and np.array_equal(st, st_r)
+        assert np.array_equal(it > 0, it_r > 0) and np.array_equal(it > 0, it_c > 0)
+        as_rows = ok & (it <= 12) & (it_r <= 12) & (it_c <= 12)       # settled by active-set solves on every side
+        if active_horizon == 0:
+            assert np.array_equal(it[as_rows], it_r[as_rows]), (t, it[as_rows], it_r[as_rows])
+        assert np.abs(ug[as_rows] - ur[as_rows]).max() < 1e-7 and np.abs(xg[as_rows] - xr[as_rows]).max() < 1e-7, t
+        assert np.abs(ug[as_rows] - uk[as_rows]).max() < 1e-7, t      # warm and cold engines: the same solution
+        assert np.abs(ug[ok] - ur[ok]).max() < 5e-4
+        n_constrained += int((it > 0).sum())
+        ur[:] = ug; xr[:] = xg
+        c.set_iterate(xg, ug)
+        x = sim(x, s.get_u(0), T=0.015, steps=1)
+    assert n_constrained > 1000 and warm_rows > 500      # the warm start was exercised on most constrained QPs
+    s.close(); c.close()
