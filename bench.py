@@ -418,6 +418,7 @@ def main():
     ap.add_argument("--as-passes", type=int, default=None, help="cfnmpc_opts.as_passes (scheduling of the active-set solves: 0 auto, -1 monolithic, "
                                                                 "-3 solves + commit kernel, -2 / 1..12 instance-contiguous store / level-synchronous passes)")
     ap.add_argument("--as-warm", type=int, default=None, help="cfnmpc_opts.as_warm (warm start of the active set from the previous RTI step)")
+    ap.add_argument("--as-dense", type=int, default=None, help="cfnmpc_opts.as_dense (head-condensed dense active-set solves: 1 on, -1 off, 0 auto)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (default); gloo only for functional checks of the N > 1 path on "
                          "a box with fewer GPUs than ranks (ranks then share devices)")
@@ -479,7 +480,7 @@ def main():
     opt_kw = dict(active_horizon=args.active_horizon, active_set=args.active_set)
     for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2),
                  ("step_graph", args.step_graph), ("forward_sweep", args.forward_sweep), ("as_passes", args.as_passes),
-                 ("start_solve", args.start_solve), ("as_warm", args.as_warm)):
+                 ("start_solve", args.start_solve), ("as_warm", args.as_warm), ("as_dense", args.as_dense)):
         if v is not None:
             opt_kw[k] = v
 

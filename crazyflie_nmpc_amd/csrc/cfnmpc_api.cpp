@@ -92,13 +92,14 @@ constexpr size_t EV_PER_STEP = 7;
 //     waves than there are SIMDs by a margin (roll-out = latency chain); re-measured after the 4-vector layout change:
 //     N = 50: -3.5 % at 24 S, -0.5 % at 32 S, equal at 48 S; N = 100: -3.6 % up to 32 S, equal at 48 S; N = 30: +4.7 % from 24 S on;
 //   * fall-back rows compacted before the interior point: from 16 S instances.
-struct Choice { bool forward_rg, as_commit, ipm_listed; };
+struct Choice { bool forward_rg, as_commit, ipm_listed, as_dense; };
 inline Choice choose_kernels(int batch, int N, int simds) {
     const long S = simds > 0 ? simds : 1024;
     Choice c;
     c.forward_rg = (long)batch < (N <= 64 ? 8 : 6) * S;
     c.as_commit = (long)batch < (N <= 40 ? 20 : 36) * S;
     c.ipm_listed = (long)batch >= 16 * S;
+    c.as_dense = true;
     return c;
 }
 
@@ -205,6 +206,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->reinit_failed = 0;
     o->start_solve = 0;
     o->as_warm = 0;
+    o->as_dense = 0;
 }
 
 int cfnmpc_default_opts_v(cfnmpc_opts* o, int sizeof_opts) {
@@ -340,6 +342,11 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     // 2.5 % fall back at three times the bench's disturbances): only large fleets pay the compaction's extra launch
     P.as_sparse_max = P.as_grid / 2;   // = the SIMDs of the device: one constrained row per wave while they all fit at once
     P.ipm_listed = pick.ipm_listed ? 1 : 0;
+    // head-condensed dense active-set solves (cfnmpc_asdense.hip) beside the solves + commit structure; scalar box, stored blocks
+    if (o.as_dense < -1 || o.as_dense > 1) { delete s; return CFNMPC_EINVAL; }
+    if (o.as_dense == 1 && (P.as_passes != -2 && o.as_passes != 0)) { delete s; return CFNMPC_EINVAL; }
+    if (o.as_dense == 1 && o.as_passes == 0 && o.start_solve != 2 && !cond_N2) P.as_passes = -2;   // asked for: the structure it lives in
+    P.as_dense = (P.as_passes == -2 && P.active_set && !P.as_warm && o.as_dense != -1 && (o.as_dense == 1 || pick.as_dense)) ? 1 : 0;
     // start solve: the fused kernel replaces k_linearise + k_factor where nothing but the constrained instances' QP kernels
     // reads the stage blocks afterwards (matrix-free forward sweep, monolithic active-set kernel, no partial condensing,
     // no overlapped preparation); per-stage boxes (cfnmpc_set_box_stages) switch a solver back at launch time

@@ -1,0 +1,342 @@
+// cfnmpc_asdense.hip -- active-set solves of the constrained instances on the HEAD-CONDENSED dense QP (gfx950, FP64).
+//
+// Where it sits (cfnmpc_kernels.hip, launch_qp_ipm): the constrained rows of an RTI step are solved on a head of 4 .. 32 or all
+// N stages (active horizon: the unconstrained tail keeps the start solve's feedback law and enters through its cost-to-go
+// checkpoint P_head).  The Riccati form of a primal-dual active-set solve (qp_wave: one factorisation + one forward sweep over
+// the head per solve) is a chain of 2 x head dependent stages of ~1 - 1.6 us each; on the bench workload 99 % of the constrained
+// rows have heads of 8 - 16 stages, i.e. 32 - 64 inputs, and need 1 - 5 solves: 30 - 220 us per row, which IS the duration of the
+// active-set kernel wherever rows are fewer than SIMDs, and 17 % of the step at 65 536 instances.  For heads of at most 16 stages
+// this kernel solves the SAME QP, by the SAME active-set iteration, in dense form -- the reference's own solver plan condenses
+// too (PARTIAL_CONDENSING_HPIPM, generate_c_code.py:140) --:
+//
+//   1. H = R + Gamma' Q Gamma of the head in delta form (dx_0 = 0, stage cost Q on dx_1 .. dx_{h-1}, P_head on dx_h), n = 4 h
+//      inputs, ONE COLUMN PER LANE: lane j = input (k_j, a_j) propagates x_{k+1} = A_k x_k (+ B_k[:, a_j] at k = k_j) forward and
+//      the adjoint lam_i = Q x_i + A_i' lam_{i+1}, H[(i, .), j] = B_i' lam_{i+1} (+ R at its own entry) backward -- 259 fused
+//      multiply-adds per stage and lane, the stage matrices being DPP broadcast sources (cfnmpc_dense_dpp.hpp) straight from the
+//      home blocks' row-distributed form.  The backward sweep needs the forward states: eight of them are kept in registers and
+//      heads of more than eight stages are done in two halves (the first half's states recomputed).
+//   2. G = H^-1 by n symmetric sweeps (Goodnight's sweep operator keeps the matrix symmetric, so the pivot row is the pivot
+//      COLUMN: one value per lane, exchanged through LDS once per sweep), every lane holding its row in registers.
+//   3. primal-dual active-set iteration on G: with the active inputs A fixed at c = bound - v0, delta = G[:, A] y and the
+//      multipliers of the fixed inputs are y itself, G_AA y = c_A -- a system of the size of the ACTIVE SET (a handful of
+//      inputs), solved by Gauss-Jordan elimination on the same exchange scheme.  Same classification rule, same sequence of
+//      sets and same solve counts as qp_wave and the CPU restatements of the test suite; a stationary set is the KKT point of
+//      the strictly convex QP.
+//   4. dx of the head by one forward sweep; du / dx / settled flag / solve count handed to k_ascommit exactly as k_as_solves
+//      does (roll-out, tail verification, retries and the interior-point fall-back are unchanged).
+//
+// One wavefront = one row; rows with longer heads stay with k_as_solves (the compaction lists them first: P.nipm[41] rows).
+// LDS: 32 KB (H, then G) + 3 KB per wavefront -> four per compute unit.  Scalar input box only.
+#include <hip/hip_runtime.h>
+
+#include "cfnmpc_rg.hpp"
+#include "cfnmpc_dense_dpp.hpp"
+
+namespace cfn {
+
+namespace {
+
+constexpr int DN = 64;   // columns of the dense store (a head of 16 stages)
+
+struct DenseLds {
+    double G[DN * DN];      // H during the build, then G = H^-1: element (r, j) at r * DN + j (lane j: conflict-free)
+    double ex[2][DN];       // pivot-column exchange (double buffered)
+    double rx[DN];          // right-hand sides of the small system / y
+    double cv[DN];          // c of the active inputs / delta
+    int idx[DN];            // the active inputs in lane order
+};
+
+struct StageOps { double ac[10], br[4]; };
+struct BuildVisit { int kind, stage, slot; };   // 0: forward, 1: forward with the new state kept in hist[slot], 2: backward
+template <bool TWO>
+__host__ __device__ constexpr BuildVisit build_visit(int v) {
+    if (TWO) {
+        if (v < 8) return {0, v, 0};
+        if (v < 16) return {1, v, v - 8};
+        if (v < 24) return {2, 15 - (v - 16), 0};
+        if (v < 32) return {1, v - 24, v - 24};
+        return {2, 7 - (v - 32), 0};
+    }
+    if (v < 8) return {1, v, v};
+    return {2, 7 - (v - 8), 0};
+}
+constexpr int AS_MAX_SOLVES_DENSE = 12;   // the iteration cap of qp_wave (AS_MAX_SOLVES)
+
+__device__ __forceinline__ void load_ops(const Params& P, const Lane& t, const int k, StageOps& o) {
+    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, o.ac);
+    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, o.br);
+}
+
+// ---- 1. H column of this lane -> S.G[(i * 4 + a) * DN + lane] ------------------------------------------------------------------
+// TWO: head > 8 (two halves).  All lanes run every stage (lockstep); a lane's state is zero up to its own stage.
+template <bool TWO>
+__device__ __forceinline__ void dense_build(const Params& P, const Lane& t, const int head, const int chk, DenseLds& S) {
+    const int lane = threadIdx.x;
+    const int kj = lane >> 2, aj = lane & 3;
+    const int N = P.N;
+    double Qi[13];
+    SFOR(j, 0, 13, { Qi[j] = P.W[ext_of(j)]; });
+    const double Rj = aj == 0 ? P.W[13] : (aj == 1 ? P.W[14] : (aj == 2 ? P.W[15] : P.W[16]));
+    // this lane's own column of B (injected at its stage)
+    double binj[13];
+    {
+        const gdouble* bb = blk(P.BR, t, N, imin(kj, head - 1), SZ_B) + (aj * 4 + t.q) * 13;
+        SFOR(i, 0, 13, { binj[i] = bb[i]; });
+    }
+    // cost-to-go at the head: checkpoint of the start solve (packed triangle), or the terminal weight (head = N); loaded one
+    // visit before it is used (thirteen registers that the forward half does not have to carry)
+    double pr[13];   // pr[c]@lane(r) = P_head[r][c]
+    auto load_pr = [&]() {
+        if (chk >= 0) {
+            const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + chk) * SZ_PP;
+            SFOR(c, 0, 13, {
+                const double v = pc[pchk_at(c, t.q, imin(t.L, 12))];
+                pr[c] = t.L < 13 ? v : 0.0;
+            });
+        } else {
+            SFOR(c, 0, 13, { pr[c] = (t.L == c) ? P.WN[ext_of(c)] : 0.0; });
+        }
+    };
+    auto fwd = [&](const int k, double (&x)[13], const StageOps& o) {
+        double xn[13];
+        SFOR(i, 0, 3, { xn[i] = x[i]; });
+        SFOR(i, 3, 13, { xn[i] = 0.0; });
+        dense_fwd(xn, x, o.ac);
+        const double inj = (k == kj) ? 1.0 : 0.0;
+        SFOR(i, 0, 13, { x[i] = __builtin_fma(inj, binj[i], xn[i]); });
+    };
+    auto bwd = [&](const int i, double (&lam)[13], const double (&xi)[13], const StageOps& o) {
+        double h[4] = {0.0, 0.0, 0.0, 0.0};
+        dense_bwd_h(h, lam, o.br);
+        SFOR(a, 0, 4, { S.G[(i * 4 + a) * DN + lane] = h[a] + ((i == kj && a == aj) ? Rj : 0.0); });
+        double ln[13];
+        SFOR(c, 0, 3, { ln[c] = __builtin_fma(Qi[c], xi[c], lam[c]); });
+        SFOR(c, 3, 13, { ln[c] = Qi[c] * xi[c]; });
+        dense_bwd_a(ln, lam, o.ac);
+        SFOR(c, 0, 13, { lam[c] = ln[c]; });
+    };
+    // kept states: a backward stage i reads x_i, i.e. the LAST state of each forward pass is never read back -- seven slots per
+    // pass, the eighth holds the hand-over state x_8 of the two-half build
+    double x[13], lam[13], hist[8][13], zero[13];
+    SFOR(i, 0, 13, { x[i] = 0.0; lam[i] = 0.0; zero[i] = 0.0; });
+    // The visits of the stage matrices, in order (compile-time list; the operands of visit v + 1 are in flight while visit v
+    // is computed: two stage buffers used alternately):
+    //   TWO : F 0..7 | F 8..15 (x_9 .. x_16 kept) | B 15..8 | F 0..7 (x_1 .. x_8 kept) | B 7..0
+    //   else: F 0..7 (kept) | B 7..0
+    // visits of stages >= head are skipped (their loads, clamped, are harmless)
+    constexpr int NV = TWO ? 40 : 16, FIRST_B = TWO ? 16 : 8;
+    StageOps o0, o1;
+    load_ops(P, t, 0, o0);
+    SFOR(v, 0, NV, {
+        StageOps& cur = (v & 1) ? o1 : o0;
+        StageOps& nxt = (v & 1) ? o0 : o1;
+        // (the visits are straight-line code: without a fence the compiler forms the addresses of all forty visits up front and
+        //  hoists their loads as far as it can -- 400 spilled registers; the opaque stage index pins each visit's loads to its place)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (v + 1 < NV) {
+            int kn = imin(build_visit<TWO>(v + 1).stage, head - 1);
+            asm volatile("" : "+s"(kn));
+            load_ops(P, t, kn, nxt);
+        }
+        constexpr BuildVisit vv = build_visit<TWO>(v);
+        if constexpr (v == FIRST_B - 1) load_pr();
+        if constexpr (v == FIRST_B) dense_px(lam, x, pr);            // lam_head = P_head x_head
+        if constexpr (TWO && v == 24) { SFOR(i, 0, 13, { x[i] = 0.0; }); }
+        if constexpr (vv.kind != 2) {
+            if (vv.stage < head) fwd(vv.stage, x, cur);
+            if constexpr (vv.kind == 1 && vv.slot < 7) { SFOR(i, 0, 13, { hist[vv.slot][i] = x[i]; }); }
+            if constexpr (TWO && v == 7) { SFOR(i, 0, 13, { hist[7][i] = x[i]; }); }
+        } else {
+            constexpr int i = vv.stage;
+            if (i < head) {
+                if constexpr (TWO && v < 24) {          // first half: x_8 from the hand-over copy, x_9 .. x_15 from the kept states
+                    if constexpr (i == 8) bwd(i, lam, hist[7], cur);
+                    else bwd(i, lam, hist[i - 9], cur);
+                } else {
+                    if constexpr (i == 0) bwd(i, lam, zero, cur);
+                    else bwd(i, lam, hist[i - 1], cur);
+                }
+            }
+        }
+    });
+}
+
+// one step of the pivot exchange: every lane publishes `mine`, gets the NB values of its DPP lane position and the pivot
+template <int NB>
+__device__ __forceinline__ void exchange(double* ex, const int lane, const int k, const double mine, double (&creg)[NB], double& d) {
+    ex[lane] = mine;
+    __syncthreads();
+    SFOR(tt, 0, NB, { creg[tt] = ex[(lane & 15) + 16 * tt]; });
+    d = ex[k];
+}
+
+// ---- 2. + 3.: G = H^-1 and the active-set iteration; NB = sixteens of inputs (n = 16 NB >= 4 head) ---------------------------
+// returns the number of solves (> 0: settled, delta in S.cv), 0: not settled / factorisation failed
+template <int NB>
+__device__ __forceinline__ int dense_solve(const Params& P, const Lane& t, const int head, DenseLds& S) {
+    constexpr int n = 16 * NB;
+    const int lane = threadIdx.x;
+    const int nr = 4 * head;                 // real inputs; lanes / columns behind them are padding (identity)
+    double w[n];
+    SFOR(c, 0, n, { w[c] = S.G[c * DN + lane]; });
+    SFOR(c, 0, n, { if (lane >= nr || c >= nr) w[c] = (lane == c) ? 1.0 : 0.0; });
+    bool ok = true;
+    // symmetric sweeps: after all of them w = -H^-1 (lane = row)
+    SFOR(k, 0, n, {
+        double creg[NB], d;
+        exchange<NB>(S.ex[k & 1], lane, k, w[k], creg, d);
+        ok = ok && (d > 0.0);
+        const double rinv = rcp_nr(d);
+        const double tk = (lane == k) ? (1.0 - rinv) : w[k] * rinv;   // lane k: its own row ends as row / d
+        const double negt = -tk;
+        SFOR(tt, 0, NB, { rank1bc16(&w[16 * tt], negt, creg[tt]); });
+        w[k] = (lane == k) ? -rinv : tk;
+    });
+    if (!__all(ok)) return 0;
+    __syncthreads();
+    SFOR(c, 0, n, { S.G[c * DN + lane] = -w[c]; });   // G, row `lane` (= column `lane`)
+    // element state of this lane's input
+    const int kj = lane >> 2, aj = lane & 3;
+    const bool real = lane < nr;
+    const size_t e = i4(P, t, imin(kj, head - 1), aj);
+    const double v0 = real ? gm(P.v)[e] : 0.0;
+    const double uk = real ? gm(P.uit)[e] : 0.0;
+    const double lb = real ? P.u_min - uk : -1e300, ub = real ? P.u_max - uk : 1e300;
+    int cls = v0 < lb ? 1 : (v0 > ub ? 2 : 0);
+    double c = cls == 1 ? lb - v0 : (cls == 2 ? ub - v0 : 0.0);
+    double delta = 0.0;
+    int solves = 0;
+    bool done = false;
+    for (int it = 1; it <= AS_MAX_SOLVES_DENSE && !done; it++) {
+        solves = it;
+        const bool act = cls != 0;
+        const unsigned long long mask = __ballot(act);
+        const int nA = __popcll(mask);
+        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        __syncthreads();
+        if (act) { S.idx[rank] = lane; }
+        S.cv[lane] = c;
+        __syncthreads();
+        // small system G_AA y = c_A: lane r < nA holds row r (the active inputs in lane order), the others identity rows
+        const int myvar = lane < nA ? S.idx[lane] : 0;
+        double y = 0.0;
+        auto small = [&](auto nba_) {
+            constexpr int NBA = decltype(nba_)::value;
+            constexpr int m = 16 * NBA;
+            double ws[m];
+            SFOR(s, 0, m, {
+                const int var = S.idx[s < nA ? s : 0];               // (uniform)
+                const double g = S.G[var * DN + myvar];
+                ws[s] = (lane < nA && s < nA) ? g : ((lane == s) ? 1.0 : 0.0);
+            });
+            double rhs = lane < nA ? S.cv[myvar] : 0.0;
+            double dinv = 1.0;
+            SFOR(j, 0, m, {
+                double creg[NBA], d;
+                S.rx[lane] = rhs;
+                exchange<NBA>(S.ex[j & 1], lane, j, ws[j], creg, d);
+                const double rj = S.rx[j];
+                ok = ok && (d > 0.0);
+                const double rinv = rcp_nr(d);
+                const double mj = (lane == j) ? 0.0 : ws[j] * rinv;
+                dinv = (lane == j) ? rinv : dinv;
+                const double negm = -mj;
+                SFOR(tt, j / 16, NBA, { rank1bc16(&ws[16 * tt], negm, creg[tt]); });
+                rhs = __builtin_fma(negm, rj, rhs);
+                __syncthreads();   // (S.rx is rewritten by the next step)
+            });
+            y = rhs * dinv;
+        };
+        if (nA <= 16) small(std::integral_constant<int, 1>{});
+        else if (nA <= 32) { if constexpr (NB >= 2) small(std::integral_constant<int, 2>{}); }
+        else if (nA <= 48) { if constexpr (NB >= 3) small(std::integral_constant<int, 3>{}); }
+        else { if constexpr (NB >= 4) small(std::integral_constant<int, 4>{}); }
+        if (!__all(ok)) return 0;
+        __syncthreads();
+        S.rx[lane] = y;      // y_r of the r-th active input (lanes >= nA: 0)
+        __syncthreads();
+        // delta = G[:, A] y ; multiplier of a fixed input = its y
+        double dl = 0.0;
+        for (int s = 0; s < nA; s++) dl = __builtin_fma(S.G[S.idx[s] * DN + lane], S.rx[s], dl);
+        delta = dl;
+        const double grad = act ? S.rx[rank] : 0.0;
+        const double vn = v0 + dl;
+        int nc;
+        if (cls == 0) nc = vn < lb ? 1 : (vn > ub ? 2 : 0);
+        else if (cls == 1) nc = grad > 0.0 ? 1 : 0;
+        else nc = grad < 0.0 ? 2 : 0;
+        const bool changed = __any(real && nc != cls);
+        cls = real ? nc : 0;
+        c = cls == 1 ? lb - v0 : (cls == 2 ? ub - v0 : 0.0);
+        done = !changed;
+    }
+    __syncthreads();
+    S.cv[lane] = delta;
+    __syncthreads();
+    return done ? solves : 0;
+}
+
+}  // namespace
+
+KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
+    __shared__ DenseLds S;
+    const int lane = threadIdx.x;
+    const int N = P.N;
+    const int nipm = gm(P.nipm)[0], nbig = gm(P.nipm)[41];
+    for (int slot = nbig + (int)blockIdx.x; slot < nipm; slot += (int)gridDim.x) {
+        const int inst = gm(P.ilist)[slot];
+        const int head = gm(P.head)[inst];           // <= 16 (or N <= 16): guaranteed by the list order (k_scatter)
+        const double viol = gm(P.viol)[inst];
+        // rows far outside the box skip the active-set iteration (as qp_wave): straight to the interior point
+        const bool try_as = viol > 0.0 && !(P.as_skip_viol > 0.0 && viol > P.as_skip_viol * (P.u_max - P.u_min));
+        if (!try_as || head < 1 || head > 16) {
+            if (lane == 0) gm(P.asst)[slot] = 0;
+            continue;
+        }
+        int chk = -1;
+        SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
+        // every DPP row of the wave addresses the same instance (the stage matrices are broadcast sources inside a row)
+        const Lane t = lane_indirect(P, inst, true);
+        __syncthreads();
+        if (head > 8) dense_build<true>(P, t, head, chk, S);
+        else dense_build<false>(P, t, head, chk, S);
+        __syncthreads();
+        int solves;
+        if (head <= 4) solves = dense_solve<1>(P, t, head, S);
+        else if (head <= 8) solves = dense_solve<2>(P, t, head, S);
+        else if (head <= 12) solves = dense_solve<3>(P, t, head, S);
+        else solves = dense_solve<4>(P, t, head, S);
+        if (solves > 0) {
+            // du of the head -> the compact slot's P.dva; dx_1 .. dx_head -> P.czdx (what k_ascommit reads)
+            const double dl = S.cv[lane];
+            if (lane < 4 * head) gm(P.dva)[(size_t)slot * N * 4 + lane] = dl;
+            double x = 0.0;
+            StageOps o0, o1;
+            load_ops(P, t, 0, o0);
+            auto step = [&](const StageOps& o, const int k) {
+                double xn = t.L < 3 ? x : 0.0;
+                dotbc<10, 3>(xn, o.ac, x);
+                SFOR(a, 0, 4, { xn = __builtin_fma(o.br[a], S.cv[k * 4 + a], xn); });
+                x = xn;
+                if (t.row == 0 && t.L < 13) gm(P.czdx)[((size_t)slot * (N + 1) + k + 1) * 13 + t.L] = x;
+            };
+            for (int k = 0; k < head; k += 2) {
+                load_ops(P, t, imin(k + 1, head - 1), o1);
+                step(o0, k);
+                if (k + 1 >= head) break;
+                load_ops(P, t, imin(k + 2, head - 1), o0);
+                step(o1, k + 1);
+            }
+        }
+        if (lane == 0) {
+            gm(P.asst)[slot] = solves > 0 ? 1 : 0;
+            if (solves > 0) gm(P.iters)[inst] = solves;
+        }
+    }
+}
+
+void launch_as_dense(const Params& P, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(k_as_dense, dim3(grid), dim3(64), 0, st, P);
+}
+
+}  // namespace cfn

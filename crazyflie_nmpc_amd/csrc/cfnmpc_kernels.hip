@@ -1164,7 +1164,12 @@ __global__ __launch_bounds__(256) void k_scatter(Params P) {
         int acc = 0;
         for (int j = 0; j < N_BIN; j++) { base[j] = acc; acc += gm(P.nipm)[1 + j]; }
         base[N_BIN] = acc;
-        if (blockIdx.x == 0) gm(P.nipm)[0] = acc;
+        if (blockIdx.x == 0) {
+            gm(P.nipm)[0] = acc;
+            // rows whose head is longer than 16 stages come first in the list (bins are ordered by head class, longest first:
+            // full horizon, 32, 24 | 16, 12, 8, 4): their number -- the dense active-set kernel (cfnmpc_asdense.hip) takes the rest
+            gm(P.nipm)[41] = P.N > 16 ? base[9] : 0;
+        }
     }
     if (blockIdx.x == 0 && P.ascnt && threadIdx.x < 32) gm(P.ascnt)[threadIdx.x] = 0;   // work lists of the active-set passes
     __syncthreads();
@@ -1350,7 +1355,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     // MODE 2 works on the list k_ipm_list compacted from the rows the active-set kernels left (P.ilist2, count in
     // P.nipm[40]): four fall-back rows per wave instead of one row in each of the waves they were scattered over
     const bool listed = MODE == 2 && P.ipm_listed;   // (small fleets skip k_ipm_list: the rows stay where k_as had them)
-    const int nipm = gm(P.nipm)[listed ? 40 : 0];
+    // (MODE 4 beside the dense kernel: only the rows with heads of more than 16 stages, the first P.nipm[41] of the list)
+    const int nipm = gm(P.nipm)[listed ? 40 : ((MODE == 4 && P.as_dense) ? 41 : 0)];
     // SPARSE (active-set kernels, short lists): ONE list slot per wave (row 0; rows 1..3 idle) while the constrained rows
     // number fewer than the SIMDs -- every row then sweeps its own head, restarts at its own stage and stops after its own
     // last solve instead of following the slowest of four wave-mates, and the kernel lasts as long as its hardest ROW.
@@ -2859,6 +2865,8 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         const int G = imax_h(1, imin_h(P.as_grid, P.NW));
         if (P.as_passes == -2) {
             hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, P);
+            // heads of at most 16 stages: head-condensed dense solves, one row per wavefront, one wavefront per SIMD
+            if (P.as_dense) launch_as_dense(P, imax_h(1, imin_h(P.as_grid / 2, P.NW * 4)), st);
         } else if (P.as_passes < 0) {
             hipLaunchKernelGGL(k_asp_all, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
         } else {

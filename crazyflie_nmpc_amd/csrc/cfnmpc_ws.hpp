@@ -100,6 +100,7 @@ struct Params {
     // warm start of the active set (cfnmpc_opts.as_warm): per instance the classification its last SETTLED active-set solve ended
     // with (wcls [inst][N * 4] bytes: 0 free, 1 lower, 2 upper; 0 behind that solve's head) and whether the instance's previous RTI
     // step ended that way (wvalid [inst]: the forward sweep clears it for feasible instances, the QP kernels set / clear it)
+    int as_dense;                // 1: rows with heads of at most 16 stages are solved by k_as_dense (cfnmpc_asdense.hip), beside k_as_solves
     int as_warm;
     unsigned char* wcls;
     int* wvalid;
@@ -176,6 +177,7 @@ void launch_cfactor(const Params& P, hipStream_t st);
 void launch_factor_chunk(const Params& P, hipStream_t st);   // experiment: stages [P.fk_lo, P.fk_hi) of the start solve
 #endif
 void launch_factor_only(const Params& P, hipStream_t st);
+void launch_as_dense(const Params& P, int grid, hipStream_t st);   // cfnmpc_asdense.hip: head-condensed dense active-set solves
 void launch_linfactor(const Params& P, hipStream_t st);    // cfnmpc_linfactor.hip: fused linearisation + backward factorisation
 void launch_cforward(const Params& P, hipStream_t st);   // (in cfnmpc_kernels.hip: k_forward with condensed gains)
 void launch_cipm(const Params& P, hipStream_t st);

@@ -59,7 +59,7 @@ typedef struct cfnmpc_solver cfnmpc_solver;
  *     otherwise, nothing written) -- what C callers and bindings should use; CFNMPC_DEFAULT_OPTS(&o) spells it;
  *   - every cfnmpc_opts starts with its own size (set by cfnmpc_default_opts*), and cfnmpc_create / cfnmpc_fleet_create /
  *     cfnmpc_multi_create* refuse (CFNMPC_EINVAL) an object whose struct_size is not the library's. */
-#define CFNMPC_ABI_VERSION 6
+#define CFNMPC_ABI_VERSION 7
 
 /* Replaces the constants baked into the generated solver by
  * crazyflie_controller/scripts/crazyflie_full_model/generate_c_code.py:41-146. */
@@ -191,6 +191,15 @@ typedef struct cfnmpc_opts {
                             cfnmpc_init_iterate / cfnmpc_set_iterate.  Read by the monolithic and the solves + commit kernels
                             (as_passes 0 / -1 / -3); the level-synchronous variants ignore it.  Default 0: see DESIGN.md section 5.5
                             for the measured solve histograms. */
+    int as_dense;        /* QP, active_set = 1, solves + commit structure (as_passes 0 auto / -3): rows whose head is at most 16
+                            stages long (99 % of the constrained rows of the bench workload) are solved on the HEAD-CONDENSED DENSE
+                            QP -- the same active-set iteration on H = R + Gamma' Q Gamma of the head (4 x head inputs, the tail's
+                            cost-to-go as terminal weight), inverted once per row, every solve then a system of the size of the
+                            active set (csrc/cfnmpc_asdense.hip) -- instead of one Riccati factorisation + forward sweep over the
+                            head per solve.  Same classification rule, same solve counts, same solutions to rounding (the reference's
+                            own plan condenses too: PARTIAL_CONDENSING_HPIPM, generate_c_code.py:140).  1 = on (selects the solves +
+                            commit structure), -1 = off, 0 (default) = by measurement.  Scalar box only;
+                            not with as_warm. */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);   /* unchecked: the caller's struct MUST be this header's */
