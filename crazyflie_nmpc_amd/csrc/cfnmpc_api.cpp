@@ -347,6 +347,18 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     if (o.as_dense == 1 && (P.as_passes != -2 && o.as_passes != 0)) { delete s; return CFNMPC_EINVAL; }
     if (o.as_dense == 1 && o.as_passes == 0 && o.start_solve != 2 && !cond_N2) P.as_passes = -2;   // asked for: the structure it lives in
     P.as_dense = (P.as_passes == -2 && P.active_set && !P.as_warm && o.as_dense != -1 && (o.as_dense == 1 || pick.as_dense)) ? 1 : 0;
+    if (P.as_dense) {   // side stream of the rows with long heads (launch_qp_ipm); without it the two kernels simply run one after the other
+        hipStream_t side = nullptr;
+        hipEvent_t ef = nullptr, ej = nullptr;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ef, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ej, hipEventDisableTiming) == hipSuccess) {
+            P.as_side = side; P.as_fork = ef; P.as_join = ej;
+        } else {
+            if (side) (void)hipStreamDestroy(side);
+            if (ef) (void)hipEventDestroy(ef);
+            (void)hipGetLastError();
+        }
+    }
     // start solve: the fused kernel replaces k_linearise + k_factor where nothing but the constrained instances' QP kernels
     // reads the stage blocks afterwards (matrix-free forward sweep, monolithic active-set kernel, no partial condensing,
     // no overlapped preparation); per-stage boxes (cfnmpc_set_box_stages) switch a solver back at launch time
@@ -415,6 +427,12 @@ int cfnmpc_free(cfnmpc_solver* s) {
     if (!s) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
+    if (s->P.as_side) {
+        (void)hipStreamSynchronize((hipStream_t)s->P.as_side);
+        (void)hipStreamDestroy((hipStream_t)s->P.as_side);
+        (void)hipEventDestroy((hipEvent_t)s->P.as_fork);
+        (void)hipEventDestroy((hipEvent_t)s->P.as_join);
+    }
     for (int p = 0; p < 2; p++) {
         if (s->glaunched[p]) { (void)hipEventSynchronize(s->glaunched[p]); (void)hipEventDestroy(s->glaunched[p]); }
         if (s->gexec[p]) (void)hipGraphExecDestroy(s->gexec[p]);
@@ -843,6 +861,8 @@ extern "C++" { namespace cfn { void debug_prof_read(unsigned long long* out, int
 float cfnmpc_debug_bench_sweep(cfnmpc_solver* s, int waves, int head, int reps, int which) {
     return cfn::debug_bench_sweep(s->P, waves, head, reps, which);
 }
+extern "C++" { namespace cfn { void debug_dprof_read(unsigned long long* out, int reset); } }
+int cfnmpc_debug_dprof(unsigned long long* out, int reset) { (void)hipDeviceSynchronize(); cfn::debug_dprof_read(out, reset); return 0; }
 int cfnmpc_debug_prof(unsigned long long* out, int reset) { (void)hipDeviceSynchronize(); cfn::debug_prof_read(out, reset); return 0; }
 #endif
 

@@ -41,10 +41,16 @@ constexpr int DN = 64;   // columns of the dense store (a head of 16 stages)
 struct DenseLds {
     double G[DN * DN];      // H during the build, then G = H^-1: element (r, j) at r * DN + j (lane j: conflict-free)
     double ex[2][DN];       // pivot-column exchange (double buffered)
-    double rx[DN];          // right-hand sides of the small system / y
+    double rx[2][DN];       // right-hand sides of the small system (double buffered like ex) / y
     double cv[DN];          // c of the active inputs / delta
     int idx[DN];            // the active inputs in lane order
+    double pm[16 * 13];     // cost-to-go at the head, lane-distributed: pm[L * 13 + c] = P_head[L][c]
 };
+// During the build the H block of stage k (rows 4 k .. 4 k + 3: 256 doubles) first holds that stage's matrices in the lane-distributed
+// form of the home blocks -- lane L of a DPP row: A[L][3 .. 12] | B[L][0 .. 3] at k * 256 + L * 14 -- staged once from HBM with all loads
+// in flight together; the backward visit of stage k is the last reader of that block and overwrites it with its rows of H.
+constexpr int ST_BLK = 256, ST_ROW = 14;
+static_assert(16 * ST_ROW <= ST_BLK && ST_BLK == 4 * DN, "staged stage matrices fit the stage's H rows");
 
 struct StageOps { double ac[10], br[4]; };
 struct BuildVisit { int kind, stage, slot; };   // 0: forward, 1: forward with the new state kept in hist[slot], 2: backward
@@ -66,6 +72,35 @@ __device__ __forceinline__ void load_ops(const Params& P, const Lane& t, const i
     ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, o.ac);
     ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, o.br);
 }
+__device__ __forceinline__ void lds_ops(const double* G, const Lane& t, const int k, StageOps& o) {
+    const double* b = G + k * ST_BLK + t.L * ST_ROW;
+    SFOR(g, 0, 10, { o.ac[g] = b[g]; });
+    SFOR(a, 0, 4, { o.br[a] = b[10 + a]; });
+}
+// stage matrices of the head and the cost-to-go at the head -> LDS (one exposed HBM latency per row)
+__device__ __forceinline__ void dense_stage(const Params& P, const Lane& t, const int head, const int chk, double* G, double* pm) {
+    StageOps o[4];
+    SFOR(b, 0, 4, { load_ops(P, t, imin(4 * b + t.row, head - 1), o[b]); });   // DPP row r of batch b: stage 4 b + r
+    double pr[13];
+    if (chk >= 0) {
+        const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + chk) * SZ_PP;
+        SFOR(c, 0, 13, {
+            const double v = pc[pchk_at(c, t.q, imin(t.L, 12))];
+            pr[c] = t.L < 13 ? v : 0.0;
+        });
+    } else {
+        SFOR(c, 0, 13, { pr[c] = (t.L == c) ? P.WN[ext_of(c)] : 0.0; });
+    }
+    SFOR(b, 0, 4, {
+        const int k = 4 * b + t.row;
+        if (k < head) {
+            double* d = G + k * ST_BLK + t.L * ST_ROW;
+            SFOR(g, 0, 10, { d[g] = o[b].ac[g]; });
+            SFOR(a, 0, 4, { d[10 + a] = o[b].br[a]; });
+        }
+    });
+    if (t.row == 0) SFOR(c, 0, 13, { pm[t.L * 13 + c] = pr[c]; });
+}
 
 // ---- 1. H column of this lane -> S.G[(i * 4 + a) * DN + lane] ------------------------------------------------------------------
 // TWO: head > 8 (two halves).  All lanes run every stage (lockstep); a lane's state is zero up to its own stage.
@@ -73,30 +108,14 @@ template <bool TWO>
 __device__ __forceinline__ void dense_build(const Params& P, const Lane& t, const int head, const int chk, DenseLds& S) {
     const int lane = threadIdx.x;
     const int kj = lane >> 2, aj = lane & 3;
-    const int N = P.N;
     double Qi[13];
     SFOR(j, 0, 13, { Qi[j] = P.W[ext_of(j)]; });
     const double Rj = aj == 0 ? P.W[13] : (aj == 1 ? P.W[14] : (aj == 2 ? P.W[15] : P.W[16]));
     // this lane's own column of B (injected at its stage)
     double binj[13];
-    {
-        const gdouble* bb = blk(P.BR, t, N, imin(kj, head - 1), SZ_B) + (aj * 4 + t.q) * 13;
-        SFOR(i, 0, 13, { binj[i] = bb[i]; });
-    }
-    // cost-to-go at the head: checkpoint of the start solve (packed triangle), or the terminal weight (head = N); loaded one
-    // visit before it is used (thirteen registers that the forward half does not have to carry)
-    double pr[13];   // pr[c]@lane(r) = P_head[r][c]
-    auto load_pr = [&]() {
-        if (chk >= 0) {
-            const gdouble* pc = gm(P.Pchk) + ((size_t)t.wave * N_CHK + chk) * SZ_PP;
-            SFOR(c, 0, 13, {
-                const double v = pc[pchk_at(c, t.q, imin(t.L, 12))];
-                pr[c] = t.L < 13 ? v : 0.0;
-            });
-        } else {
-            SFOR(c, 0, 13, { pr[c] = (t.L == c) ? P.WN[ext_of(c)] : 0.0; });
-        }
-    };
+    SFOR(i, 0, 13, { binj[i] = S.G[imin(kj, head - 1) * ST_BLK + i * ST_ROW + 10 + aj]; });
+    double pr[13];   // pr[c]@lane(r) = P_head[r][c] (read from the staged copy one visit before its use)
+    auto load_pr = [&]() { SFOR(c, 0, 13, { pr[c] = S.pm[t.L * 13 + c]; }); };
     auto fwd = [&](const int k, double (&x)[13], const StageOps& o) {
         double xn[13];
         SFOR(i, 0, 3, { xn[i] = x[i]; });
@@ -126,7 +145,7 @@ __device__ __forceinline__ void dense_build(const Params& P, const Lane& t, cons
     // visits of stages >= head are skipped (their loads, clamped, are harmless)
     constexpr int NV = TWO ? 40 : 16, FIRST_B = TWO ? 16 : 8;
     StageOps o0, o1;
-    load_ops(P, t, 0, o0);
+    lds_ops(S.G, t, 0, o0);
     SFOR(v, 0, NV, {
         StageOps& cur = (v & 1) ? o1 : o0;
         StageOps& nxt = (v & 1) ? o0 : o1;
@@ -136,7 +155,7 @@ __device__ __forceinline__ void dense_build(const Params& P, const Lane& t, cons
         if constexpr (v + 1 < NV) {
             int kn = imin(build_visit<TWO>(v + 1).stage, head - 1);
             asm volatile("" : "+s"(kn));
-            load_ops(P, t, kn, nxt);
+            lds_ops(S.G, t, kn, nxt);
         }
         constexpr BuildVisit vv = build_visit<TWO>(v);
         if constexpr (v == FIRST_B - 1) load_pr();
@@ -161,15 +180,6 @@ __device__ __forceinline__ void dense_build(const Params& P, const Lane& t, cons
     });
 }
 
-// one step of the pivot exchange: every lane publishes `mine`, gets the NB values of its DPP lane position and the pivot
-template <int NB>
-__device__ __forceinline__ void exchange(double* ex, const int lane, const int k, const double mine, double (&creg)[NB], double& d) {
-    ex[lane] = mine;
-    __syncthreads();
-    SFOR(tt, 0, NB, { creg[tt] = ex[(lane & 15) + 16 * tt]; });
-    d = ex[k];
-}
-
 // ---- 2. + 3.: G = H^-1 and the active-set iteration; NB = sixteens of inputs (n = 16 NB >= 4 head) ---------------------------
 // returns the number of solves (> 0: settled, delta in S.cv), 0: not settled / factorisation failed
 template <int NB>
@@ -181,16 +191,33 @@ __device__ __forceinline__ int dense_solve(const Params& P, const Lane& t, const
     SFOR(c, 0, n, { w[c] = S.G[c * DN + lane]; });
     SFOR(c, 0, n, { if (lane >= nr || c >= nr) w[c] = (lane == c) ? 1.0 : 0.0; });
     bool ok = true;
-    // symmetric sweeps: after all of them w = -H^-1 (lane = row)
+    // symmetric sweeps: after all of them w = -H^-1 (lane = row).  One LDS exchange per sweep -- every lane publishes its element
+    // k, reads the NB values of its DPP lane position and the pivot -- software-pipelined: the block that holds column k + 1 is
+    // updated first, the next pivot column published and its reads issued, and only then the other blocks (their fused
+    // multiply-adds cover the LDS round trip).  One wavefront: LDS operations execute in program order, no barrier needed.
+    const int L = lane & 15;
+    double cr[2][NB], dd[2];
+    S.ex[0][lane] = w[0];
+    SFOR(tt, 0, NB, { cr[0][tt] = S.ex[0][L + 16 * tt]; });
+    dd[0] = S.ex[0][0];
     SFOR(k, 0, n, {
-        double creg[NB], d;
-        exchange<NB>(S.ex[k & 1], lane, k, w[k], creg, d);
+        constexpr int b = k & 1, bn = b ^ 1;
+        constexpr int bf = (k + 1 < n) ? (k + 1) / 16 : 0;       // the block of the next pivot column
+        const double d = dd[b];
         ok = ok && (d > 0.0);
         const double rinv = rcp_nr(d);
         const double tk = (lane == k) ? (1.0 - rinv) : w[k] * rinv;   // lane k: its own row ends as row / d
+        const double wk_new = (lane == k) ? -rinv : tk;
         const double negt = -tk;
-        SFOR(tt, 0, NB, { rank1bc16(&w[16 * tt], negt, creg[tt]); });
-        w[k] = (lane == k) ? -rinv : tk;
+        rank1bc16(&w[16 * bf], negt, cr[b][bf]);
+        if constexpr (k / 16 == bf) w[k] = wk_new;
+        if constexpr (k + 1 < n) {
+            S.ex[bn][lane] = w[k + 1];
+            SFOR(tt, 0, NB, { cr[bn][tt] = S.ex[bn][L + 16 * tt]; });
+            dd[bn] = S.ex[bn][k + 1];
+        }
+        SFOR(tt, 0, NB, { if constexpr (tt != bf) rank1bc16(&w[16 * tt], negt, cr[b][tt]); });
+        if constexpr (k / 16 != bf) w[k] = wk_new;
     });
     if (!__all(ok)) return 0;
     __syncthreads();
@@ -213,53 +240,101 @@ __device__ __forceinline__ int dense_solve(const Params& P, const Lane& t, const
         const unsigned long long mask = __ballot(act);
         const int nA = __popcll(mask);
         const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-        __syncthreads();
-        if (act) { S.idx[rank] = lane; }
-        S.cv[lane] = c;
-        __syncthreads();
-        // small system G_AA y = c_A: lane r < nA holds row r (the active inputs in lane order), the others identity rows
-        const int myvar = lane < nA ? S.idx[lane] : 0;
-        double y = 0.0;
-        auto small = [&](auto nba_) {
-            constexpr int NBA = decltype(nba_)::value;
-            constexpr int m = 16 * NBA;
-            double ws[m];
-            SFOR(s, 0, m, {
-                const int var = S.idx[s < nA ? s : 0];               // (uniform)
-                const double g = S.G[var * DN + myvar];
-                ws[s] = (lane < nA && s < nA) ? g : ((lane == s) ? 1.0 : 0.0);
+        double dl = 0.0, grad = 0.0;
+        if (nA <= 16) {
+            // The usual case -- a handful of active inputs -- entirely in registers: every 16-lane DPP row holds a copy of the
+            // small system (lane L: row L of G_AA, the active inputs in lane order; rows behind the set: identity), the pivot
+            // column of a Gauss-Jordan step is the lanes' own element (symmetry of the trailing block) and reaches the others
+            // as a DPP broadcast source -- no LDS exchange, no barrier.
+            int ix[16];                      // the active inputs (wave-uniform: scalar registers)
+            {
+                unsigned long long m2 = mask;
+                SFOR(s2, 0, 16, { ix[s2] = m2 ? (int)__builtin_ctzll(m2) : 0; m2 &= m2 - 1ull; });
+            }
+            const int L = lane & 15;
+            int myvar = 0;
+            SFOR(s2, 0, 16, { myvar = (L == s2) ? ix[s2] : myvar; });
+            double ws[16];
+            SFOR(s2, 0, 16, {
+                const double g = S.G[ix[s2] * DN + myvar];
+                ws[s2] = (L < nA && s2 < nA) ? g : ((L == s2) ? 1.0 : 0.0);
             });
-            double rhs = lane < nA ? S.cv[myvar] : 0.0;
+            double rhs = __shfl(c, myvar);
+            rhs = L < nA ? rhs : 0.0;
             double dinv = 1.0;
-            SFOR(j, 0, m, {
-                double creg[NBA], d;
-                S.rx[lane] = rhs;
-                exchange<NBA>(S.ex[j & 1], lane, j, ws[j], creg, d);
-                const double rj = S.rx[j];
+            SFOR(j, 0, 16, {
+                double col = ws[j];
+                asm volatile("" : "+v"(col));          // (a register of its own: the block below rewrites ws[j] while reading col)
+                const double d = bc<j>(col);
+                const double rj = bc<j>(rhs);
                 ok = ok && (d > 0.0);
                 const double rinv = rcp_nr(d);
-                const double mj = (lane == j) ? 0.0 : ws[j] * rinv;
-                dinv = (lane == j) ? rinv : dinv;
+                const double mj = (L == j) ? 0.0 : col * rinv;
+                dinv = (L == j) ? rinv : dinv;
                 const double negm = -mj;
-                SFOR(tt, j / 16, NBA, { rank1bc16(&ws[16 * tt], negm, creg[tt]); });
+                rank1bc16(&ws[0], negm, col);
                 rhs = __builtin_fma(negm, rj, rhs);
-                __syncthreads();   // (S.rx is rewritten by the next step)
             });
-            y = rhs * dinv;
-        };
-        if (nA <= 16) small(std::integral_constant<int, 1>{});
-        else if (nA <= 32) { if constexpr (NB >= 2) small(std::integral_constant<int, 2>{}); }
-        else if (nA <= 48) { if constexpr (NB >= 3) small(std::integral_constant<int, 3>{}); }
-        else { if constexpr (NB >= 4) small(std::integral_constant<int, 4>{}); }
-        if (!__all(ok)) return 0;
-        __syncthreads();
-        S.rx[lane] = y;      // y_r of the r-th active input (lanes >= nA: 0)
-        __syncthreads();
-        // delta = G[:, A] y ; multiplier of a fixed input = its y
-        double dl = 0.0;
-        for (int s = 0; s < nA; s++) dl = __builtin_fma(S.G[S.idx[s] * DN + lane], S.rx[s], dl);
+            if (!__all(ok)) return 0;
+            const double y = rhs * dinv;     // lane L of every DPP row: y of the L-th active input
+            // delta = G[:, A] y ; multiplier of a fixed input = its y
+            SFOR(s2, 0, 16, {
+                const double g = S.G[ix[s2] * DN + lane];
+                const double ys = bc<s2>(y);
+                dl = __builtin_fma(s2 < nA ? g : 0.0, ys, dl);
+            });
+            grad = __shfl(y, rank & 15);
+        } else {
+            // more than sixteen active inputs (the hard rows): the same elimination with the pivot column exchanged through LDS
+            // (lane r < nA: row r of G_AA; one wavefront: LDS operations execute in program order)
+            if (act) { S.idx[rank] = lane; }
+            S.cv[lane] = c;
+            const int myvar = lane < nA ? S.idx[lane] : 0;
+            double y = 0.0;
+            auto small = [&](auto nba_) {
+                constexpr int NBA = decltype(nba_)::value;
+                constexpr int m = 16 * NBA;
+                double ws[m];
+                SFOR(s, 0, m, {
+                    const int var = S.idx[s < nA ? s : 0];               // (uniform)
+                    const double g = S.G[var * DN + myvar];
+                    ws[s] = (lane < nA && s < nA) ? g : ((lane == s) ? 1.0 : 0.0);
+                });
+                double rhs = lane < nA ? S.cv[myvar] : 0.0;
+                double dinv = 1.0;
+                SFOR(j, 0, m, {
+                    if (j < nA) {        // (the rows behind the set are identity rows: nothing to eliminate)
+                        double creg[NBA];
+                        S.ex[j & 1][lane] = ws[j];
+                        S.rx[j & 1][lane] = rhs;
+                        SFOR(tt, j / 16, NBA, { creg[tt] = S.ex[j & 1][(lane & 15) + 16 * tt]; });
+                        const double d = S.ex[j & 1][j], rj = S.rx[j & 1][j];
+                        ok = ok && (d > 0.0);
+                        const double rinv = rcp_nr(d);
+                        const double mj = (lane == j) ? 0.0 : ws[j] * rinv;
+                        dinv = (lane == j) ? rinv : dinv;
+                        const double negm = -mj;
+                        SFOR(tt, j / 16, NBA, { rank1bc16(&ws[16 * tt], negm, creg[tt]); });
+                        rhs = __builtin_fma(negm, rj, rhs);
+                    }
+                });
+                y = rhs * dinv;
+            };
+            if (nA <= 32) { if constexpr (NB >= 2) small(std::integral_constant<int, 2>{}); }
+            else if (nA <= 48) { if constexpr (NB >= 3) small(std::integral_constant<int, 3>{}); }
+            else { if constexpr (NB >= 4) small(std::integral_constant<int, 4>{}); }
+            if (!__all(ok)) return 0;
+            S.rx[0][lane] = y;      // y_r of the r-th active input (lanes >= nA: 0)
+            for (int s0 = 0; s0 < nA; s0 += 8) {      // delta = G[:, A] y, eight terms per batch (loads first)
+                int iv[8]; double gv[8], yv[8];
+                SFOR(q, 0, 8, { iv[q] = S.idx[imin(s0 + q, nA - 1)]; });
+                SFOR(q, 0, 8, { gv[q] = S.G[iv[q] * DN + lane]; yv[q] = S.rx[0][imin(s0 + q, nA - 1)]; });
+                SFOR(q, 0, 8, { dl = __builtin_fma(s0 + q < nA ? gv[q] : 0.0, yv[q], dl); });
+            }
+            grad = S.rx[0][rank];
+        }
         delta = dl;
-        const double grad = act ? S.rx[rank] : 0.0;
+        grad = act ? grad : 0.0;
         const double vn = v0 + dl;
         int nc;
         if (cls == 0) nc = vn < lb ? 1 : (vn > ub ? 2 : 0);
@@ -278,12 +353,24 @@ __device__ __forceinline__ int dense_solve(const Params& P, const Lane& t, const
 
 }  // namespace
 
+#ifdef CFN_PROF
+// (development builds with -DCFN_PROF: phases of the longest row and sums over all rows, wall-clock ticks of 10 ns)
+__device__ unsigned long long g_dprof[32];
+#define DPROF(i) { const unsigned long long now_ = wall_clock64(); dacc[i] += now_ - dlast; dlast = now_; }
+#else
+#define DPROF(i)
+#endif
+
 KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
     __shared__ DenseLds S;
     const int lane = threadIdx.x;
     const int N = P.N;
     const int nipm = gm(P.nipm)[0], nbig = gm(P.nipm)[41];
     for (int slot = nbig + (int)blockIdx.x; slot < nipm; slot += (int)gridDim.x) {
+#ifdef CFN_PROF
+        unsigned long long dacc[6] = {0, 0, 0, 0, 0, 0}, dlast = wall_clock64();
+        const unsigned long long dstart = dlast;
+#endif
         const int inst = gm(P.ilist)[slot];
         const int head = gm(P.head)[inst];           // <= 16 (or N <= 16): guaranteed by the list order (k_scatter)
         const double viol = gm(P.viol)[inst];
@@ -298,14 +385,19 @@ KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
         // every DPP row of the wave addresses the same instance (the stage matrices are broadcast sources inside a row)
         const Lane t = lane_indirect(P, inst, true);
         __syncthreads();
+        dense_stage(P, t, head, chk, S.G, S.pm);
+        __syncthreads();
+        DPROF(0)
         if (head > 8) dense_build<true>(P, t, head, chk, S);
         else dense_build<false>(P, t, head, chk, S);
         __syncthreads();
+        DPROF(1)
         int solves;
         if (head <= 4) solves = dense_solve<1>(P, t, head, S);
         else if (head <= 8) solves = dense_solve<2>(P, t, head, S);
         else if (head <= 12) solves = dense_solve<3>(P, t, head, S);
         else solves = dense_solve<4>(P, t, head, S);
+        DPROF(2)
         if (solves > 0) {
             // du of the head -> the compact slot's P.dva; dx_1 .. dx_head -> P.czdx (what k_ascommit reads)
             const double dl = S.cv[lane];
@@ -332,9 +424,25 @@ KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
             gm(P.asst)[slot] = solves > 0 ? 1 : 0;
             if (solves > 0) gm(P.iters)[inst] = solves;
         }
+#ifdef CFN_PROF
+        DPROF(3)
+        if (lane == 0) {
+            const unsigned long long tot = dlast - dstart;
+            const unsigned long long old = atomicMax(&g_dprof[8], tot);
+            if (tot > old) { for (int i = 0; i < 6; i++) g_dprof[i] = dacc[i]; g_dprof[11] = solves; g_dprof[12] = head; }
+            atomicAdd(&g_dprof[9], tot); atomicAdd(&g_dprof[10], 1ull); atomicAdd(&g_dprof[13], (unsigned long long)solves);
+            for (int i = 0; i < 6; i++) atomicAdd(&g_dprof[16 + i], dacc[i]);
+        }
+#endif
     }
 }
 
+#ifdef CFN_PROF
+void debug_dprof_read(unsigned long long* out, int reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dprof), sizeof(unsigned long long) * 32);
+    if (reset) { unsigned long long z[32] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dprof), z, sizeof z); }
+}
+#endif
 void launch_as_dense(const Params& P, int grid, hipStream_t st) {
     hipLaunchKernelGGL(k_as_dense, dim3(grid), dim3(64), 0, st, P);
 }

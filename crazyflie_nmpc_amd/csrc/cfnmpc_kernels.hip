@@ -1400,6 +1400,10 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         tc.wave = tc.inst >> 2; tc.q = tc.inst & 3;
     } else {
         tc.wave = vb; tc.q = t.row; tc.inst = vb * 4 + t.row;
+        // a row without work is parked on the spare compact block as well: beside the dense kernel (MODE 4, P.as_dense) the list
+        // slots behind this kernel's share belong to rows k_as_dense is working on AT THE SAME TIME -- an idle row sweeping
+        // "its" compact slot would overwrite their du / dx
+        if (!has) { tc.wave = P.NW; tc.inst = P.NW * 4 + t.row; }
     }
     Params Q = P;
     Q.v4b = 0;   // (compact 4-vectors: instance-major, a row's head contiguous)
@@ -2863,10 +2867,23 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         // launch loops over the remaining solves in-wave; as_passes < 0: every solve in one launch.  Then commit,
         // retries over a longer head, interior point for the rest.
         const int G = imax_h(1, imin_h(P.as_grid, P.NW));
-        if (P.as_passes == -2) {
+        if (P.as_passes == -2 && P.as_dense) {
+            // heads of at most 16 stages: head-condensed dense solves (one row per wavefront, one wavefront per SIMD) on the
+            // caller's stream; the rows with longer heads (the first P.nipm[41] of the list: none, or a handful) keep the Riccati
+            // form of the iteration in k_as_solves, forked onto the solver's side stream -- two latency chains side by side
+            hipStream_t side = (hipStream_t)P.as_side;
+            if (side) {
+                (void)hipEventRecord((hipEvent_t)P.as_fork, st);
+                (void)hipStreamWaitEvent(side, (hipEvent_t)P.as_fork, 0);
+                hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, side, P);
+                (void)hipEventRecord((hipEvent_t)P.as_join, side);
+            } else {
+                hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, P);
+            }
+            launch_as_dense(P, imax_h(1, imin_h(P.as_grid / 2, P.NW * 4)), st);
+            if (side) (void)hipStreamWaitEvent(st, (hipEvent_t)P.as_join, 0);
+        } else if (P.as_passes == -2) {
             hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, P);
-            // heads of at most 16 stages: head-condensed dense solves, one row per wavefront, one wavefront per SIMD
-            if (P.as_dense) launch_as_dense(P, imax_h(1, imin_h(P.as_grid / 2, P.NW * 4)), st);
         } else if (P.as_passes < 0) {
             hipLaunchKernelGGL(k_asp_all, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
         } else {

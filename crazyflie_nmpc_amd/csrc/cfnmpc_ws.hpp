@@ -101,6 +101,9 @@ struct Params {
     // with (wcls [inst][N * 4] bytes: 0 free, 1 lower, 2 upper; 0 behind that solve's head) and whether the instance's previous RTI
     // step ended that way (wvalid [inst]: the forward sweep clears it for feasible instances, the QP kernels set / clear it)
     int as_dense;                // 1: rows with heads of at most 16 stages are solved by k_as_dense (cfnmpc_asdense.hip), beside k_as_solves
+    // host-only (never read on the device): side stream + fork / join events on which k_as_solves -- the few rows with longer
+    // heads, a latency chain of its own -- runs BESIDE k_as_dense (hipStream_t / hipEvent_t, owned by the solver)
+    void *as_side, *as_fork, *as_join;
     int as_warm;
     unsigned char* wcls;
     int* wvalid;

@@ -1,0 +1,98 @@
+"""Head-condensed dense active-set solves (cfnmpc_opts.as_dense, csrc/cfnmpc_asdense.hip) against the Riccati form of the same
+iteration (as_dense = -1: k_as_solves for every row) and against the CPU restatement: same statuses, same solve counts, same
+iterates to rounding -- closed loops with staggered kicks (heads of 4 .. 16 stages and longer ones side by side), horizons
+around and below the dense limit (the head is the whole horizon and ends in the terminal weight), other boxes and weights."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HOV = 15.777730167256925
+
+
+def _loop(oracle, B, N, steps, scale, opt_a, opt_b, seed=5, box=None, check=None):
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(seed)
+    x = oracle.sample_hover_x0(rng, B, scale=scale)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    a = BatchSolver(B, default_opts(N=N, **opt_a)); b = BatchSolver(B, default_opts(N=N, **opt_b))
+    for s in (a, b):
+        if box:
+            s.set_box(*box)
+        s.set_x0(x); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    cohort = max(1, B // 10)
+    kicks = oracle.sample_hover_x0(rng, cohort * steps, scale=scale).reshape(steps, cohort, 13)
+    heads, total = {}, 0
+    for t in range(steps):
+        c0 = (t * cohort) % max(B - cohort, 1)
+        x[c0:c0 + cohort] = kicks[t]
+        a.set_x0(x); b.set_x0(x)
+        a.solve(1); b.solve(1)
+        sa, ia, _ = a.stats(); sb, ib, _ = b.stats()
+        xa, ua = a.get_iterate(); xb, ub = b.get_iterate()
+        assert np.array_equal(sa, sb), (t, np.nonzero(sa != sb)[0][:10], sa[sa != sb][:10], sb[sa != sb][:10])
+        assert np.array_equal(ia, ib), (t, np.nonzero(ia != ib)[0][:10], ia[ia != ib][:10], ib[ia != ib][:10])
+        ok = sa == 0
+        err = max(np.abs(ua[ok] - ub[ok]).max(), np.abs(xa[ok] - xb[ok]).max())
+        assert err < 1e-8, (t, err)
+        for h in a.heads()[ia > 0]:
+            heads[int(h)] = heads.get(int(h), 0) + 1
+        total += int((ia > 0).sum())
+        if check:
+            check(t, x, a, ia, sa, ua, xa)
+        b.set_iterate(xa, ua)                      # one trajectory
+        x = sim(x, a.get_u(0), T=0.015, steps=1)
+    a.close(); b.close()
+    return heads, total
+
+
+@pytest.mark.parametrize("B,scale", [(37, 1.0), (1500, 1.0), (1500, 1.6), (6000, 1.0)])
+def test_dense_solves_match_riccati_solves(oracle, B, scale):
+    heads, total = _loop(oracle, B, 50, 12, scale, dict(as_dense=1), dict(as_dense=-1, as_passes=-3))
+    assert total > B // 4 and sum(v for h, v in heads.items() if h <= 16) > 0.5 * total, heads     # the dense kernel had the bulk of the rows
+    if scale > 1.5:
+        assert any(h > 16 for h in heads), heads                                                  # ... beside rows of k_as_solves
+
+
+@pytest.mark.parametrize("N", [5, 8, 9, 12, 16, 17, 20])
+def test_dense_solves_on_short_horizons(oracle, N):
+    """N <= 16: every constrained row's head is the whole horizon (terminal weight instead of a checkpoint, 4 N inputs, padded to
+    the next multiple of sixteen); N = 17, 20: heads 4 .. 16 dense, the full horizon with k_as_solves."""
+    heads, total = _loop(oracle, 300, N, 6, 2.0, dict(as_dense=1), dict(as_dense=-1, as_passes=-3), seed=N)
+    assert total > 50, (heads, total)
+
+
+def test_dense_solves_match_restatement(oracle, cref):
+    """... and against the C restatement (full-horizon active-set solves there): statuses, solve counts where both sides sweep the
+    full horizon are covered by test_gpu_parity; here the default engine (active horizon, dense heads) closed loop, iterates 1e-7."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N = 256, 50
+    rng = np.random.default_rng(77)
+    x = oracle.sample_hover_x0(rng, B, scale=1.3)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    # (tol 1e-11 on both sides: rows far outside the box skip the active-set iteration -- as_skip_viol -- and are solved by the
+    #  interior point, whose two implementations agree at the level of the QP tolerance)
+    s = BatchSolver(B, default_opts(as_dense=1, u_min=1.0, u_max=20.0, tol=1e-11))
+    s.set_x0(x); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    opts = cref.default_opts(active_set=1, u_min=1.0, u_max=20.0, tol=1e-11)
+    xr = np.repeat(x[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    n = 0
+    for t in range(10):
+        s.set_x0(x); s.solve(1)
+        st, it, _ = s.stats()
+        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        xg, ug = s.get_iterate()
+        assert (st == 0).all() and (st_r == 0).all() and np.array_equal(it > 0, it_r > 0)
+        exact = (it <= 12) & (it_r <= 12)       # settled by active-set solves on both sides (else: interior point at tol 1e-8)
+        assert exact.mean() > 0.98
+        assert np.abs(ug[exact] - ur[exact]).max() < 1e-7 and np.abs(xg[exact] - xr[exact]).max() < 1e-7, (t, np.abs(ug[exact] - ur[exact]).max())
+        assert np.abs(ug - ur).max() < 5e-4
+        assert ug.min() >= 1.0 - 1e-9 and ug.max() <= 20.0 + 1e-9
+        n += int((it > 0).sum())
+        ur[:] = ug; xr[:] = xg
+        x = sim(x, s.get_u(0), T=0.015, steps=1)
+    assert n > 100
+    s.close()
