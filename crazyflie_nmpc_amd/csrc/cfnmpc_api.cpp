@@ -91,7 +91,12 @@ constexpr size_t EV_PER_STEP = 7;
 //   * active-set solves + commit kernel instead of the monolithic kernel: while the ~8 % constrained rows make fewer
 //     waves than there are SIMDs by a margin (roll-out = latency chain); re-measured after the 4-vector layout change:
 //     N = 50: -3.5 % at 24 S, -0.5 % at 32 S, equal at 48 S; N = 100: -3.6 % up to 32 S, equal at 48 S; N = 30: +4.7 % from 24 S on;
-//   * fall-back rows compacted before the interior point: from 16 S instances.
+//   * fall-back rows compacted before the interior point: from 16 S instances;
+//   * head-condensed dense active-set solves (k_as_dense) for the rows with heads of at most 16 stages: below 18 S instances
+//     (round 5, one box, A/B per size: 2 S +20.6 %, 4 S +8.5 %, 8 S +9.6 %, 12 S +1.8 %, 16 S +1.1 %, 20 S -1.8 %, 24 S -1.4 %,
+//     28 S -0.5 %, 32 S -5 %: one row per wavefront and SIMD -- while the ~8 % constrained rows fit the SIMDs once the kernel lasts
+//     as long as its hardest row, 50 - 90 us instead of 220; beyond that its ~47 us per row are rounds of waves and the four
+//     rows per wavefront of k_as_solves / k_as win on throughput), profiles/r05_as_dense.md.
 struct Choice { bool forward_rg, as_commit, ipm_listed, as_dense; };
 inline Choice choose_kernels(int batch, int N, int simds) {
     const long S = simds > 0 ? simds : 1024;
@@ -99,7 +104,7 @@ inline Choice choose_kernels(int batch, int N, int simds) {
     c.forward_rg = (long)batch < (N <= 64 ? 8 : 6) * S;
     c.as_commit = (long)batch < (N <= 40 ? 20 : 36) * S;
     c.ipm_listed = (long)batch >= 16 * S;
-    c.as_dense = true;
+    c.as_dense = (long)batch < 18 * S;
     return c;
 }
 

@@ -15,18 +15,18 @@
 //      multiply-adds per stage and lane, the stage matrices being DPP broadcast sources (cfnmpc_dense_dpp.hpp) straight from the
 //      home blocks' row-distributed form.  The backward sweep needs the forward states: eight of them are kept in registers and
 //      heads of more than eight stages are done in two halves (the first half's states recomputed).
-//   2. G = H^-1 by n symmetric sweeps (Goodnight's sweep operator keeps the matrix symmetric, so the pivot row is the pivot
-//      COLUMN: one value per lane, exchanged through LDS once per sweep), every lane holding its row in registers.
-//   3. primal-dual active-set iteration on G: with the active inputs A fixed at c = bound - v0, delta = G[:, A] y and the
-//      multipliers of the fixed inputs are y itself, G_AA y = c_A -- a system of the size of the ACTIVE SET (a handful of
-//      inputs), solved by Gauss-Jordan elimination on the same exchange scheme.  Same classification rule, same sequence of
-//      sets and same solve counts as qp_wave and the CPU restatements of the test suite; a stationary set is the KKT point of
-//      the strictly convex QP.
+//   2. + 3. the primal-dual active-set iteration on the SWEPT matrix: every lane holds its row of H in registers; Goodnight's
+//      symmetric sweep on the free inputs F leaves -H_FF^-1, H_FF^-1 H_FA and the Schur complement of the fixed inputs in
+//      place, so one solve with the inputs A fixed at c = bound - v0 is ONE matrix-vector product (delta_F = -W[F, A] c_A,
+//      multipliers = W[A, A] c_A), and since sweeps commute and are reversible the matrix follows the active set: the first
+//      iteration sweeps the initially free inputs, every later one only the inputs whose class changed.  Same classification
+//      rule, same sequence of sets and same solve counts as qp_wave and the CPU restatements of the test suite; a stationary
+//      set is the KKT point of the strictly convex QP.
 //   4. dx of the head by one forward sweep; du / dx / settled flag / solve count handed to k_ascommit exactly as k_as_solves
 //      does (roll-out, tail verification, retries and the interior-point fall-back are unchanged).
 //
 // One wavefront = one row; rows with longer heads stay with k_as_solves (the compaction lists them first: P.nipm[41] rows).
-// LDS: 32 KB (H, then G) + 3 KB per wavefront -> four per compute unit.  Scalar input box only.
+// LDS: 32 KB (staged stage matrices, then H) + 2 KB per wavefront -> four per compute unit.  Scalar input box only.
 #include <hip/hip_runtime.h>
 
 #include "cfnmpc_rg.hpp"
@@ -39,11 +39,8 @@ namespace {
 constexpr int DN = 64;   // columns of the dense store (a head of 16 stages)
 
 struct DenseLds {
-    double G[DN * DN];      // H during the build, then G = H^-1: element (r, j) at r * DN + j (lane j: conflict-free)
-    double ex[2][DN];       // pivot-column exchange (double buffered)
-    double rx[2][DN];       // right-hand sides of the small system (double buffered like ex) / y
-    double cv[DN];          // c of the active inputs / delta
-    int idx[DN];            // the active inputs in lane order
+    double G[DN * DN];      // the staged stage matrices, then H: element (r, j) at r * DN + j (lane j: conflict-free)
+    double cv[DN];          // delta of the settled row (read by the dx sweep)
     double pm[16 * 13];     // cost-to-go at the head, lane-distributed: pm[L * 13 + c] = P_head[L][c]
 };
 // During the build the H block of stage k (rows 4 k .. 4 k + 3: 256 doubles) first holds that stage's matrices in the lane-distributed
@@ -180,166 +177,77 @@ __device__ __forceinline__ void dense_build(const Params& P, const Lane& t, cons
     });
 }
 
-// ---- 2. + 3.: G = H^-1 and the active-set iteration; NB = sixteens of inputs (n = 16 NB >= 4 head) ---------------------------
-// returns the number of solves (> 0: settled, delta in S.cv), 0: not settled / factorisation failed
+// ---- 2. + 3.: the active-set iteration on the SWEPT matrix; NB = sixteens of inputs (n = 16 NB >= 4 head) -------------------
+// Goodnight's symmetric sweep on an index set F turns H = [H_FF H_FA; H_AF H_AA] into
+//     [ -H_FF^-1 ,  H_FF^-1 H_FA ;  H_AF H_FF^-1 ,  H_AA - H_AF H_FF^-1 H_FA ],
+// i.e. exactly what one active-set solve with the inputs A fixed at c needs: with val = W[:, A] c_A the free inputs move by
+// delta_F = -val_F and the multipliers of the fixed ones are val_A (Schur complement).  Sweeps commute and are reversible (the reverse
+// sweep differs in one sign), so the matrix FOLLOWS the active set: the first iteration sweeps the initially free inputs, every
+// later one only the inputs that changed their class -- a few rank-one updates instead of a new factorisation -- and each solve is
+// one matrix-vector product.  A sweep: every lane holds its row; the pivot column is the lanes' own element k (the swept matrix
+// stays symmetric), which reaches the 16-lane DPP rows by one cross-lane permute per sixteen columns; its pivot by v_readlane.
+// returns the number of solves (> 0: settled, delta in S.cv), 0: not settled / a pivot of the wrong sign
 template <int NB>
-__device__ __forceinline__ int dense_solve(const Params& P, const Lane& t, const int head, DenseLds& S) {
+__device__ __forceinline__ int dense_solve(const Params& P, const int head, const double v0, const double uk, DenseLds& S) {
     constexpr int n = 16 * NB;
     const int lane = threadIdx.x;
-    const int nr = 4 * head;                 // real inputs; lanes / columns behind them are padding (identity)
+    const int L = lane & 15;
+    const int nr = 4 * head;                 // real inputs; lanes / columns behind them are padding (identity, never swept)
     double w[n];
     SFOR(c, 0, n, { w[c] = S.G[c * DN + lane]; });
     SFOR(c, 0, n, { if (lane >= nr || c >= nr) w[c] = (lane == c) ? 1.0 : 0.0; });
-    bool ok = true;
-    // symmetric sweeps: after all of them w = -H^-1 (lane = row).  One LDS exchange per sweep -- every lane publishes its element
-    // k, reads the NB values of its DPP lane position and the pivot -- software-pipelined: the block that holds column k + 1 is
-    // updated first, the next pivot column published and its reads issued, and only then the other blocks (their fused
-    // multiply-adds cover the LDS round trip).  One wavefront: LDS operations execute in program order, no barrier needed.
-    const int L = lane & 15;
-    double cr[2][NB], dd[2];
-    S.ex[0][lane] = w[0];
-    SFOR(tt, 0, NB, { cr[0][tt] = S.ex[0][L + 16 * tt]; });
-    dd[0] = S.ex[0][0];
-    SFOR(k, 0, n, {
-        constexpr int b = k & 1, bn = b ^ 1;
-        constexpr int bf = (k + 1 < n) ? (k + 1) / 16 : 0;       // the block of the next pivot column
-        const double d = dd[b];
-        ok = ok && (d > 0.0);
-        const double rinv = rcp_nr(d);
-        const double tk = (lane == k) ? (1.0 - rinv) : w[k] * rinv;   // lane k: its own row ends as row / d
-        const double wk_new = (lane == k) ? -rinv : tk;
-        const double negt = -tk;
-        rank1bc16(&w[16 * bf], negt, cr[b][bf]);
-        if constexpr (k / 16 == bf) w[k] = wk_new;
-        if constexpr (k + 1 < n) {
-            S.ex[bn][lane] = w[k + 1];
-            SFOR(tt, 0, NB, { cr[bn][tt] = S.ex[bn][L + 16 * tt]; });
-            dd[bn] = S.ex[bn][k + 1];
-        }
-        SFOR(tt, 0, NB, { if constexpr (tt != bf) rank1bc16(&w[16 * tt], negt, cr[b][tt]); });
-        if constexpr (k / 16 != bf) w[k] = wk_new;
-    });
-    if (!__all(ok)) return 0;
-    __syncthreads();
-    SFOR(c, 0, n, { S.G[c * DN + lane] = -w[c]; });   // G, row `lane` (= column `lane`)
     // element state of this lane's input
-    const int kj = lane >> 2, aj = lane & 3;
     const bool real = lane < nr;
-    const size_t e = i4(P, t, imin(kj, head - 1), aj);
-    const double v0 = real ? gm(P.v)[e] : 0.0;
-    const double uk = real ? gm(P.uit)[e] : 0.0;
     const double lb = real ? P.u_min - uk : -1e300, ub = real ? P.u_max - uk : 1e300;
     int cls = v0 < lb ? 1 : (v0 > ub ? 2 : 0);
     double c = cls == 1 ? lb - v0 : (cls == 2 ? ub - v0 : 0.0);
     double delta = 0.0;
+    const unsigned long long realmask = nr >= 64 ? ~0ull : ((1ull << nr) - 1ull);
+    unsigned long long swept = 0ull;
+    bool ok = true;
     int solves = 0;
     bool done = false;
     for (int it = 1; it <= AS_MAX_SOLVES_DENSE && !done; it++) {
         solves = it;
         const bool act = cls != 0;
-        const unsigned long long mask = __ballot(act);
-        const int nA = __popcll(mask);
-        const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-        double dl = 0.0, grad = 0.0;
-        if (nA <= 16) {
-            // The usual case -- a handful of active inputs -- entirely in registers: every 16-lane DPP row holds a copy of the
-            // small system (lane L: row L of G_AA, the active inputs in lane order; rows behind the set: identity), the pivot
-            // column of a Gauss-Jordan step is the lanes' own element (symmetry of the trailing block) and reaches the others
-            // as a DPP broadcast source -- no LDS exchange, no barrier.
-            int ix[16];                      // the active inputs (wave-uniform: scalar registers)
-            {
-                unsigned long long m2 = mask;
-                SFOR(s2, 0, 16, { ix[s2] = m2 ? (int)__builtin_ctzll(m2) : 0; m2 &= m2 - 1ull; });
-            }
-            const int L = lane & 15;
-            int myvar = 0;
-            SFOR(s2, 0, 16, { myvar = (L == s2) ? ix[s2] : myvar; });
-            double ws[16];
-            SFOR(s2, 0, 16, {
-                const double g = S.G[ix[s2] * DN + myvar];
-                ws[s2] = (L < nA && s2 < nA) ? g : ((L == s2) ? 1.0 : 0.0);
-            });
-            double rhs = __shfl(c, myvar);
-            rhs = L < nA ? rhs : 0.0;
-            double dinv = 1.0;
-            SFOR(j, 0, 16, {
-                double col = ws[j];
-                asm volatile("" : "+v"(col));          // (a register of its own: the block below rewrites ws[j] while reading col)
-                const double d = bc<j>(col);
-                const double rj = bc<j>(rhs);
-                ok = ok && (d > 0.0);
+        const unsigned long long free_now = realmask & ~__ballot(act);
+        const unsigned long long chg = swept ^ free_now;
+        // (straight-line walk over the n unrolled sweep bodies with a wave-uniform skip each.  Measured alternatives, both slower by
+        //  ~14 us per row because the register allocator then spills the rows: a loop over the due indices with a binary dispatch
+        //  to the body, and prefetching the next pivot column inside the previous sweep)
+        SFOR(k, 0, n, {
+            if ((chg >> k) & 1ull) {
+                const bool rev = !((free_now >> k) & 1ull);          // the input became active: take it out of the swept set
+                const double col = w[k];
+                double creg[NB];
+                SFOR(tt, 0, NB, { creg[tt] = __shfl(col, L + 16 * tt); });
+                const double d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(col), k), __builtin_amdgcn_readlane(__double2loint(col), k));
+                ok = ok && (rev ? (d < 0.0) : (d > 0.0));
                 const double rinv = rcp_nr(d);
-                const double mj = (L == j) ? 0.0 : col * rinv;
-                dinv = (L == j) ? rinv : dinv;
-                const double negm = -mj;
-                rank1bc16(&ws[0], negm, col);
-                rhs = __builtin_fma(negm, rj, rhs);
-            });
-            if (!__all(ok)) return 0;
-            const double y = rhs * dinv;     // lane L of every DPP row: y of the L-th active input
-            // delta = G[:, A] y ; multiplier of a fixed input = its y
-            SFOR(s2, 0, 16, {
-                const double g = S.G[ix[s2] * DN + lane];
-                const double ys = bc<s2>(y);
-                dl = __builtin_fma(s2 < nA ? g : 0.0, ys, dl);
-            });
-            grad = __shfl(y, rank & 15);
-        } else {
-            // more than sixteen active inputs (the hard rows): the same elimination with the pivot column exchanged through LDS
-            // (lane r < nA: row r of G_AA; one wavefront: LDS operations execute in program order)
-            if (act) { S.idx[rank] = lane; }
-            S.cv[lane] = c;
-            const int myvar = lane < nA ? S.idx[lane] : 0;
-            double y = 0.0;
-            auto small = [&](auto nba_) {
-                constexpr int NBA = decltype(nba_)::value;
-                constexpr int m = 16 * NBA;
-                double ws[m];
-                SFOR(s, 0, m, {
-                    const int var = S.idx[s < nA ? s : 0];               // (uniform)
-                    const double g = S.G[var * DN + myvar];
-                    ws[s] = (lane < nA && s < nA) ? g : ((lane == s) ? 1.0 : 0.0);
-                });
-                double rhs = lane < nA ? S.cv[myvar] : 0.0;
-                double dinv = 1.0;
-                SFOR(j, 0, m, {
-                    if (j < nA) {        // (the rows behind the set are identity rows: nothing to eliminate)
-                        double creg[NBA];
-                        S.ex[j & 1][lane] = ws[j];
-                        S.rx[j & 1][lane] = rhs;
-                        SFOR(tt, j / 16, NBA, { creg[tt] = S.ex[j & 1][(lane & 15) + 16 * tt]; });
-                        const double d = S.ex[j & 1][j], rj = S.rx[j & 1][j];
-                        ok = ok && (d > 0.0);
-                        const double rinv = rcp_nr(d);
-                        const double mj = (lane == j) ? 0.0 : ws[j] * rinv;
-                        dinv = (lane == j) ? rinv : dinv;
-                        const double negm = -mj;
-                        SFOR(tt, j / 16, NBA, { rank1bc16(&ws[16 * tt], negm, creg[tt]); });
-                        rhs = __builtin_fma(negm, rj, rhs);
-                    }
-                });
-                y = rhs * dinv;
-            };
-            if (nA <= 32) { if constexpr (NB >= 2) small(std::integral_constant<int, 2>{}); }
-            else if (nA <= 48) { if constexpr (NB >= 3) small(std::integral_constant<int, 3>{}); }
-            else { if constexpr (NB >= 4) small(std::integral_constant<int, 4>{}); }
-            if (!__all(ok)) return 0;
-            S.rx[0][lane] = y;      // y_r of the r-th active input (lanes >= nA: 0)
-            for (int s0 = 0; s0 < nA; s0 += 8) {      // delta = G[:, A] y, eight terms per batch (loads first)
-                int iv[8]; double gv[8], yv[8];
-                SFOR(q, 0, 8, { iv[q] = S.idx[imin(s0 + q, nA - 1)]; });
-                SFOR(q, 0, 8, { gv[q] = S.G[iv[q] * DN + lane]; yv[q] = S.rx[0][imin(s0 + q, nA - 1)]; });
-                SFOR(q, 0, 8, { dl = __builtin_fma(s0 + q < nA ? gv[q] : 0.0, yv[q], dl); });
+                const double tk = col * rinv;
+                const double ti = (lane == k) ? (rev ? 1.0 + rinv : 1.0 - rinv) : tk;   // lane k: its own row ends as +- row / d
+                const double negt = -ti;
+                SFOR(tt, 0, NB, { rank1bc16(&w[16 * tt], negt, creg[tt]); });
+                w[k] = (lane == k) ? -rinv : (rev ? -tk : tk);
             }
-            grad = S.rx[0][rank];
-        }
+        });
+        swept = free_now;
+        if (!ok) return 0;
+        // val = W[:, A] c_A
+        const double cc = act ? c : 0.0;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        SFOR(tt, 0, NB, {
+            const double cr = __shfl(cc, L + 16 * tt);
+            dot16bc4(acc, &w[16 * tt], cr);
+        });
+        const double val = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        const double dl = act ? c : -val;
         delta = dl;
-        grad = act ? grad : 0.0;
         const double vn = v0 + dl;
         int nc;
         if (cls == 0) nc = vn < lb ? 1 : (vn > ub ? 2 : 0);
-        else if (cls == 1) nc = grad > 0.0 ? 1 : 0;
-        else nc = grad < 0.0 ? 2 : 0;
+        else if (cls == 1) nc = val > 0.0 ? 1 : 0;       // multiplier of a fixed input: stays while it pushes outward
+        else nc = val < 0.0 ? 2 : 0;
         const bool changed = __any(real && nc != cls);
         cls = real ? nc : 0;
         c = cls == 1 ? lb - v0 : (cls == 2 ? ub - v0 : 0.0);
@@ -384,6 +292,10 @@ KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
         SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
         // every DPP row of the wave addresses the same instance (the stage matrices are broadcast sources inside a row)
         const Lane t = lane_indirect(P, inst, true);
+        // this lane's input (k_j, a_j): unconstrained minimiser and iterate, in flight during the build
+        const size_t e4 = i4(P, t, imin(lane >> 2, head - 1), lane & 3);
+        const double v0 = lane < 4 * head ? gm(P.v)[e4] : 0.0;
+        const double uk = lane < 4 * head ? gm(P.uit)[e4] : 0.0;
         __syncthreads();
         dense_stage(P, t, head, chk, S.G, S.pm);
         __syncthreads();
@@ -393,18 +305,33 @@ KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
         __syncthreads();
         DPROF(1)
         int solves;
-        if (head <= 4) solves = dense_solve<1>(P, t, head, S);
-        else if (head <= 8) solves = dense_solve<2>(P, t, head, S);
-        else if (head <= 12) solves = dense_solve<3>(P, t, head, S);
-        else solves = dense_solve<4>(P, t, head, S);
+        if (head <= 4) solves = dense_solve<1>(P, head, v0, uk, S);
+        else if (head <= 8) solves = dense_solve<2>(P, head, v0, uk, S);
+        else if (head <= 12) solves = dense_solve<3>(P, head, v0, uk, S);
+        else solves = dense_solve<4>(P, head, v0, uk, S);
         DPROF(2)
         if (solves > 0) {
             // du of the head -> the compact slot's P.dva; dx_1 .. dx_head -> P.czdx (what k_ascommit reads)
             const double dl = S.cv[lane];
             if (lane < 4 * head) gm(P.dva)[(size_t)slot * N * 4 + lane] = dl;
+            // the stage matrices once more (the H store is free again): staged with all loads in flight, then the sequential sweep
+            __syncthreads();
+            {
+                StageOps o[4];
+                SFOR(b, 0, 4, { load_ops(P, t, imin(4 * b + t.row, head - 1), o[b]); });
+                SFOR(b, 0, 4, {
+                    const int k = 4 * b + t.row;
+                    if (k < head) {
+                        double* d = S.G + k * ST_BLK + t.L * ST_ROW;
+                        SFOR(g, 0, 10, { d[g] = o[b].ac[g]; });
+                        SFOR(a, 0, 4, { d[10 + a] = o[b].br[a]; });
+                    }
+                });
+            }
+            __syncthreads();
             double x = 0.0;
             StageOps o0, o1;
-            load_ops(P, t, 0, o0);
+            lds_ops(S.G, t, 0, o0);
             auto step = [&](const StageOps& o, const int k) {
                 double xn = t.L < 3 ? x : 0.0;
                 dotbc<10, 3>(xn, o.ac, x);
@@ -413,10 +340,10 @@ KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
                 if (t.row == 0 && t.L < 13) gm(P.czdx)[((size_t)slot * (N + 1) + k + 1) * 13 + t.L] = x;
             };
             for (int k = 0; k < head; k += 2) {
-                load_ops(P, t, imin(k + 1, head - 1), o1);
+                lds_ops(S.G, t, imin(k + 1, head - 1), o1);
                 step(o0, k);
                 if (k + 1 >= head) break;
-                load_ops(P, t, imin(k + 2, head - 1), o0);
+                lds_ops(S.G, t, imin(k + 2, head - 1), o0);
                 step(o1, k + 1);
             }
         }
