@@ -2380,6 +2380,9 @@ __global__ __launch_bounds__(64) void k_asp_all(Params P) {
 // Settled rows: new iterate = candidate (start solve) + delta.  One wave = four consecutive compact slots.
 // DEEP: three rotating stage buffers in the tail loop (one wave per SIMD: small fleets, where the tail is a
 // latency chain); otherwise two (two waves per SIMD: large fleets, where it is bound by the home blocks' bytes).
+#ifndef CFN_COMMIT_DEPTH
+#define CFN_COMMIT_DEPTH 3
+#endif
 template <bool DEEP>
 __device__ __forceinline__ void ascommit_body(const Params& P) {
     const int nipm = gm(P.nipm)[0];
@@ -2472,20 +2475,21 @@ __device__ __forceinline__ void ascommit_body(const Params& P) {
             }
         }
         if (hmin < N && DEEP) {
-            In b0, b1, b2;
-            load(hmin, b0);
-            load(imin(hmin + 1, N - 1), b1);
+            // CFN_COMMIT_DEPTH rotating stage buffers: the loads of stage k + DEPTH - 1 are issued before the arithmetic of stage k
+            // (one wave per SIMD, the home blocks of a constrained row come from HBM / MALL: ~1 - 2 us per round trip against
+            // ~0.15 us of arithmetic per stage)
+            constexpr int D = CFN_COMMIT_DEPTH;
+            In b[D];
+            SFOR(j, 0, D - 1, { load(imin(hmin + j, N - 1), b[j]); });
             int k = hmin;
             while (k < N) {
-                load(imin(k + 2, N - 1), b2);
-                body(b0, k);
-                if (++k >= N) break;
-                load(imin(k + 2, N - 1), b0);
-                body(b1, k);
-                if (++k >= N) break;
-                load(imin(k + 2, N - 1), b1);
-                body(b2, k);
-                ++k;
+                SFOR(j, 0, D, {
+                    if (k < N) {
+                        load(imin(k + D - 1, N - 1), b[(j + D - 1) % D]);
+                        body(b[j], k);
+                        ++k;
+                    }
+                });
             }
         }
         kviol = (int)row_max((double)kviol);
