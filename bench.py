@@ -350,13 +350,14 @@ def mixed_horizon_run(batch, dev, rng, steps, warmup, predictor="queued"):
     return out
 
 
-def timed_run(fleet, steps, warmup, barrier):
+def timed_run(fleet, steps, warmup, barrier, profile=True):
     """W untimed + exactly K timed steps between barrier + synchronize; the step's kernels are
     bracketed by HIP events on the launch stream during the SAME K steps (cfnmpc_set_profiling).
+    profile = False: no events in the timed region (the per-kernel split is then all zeros).
     -> (elapsed seconds, ms linearise, ms qp, stats of the last step)"""
     for _ in range(warmup):
         fleet.step()
-    fleet.solver.set_profiling(True)
+    fleet.solver.set_profiling(bool(profile))
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -408,6 +409,7 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak"], default=None,
                     help="strong (default for N > 1): --batch instances split over the GPUs; weak: --batch per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="no HIP events around the kernels of the timed steps (roofline fields from kernel time are then void)")
     ap.add_argument("--no-extras", action="store_true", help="skip the sensitivity runs (and the weak run beside a strong one)")
     ap.add_argument("--active-horizon", type=int, default=1)
     ap.add_argument("--active-set", type=int, default=1)
@@ -489,12 +491,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(batch_rank, steps, warmup, workload=args.workload, kick_scale=args.kick_scale, seed_off=0, **kw):
+    def measure(batch_rank, steps, warmup, workload=args.workload, kick_scale=args.kick_scale, seed_off=0, profile=True, **kw):
         """One closed-loop run of `batch_rank` vehicles on this rank; aggregated over ranks."""
         okw = dict(opt_kw); okw.update(kw)
         fleet = Fleet(batch_rank, dev, np.random.default_rng(seed + 1000 * seed_off), workload, kick_scale, **okw)
         torch.cuda.synchronize(dev)
-        elapsed, ms_lin, ms_qp, st = timed_run(fleet, steps, warmup, barrier)
+        elapsed, ms_lin, ms_qp, st = timed_run(fleet, steps, warmup, barrier, profile and not args.no_profile)
+        if not profile and not args.no_profile:
+            # (sensitivity runs: the K timed steps carry NO events -- seven event records per step cost ~30 us, 4 - 8 % of a step
+            #  at 2048 - 8192 instances, 0.5 % at 65 536 --; the per-kernel split comes from 10 more steps with them)
+            _el, ms_lin, ms_qp, st2 = timed_run(fleet, 10, 0, barrier, True)
+            st["kms"] = st2["kms"]
         fleet.close()
         del fleet
         torch.cuda.empty_cache()
@@ -571,10 +578,13 @@ def main():
         B_rank = hi - lo
     else:
         B_rank = args.batch
-    main_run = measure(B_rank, args.steps, args.warmup)
+    # N = 1: HIP events around the kernels of the K timed steps themselves (the roofline's kernel time is measured over the timed
+    # region).  N > 1: the timed steps carry no events -- seven records per step cost ~30 us, 4 % of a step at the 8192 instances
+    # per GPU of the 8-GPU split -- and the per-kernel split comes from 10 more steps with them (roofline.kernel_ms_source)
+    main_run = measure(B_rank, args.steps, args.warmup, profile=(world == 1))
     weak = None
     if world > 1 and scaling == "strong" and not args.no_extras:
-        weak = measure(args.batch, args.steps, args.warmup, seed_off=1)
+        weak = measure(args.batch, args.steps, args.warmup, seed_off=1, profile=False)
 
     extras = {}
     if world == 1 and not args.no_extras and args.batch == TOTAL_BATCH and args.workload == "hover" and args.kick_scale == 1.0 \
@@ -582,19 +592,19 @@ def main():
         ws = min(args.warmup, 20)
 
         def brief(r):
-            return {"value": r["value"], "ms_per_step": r["ms_per_step"], "kernel_ms": r["ms_lin"] + r["ms_qp"],
+            return {"value": r["value"], "ms_per_step": r["ms_per_step"], "kernel_ms": r["ms_lin"] + r["ms_qp"],   # (kernel_ms: 10 steps WITH events after the timed ones)
                     "frac_constrained": r["frac_constrained"], "mean_qp_solves": r["mean_qp_solves"], "status_ok_frac": r["ok_frac"]}
-        extras["interior_point_only (active_set=0)"] = brief(measure(B_rank, 20, ws, active_set=0, seed_off=2))
-        extras["kick_scale_x2"] = brief(measure(B_rank, 20, ws, kick_scale=2.0, seed_off=3))
-        extras["kick_scale_x3"] = brief(measure(B_rank, 20, ws, kick_scale=3.0, seed_off=4))
+        extras["interior_point_only (active_set=0)"] = brief(measure(B_rank, 20, ws, active_set=0, seed_off=2, profile=False))
+        extras["kick_scale_x2"] = brief(measure(B_rank, 20, ws, kick_scale=2.0, seed_off=3, profile=False))
+        extras["kick_scale_x3"] = brief(measure(B_rank, 20, ws, kick_scale=3.0, seed_off=4, profile=False))
         # cfnmpc_opts.reinit_failed: vehicles whose QP failed (status 4) restart from their current state instead of keeping
         # the iterate that failed -- NOT the reference's behaviour (its node ignores the status), reported beside it
-        extras["kick_scale_x2 + reinit_failed"] = brief(measure(B_rank, 20, ws, kick_scale=2.0, seed_off=3, reinit_failed=1))
-        extras["kick_scale_x3 + reinit_failed"] = brief(measure(B_rank, 20, ws, kick_scale=3.0, seed_off=4, reinit_failed=1))
-        extras["full_horizon_sweeps (active_horizon=0)"] = brief(measure(B_rank, 20, ws, active_horizon=0, seed_off=5))
-        extras["config_C2_batch_4096"] = brief(measure(4096, 40, 40, seed_off=6))
-        extras["batch_8192 (one GPU's share of 65536 at 8 GPUs)"] = brief(measure(8192, 40, 40, seed_off=7))
-        extras["config_C4_figure8_tracking"] = brief(measure(B_rank, 20, ws, workload="figure8", seed_off=8))
+        extras["kick_scale_x2 + reinit_failed"] = brief(measure(B_rank, 20, ws, kick_scale=2.0, seed_off=3, reinit_failed=1, profile=False))
+        extras["kick_scale_x3 + reinit_failed"] = brief(measure(B_rank, 20, ws, kick_scale=3.0, seed_off=4, reinit_failed=1, profile=False))
+        extras["full_horizon_sweeps (active_horizon=0)"] = brief(measure(B_rank, 20, ws, active_horizon=0, seed_off=5, profile=False))
+        extras["config_C2_batch_4096"] = brief(measure(4096, 40, 40, seed_off=6, profile=False))
+        extras["batch_8192 (one GPU's share of 65536 at 8 GPUs)"] = brief(measure(8192, 40, 40, seed_off=7, profile=False))
+        extras["config_C4_figure8_tracking"] = brief(measure(B_rank, 20, ws, workload="figure8", seed_off=8, profile=False))
         extras["config_C5_mixed_horizons_30_50_100_delay_compensated"] = mixed_horizon_run(B_rank, dev, np.random.default_rng(seed + 9000), 20, ws)
         extras["config_C5_mixed_horizons_30_50_100_delay_compensated"]["predictor"] = (
             "x0 = RK4 prediction over the 60 ms delay THROUGH THE FOUR QUEUED INPUTS (oldest first); the reference's estimator holds the "
@@ -654,6 +664,8 @@ def main():
                          "achieved": ach / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": traffic, "traffic_source": tsrc,
                          "alg_bytes_per_launch": alg_bytes_step(N) * B_launch, "kernel_ms": ms_step,
+                         "kernel_ms_source": ("HIP events on the launch stream over the K timed steps" if world == 1 and not args.no_profile else
+                                              "10 steps with HIP events AFTER the K timed steps (which carry none)"),
                          "kernel_ms_within_step": kernel_time_consistent,
                          "linearise_ms": r["ms_lin"], "qp_ms": r["ms_qp"],
                          # the same K timed steps per kernel group (seven HIP events per step on the launch stream)
