@@ -421,6 +421,7 @@ def main():
                                                                 "-3 solves + commit kernel, -2 / 1..12 instance-contiguous store / level-synchronous passes)")
     ap.add_argument("--as-warm", type=int, default=None, help="cfnmpc_opts.as_warm (warm start of the active set from the previous RTI step)")
     ap.add_argument("--as-dense", type=int, default=None, help="cfnmpc_opts.as_dense (head-condensed dense active-set solves: 1 on, -1 off, 0 auto)")
+    ap.add_argument("--forward-split", type=int, default=None, help="cfnmpc_opts.forward_split (1 on, -1 off, 0 auto)")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="nccl = RCCL over xGMI (default); gloo only for functional checks of the N > 1 path on "
                          "a box with fewer GPUs than ranks (ranks then share devices)")
@@ -482,7 +483,7 @@ def main():
     opt_kw = dict(active_horizon=args.active_horizon, active_set=args.active_set)
     for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2),
                  ("step_graph", args.step_graph), ("forward_sweep", args.forward_sweep), ("as_passes", args.as_passes),
-                 ("start_solve", args.start_solve), ("as_warm", args.as_warm), ("as_dense", args.as_dense)):
+                 ("start_solve", args.start_solve), ("as_warm", args.as_warm), ("as_dense", args.as_dense), ("forward_split", args.forward_split)):
         if v is not None:
             opt_kw[k] = v
 

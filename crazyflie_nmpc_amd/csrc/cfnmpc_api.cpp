@@ -96,15 +96,19 @@ constexpr size_t EV_PER_STEP = 7;
 //     (round 5, one box, A/B per size: 2 S +20.6 %, 4 S +8.5 %, 8 S +9.6 %, 12 S +1.8 %, 16 S +1.1 %, 20 S -1.8 %, 24 S -1.4 %,
 //     28 S -0.5 %, 32 S -5 %: one row per wavefront and SIMD -- while the ~8 % constrained rows fit the SIMDs once the kernel lasts
 //     as long as its hardest row, 50 - 90 us instead of 220; beyond that its ~47 us per row are rounds of waves and the four
-//     rows per wavefront of k_as_solves / k_as win on throughput), profiles/r05_as_dense.md.
-struct Choice { bool forward_rg, as_commit, ipm_listed, as_dense; };
+//     rows per wavefront of k_as_solves / k_as win on throughput), profiles/r05_as_dense.md;
+//   * split forward sweep (k_forward_p1 | k_forward_p2 beside the constrained rows' kernels): wherever that structure runs with the
+//     matrix-free sweep (one box: 6144 instances +3.5 % against the unsplit matrix-free sweep and +2 % against the row-group one,
+//     8192: +7.2 %, 12 288: +1.2 %, 16 384: +0.7 %; at 4096 the row-group sweep stays ahead, 7.33 against 6.75 M).
+struct Choice { bool forward_rg, as_commit, ipm_listed, as_dense, forward_split; };
 inline Choice choose_kernels(int batch, int N, int simds) {
     const long S = simds > 0 ? simds : 1024;
     Choice c;
-    c.forward_rg = (long)batch < (N <= 64 ? 8 : 6) * S;
+    c.forward_rg = (long)batch < 6 * S;   // (round 5: 8 S -> 6 S for N <= 64 too -- the split matrix-free sweep beats the row-group one from 6 S on: 9.37 against 9.18 M at 6144 instances)
     c.as_commit = (long)batch < (N <= 40 ? 20 : 36) * S;
     c.ipm_listed = (long)batch >= 16 * S;
     c.as_dense = (long)batch < 18 * S;
+    c.forward_split = true;
     return c;
 }
 
@@ -212,6 +216,7 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->start_solve = 0;
     o->as_warm = 0;
     o->as_dense = 0;
+    o->forward_split = 0;
 }
 
 int cfnmpc_default_opts_v(cfnmpc_opts* o, int sizeof_opts) {
@@ -358,6 +363,14 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
         if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ef, hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&ej, hipEventDisableTiming) == hipSuccess) {
             P.as_side = side; P.as_fork = ef; P.as_join = ej;
+            hipStream_t side2 = nullptr;
+            hipEvent_t ej2 = nullptr;
+            if (hipStreamCreateWithFlags(&side2, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&ej2, hipEventDisableTiming) == hipSuccess) {
+                P.as_side2 = side2; P.as_join2 = ej2;
+            } else {
+                if (side2) (void)hipStreamDestroy(side2);
+                (void)hipGetLastError();
+            }
         } else {
             if (side) (void)hipStreamDestroy(side);
             if (ef) (void)hipEventDestroy(ef);
@@ -375,6 +388,10 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
         P.fused = o.start_solve == 2 ? 1 : (o.start_solve == 3 ? 2 : 0);
         P.clist_chunks = o.N >= 10 ? 10 : o.N;
     }
+    // split forward sweep: lives in the dense structure (two side streams), matrix-free sweep, horizons that reach well behind H
+    if (o.forward_split < -1 || o.forward_split > 1) { cfnmpc_free(s); return CFNMPC_EINVAL; }
+    P.fwd_split = (P.as_dense && P.as_side2 && !P.forward_rg && !cond_N2 && P.fused == 0 && o.N >= 40 && o.forward_split != -1 &&
+                   (o.forward_split == 1 || pick.forward_split)) ? 24 : 0;
     P.cond_N2 = cond_N2;
     P.v4b = cond_N2 ? 0 : 1;   // home 4-vectors wave-blocked (the condensed kernels index theirs instance-major)
     P.cond_M = cond_N2 ? o.N / cond_N2 : 0;
@@ -404,6 +421,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(ascnt, 32); ALLOC(askst, NW * 4); ALLOC(asst, NW * 4); ALLOC(asok, NW * 4);
     ALLOC(czdx, NW * 4 * (N + 1) * 13);
     if (P.as_warm) { ALLOC(wcls, NW * 4 * N * 4); ALLOC(wvalid, NW * 4); }
+    if (P.fwd_split) { ALLOC(fs_dx, ((size_t)(batch + 63) / 64) * 13 * 64); ALLOC(fs_st, ((size_t)(batch + 63) / 64) * 4 * 64); }
     if (P.as_passes != 0) ALLOC(aslist, (size_t)3 * 7 * NW * 4);
     if (cond_N2) ALLOC(cb, NW * 4 * (size_t)cond_N2 * cfn::cb_size(cfn::cond_mmax(P)));
     if (s->overlap) {
@@ -432,6 +450,11 @@ int cfnmpc_free(cfnmpc_solver* s) {
     if (!s) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
     if (s->aux) { (void)hipStreamSynchronize(s->aux); (void)hipStreamDestroy(s->aux); }
+    if (s->P.as_side2) {
+        (void)hipStreamSynchronize((hipStream_t)s->P.as_side2);
+        (void)hipStreamDestroy((hipStream_t)s->P.as_side2);
+        (void)hipEventDestroy((hipEvent_t)s->P.as_join2);
+    }
     if (s->P.as_side) {
         (void)hipStreamSynchronize((hipStream_t)s->P.as_side);
         (void)hipStreamDestroy((hipStream_t)s->P.as_side);

@@ -785,7 +785,13 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
 // the home 4-vectors are wave-blocked it is also the faster form where the sweep streams at the HBM rate (32 768 instances
 // 0.281 -> 0.254 ms, 65 536: equal), so every matrix-free sweep uses it.  (Rounds 2 - 3 kept a second form with the model's
 // rotor terms as four FP64 divisions for the large fleets; removed.)
-template <bool COND, bool FUSED_PT = false>
+// SPLIT (small fleets, cfnmpc_opts.forward_split): the sweep in two launches -- 1: stages [0, H) with the
+// classification over that window (violations, tight stages, head class, compaction ranks), hand-over of dx_H and the
+// classification state in P.fs_dx / P.fs_st; 2: stages [H, N) for every instance, run BESIDE the constrained rows' QP kernels
+// (whose heads of at most H stages read nothing behind H).  An instance that is feasible over [0, H) and violates a bound
+// behind H is a LATE row: part 2 appends it to the compacted list behind its end (P.nipm[42] counts them) with the head its
+// tight stages ask for and the flag k_as_retry picks up (P.done = 2).
+template <bool COND, bool FUSED_PT = false, int SPLIT = 0>
 __device__ __forceinline__ void forward_body(const Params& P, double* xs, double* cs, int* sflag) {
     // 13-vectors travel through LDS tiles [instance][13] so that every global access of the wave
     // is a contiguous run (as in k_linearise); K, d, u, v are 32-byte runs per lane already.
@@ -822,8 +828,24 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         SFOR(l, 0, 13, { SFOR(a, 0, 4, { in.K[a][l] = kp[(size_t)k * SZ_K + l * 16 + a]; }); });
         SFOR(a, 0, 4, { in.d[a] = gm(P.d)[i4b + (size_t)k * i4s + a]; in.u[a] = gm(P.uit)[i4b + (size_t)k * i4s + a]; });
     };
+    const int H = SPLIT ? P.fwd_split : 0;
+    const int k_lo = SPLIT == 2 ? H : 0, k_hi = SPLIT == 1 ? H : N;
     double dx[13];   // internal order
-    {
+    double viol = 0.0;
+    int last_tight = -1, nviol = 0;
+    bool sawnan = false;
+    bool early_infeasible = false, early_bad = false;   // SPLIT == 2: what part one decided
+    if constexpr (SPLIT == 2) {
+        // hand-over of part one: dx_H and the classification state, [group][13 | 4][64 lanes]
+        const gdouble* hx = gm(P.fs_dx) + (size_t)blockIdx.x * 13 * 64 + tid;
+        SFOR(i, 0, 13, { dx[i] = hx[i * 64]; });
+        const gint* hs = gm(P.fs_st) + (size_t)blockIdx.x * 4 * 64 + tid;
+        early_infeasible = hs[0] != 0; early_bad = hs[64] != 0;
+        double r1[13];
+        issue13(P.xit, N + 1, k_lo, tid, r1);
+        land13(xs, r1);
+        __syncthreads();
+    } else {
         double r0[13], r1[13];
         issue13(P.x0, 1, 0, tid, r0);
         issue13(P.xit, N + 1, 0, tid, r1);
@@ -833,14 +855,11 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         SFOR(i, 0, 13, { dx[i] = cs[tid * 13 + i] - xs[tid * 13 + i]; });
         __syncthreads();
     }
-    double viol = 0.0;
-    int last_tight = -1, nviol = 0;
-    bool sawnan = false;
     In cur, nxt;
-    load(0, cur);
+    load(k_lo, cur);
     double dxb[13];            // COND: state step at the start of the current block
     int knext = 0, jblk = 0;   // COND: first stage and index of the next block
-    for (int k = 0; k < N; k++) {
+    for (int k = k_lo; k < k_hi; k++) {
         int tl = tid;   // opaque per-stage copy (keeps the transfer offsets out of loop-invariant registers)
         asm volatile("" : "+v"(tl));
         if constexpr (COND) if (k == knext) {
@@ -947,12 +966,57 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         SFOR(i, 0, 13, { dx[i] = dxp[i] - xs[tid * 13 + i]; });
         cur = nxt;
     }
+    if (sawnan) viol = nan("");
+    if constexpr (SPLIT == 1) {
+        // ---- part one: classification over [0, H), hand-over; no terminal candidate, no restoration (part two restores the
+        //      whole horizon of a failed instance -- nobody reads its new iterate in between: it is in no list)
+        const bool okf = valid && gm(P.status)[imin(raw, P.B - 1)] == 0;
+        const bool bad = valid && (!okf || !(viol == viol));
+        const bool infeasible = valid && !bad && (viol > 0.0);
+        gdouble* hx = gm(P.fs_dx) + (size_t)blockIdx.x * 13 * 64 + tid;
+        SFOR(i, 0, 13, { hx[i * 64] = dx[i]; });
+        gint* hs = gm(P.fs_st) + (size_t)blockIdx.x * 4 * 64 + tid;
+        hs[0] = infeasible ? 1 : 0; hs[64] = bad ? 1 : 0;
+        if (valid) {
+            gm(P.viol)[inst] = infeasible ? viol : 0.0;
+            gm(P.status)[inst] = bad ? 4 : 0;
+            gm(P.iters)[inst] = 0;
+            gm(P.res)[inst] = bad ? nan("") : 0.0;
+            gm(P.head)[inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
+            if (P.as_warm && !infeasible) gm(P.wvalid)[inst] = 0;
+        }
+        const int hc = infeasible ? head_cls(P, head_class(P, last_tight + 1 + P.ah_extra)) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
+        const unsigned long long below = (1ull << tid) - 1ull;
+        SFOR(c, 0, N_BIN, {
+            const unsigned long long m = __ballot(hc == c);
+            if (hc == c) gm(P.rank)[inst] = (c << 8) | __popcll(m & below);
+            if (tid == c) gm(P.blkcnt)[blockIdx.x * BIN_STRIDE + c] = __popcll(m);
+        });
+        return;
+    }
     // candidate of the terminal stage (xs holds x_N)
     SFOR(i, 0, 13, { cs[tid * 13 + i] = xs[tid * 13 + i] + dx[i]; });
-    if (sawnan) viol = nan("");
-    const bool okf = valid && gm(P.status)[imin(raw, P.B - 1)] == 0;
-    const bool bad = valid && (!okf || !(viol == viol));
-    const bool infeasible = valid && !bad && (viol > 0.0);
+    bool bad, infeasible;
+    if constexpr (SPLIT == 2) {
+        // ---- part two: an instance that failed here only (non-finite candidate behind H; it was feasible and healthy before)
+        //      fails as a whole; one that was feasible over [0, H) and leaves the box behind H is a LATE row
+        const bool bad2 = valid && !early_bad && !early_infeasible && !(viol == viol);
+        bad = early_bad || bad2;
+        infeasible = false;   // (nothing of part one's classification is rewritten)
+        const bool late = valid && !bad && !early_infeasible && (viol > 0.0);
+        if (bad2) { gm(P.status)[inst] = 4; gm(P.res)[inst] = nan(""); }
+        if (late) {
+            gm(P.viol)[inst] = viol;
+            gm(P.head)[inst] = head_class(P, last_tight + 1 + P.ah_extra);
+            gm(P.done)[inst] = 2;                                   // k_as_retry solves it (the interior point what that leaves)
+            const int pos = atomicAdd(P.nipm + 42, 1);
+            gm(P.ilist)[gm(P.nipm)[0] + pos] = inst;
+        }
+    } else {
+        const bool okf = valid && gm(P.status)[imin(raw, P.B - 1)] == 0;
+        bad = valid && (!okf || !(viol == viol));
+        infeasible = valid && !bad && (viol > 0.0);
+    }
     sflag[tid] = bad ? 1 : 0;
     __syncthreads();
     {
@@ -960,6 +1024,7 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         SFOR(j, 0, 13, { cv[j] = cs[tid + 64 * j]; });
         SFOR(j, 0, 13, { *el13(P.xitn, tid + 64 * j, N + 1, N) = cv[j]; });
     }
+    if constexpr (SPLIT == 0) {
     if (valid) {
         gm(P.viol)[inst] = infeasible ? viol : 0.0;
         gm(P.status)[inst] = bad ? 4 : 0;
@@ -979,6 +1044,7 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
             if (hc == c) gm(P.rank)[inst] = (c << 8) | __popcll(m & below);
             if (tid == c) gm(P.blkcnt)[blockIdx.x * BIN_STRIDE + c] = __popcll(m);
         });
+    }
     }
     // The candidate went straight into the NEW iterate buffers (P.xitn, P.uitn; the host swaps the
     // buffers after the step), so instances whose unconstrained minimiser is feasible are done.
@@ -1015,6 +1081,18 @@ __global__ __launch_bounds__(64, 2) void k_forward_half(Params P) {
     forward_body<false, true>(P, xs, cs, sflag);
 }
 #endif
+KALIGN __global__ __launch_bounds__(64) void k_forward_p1(Params P) {   // split sweep, stages [0, H) + classification
+    __shared__ double xs[64 * 13], cs[64 * 13];
+    __shared__ int sflag[64];
+    forward_body<false, true, 1>(P, xs, cs, sflag);
+}
+KALIGN __global__ __launch_bounds__(64) void k_forward_p2(Params P) {   // split sweep, stages [H, N), late rows
+    __shared__ double xs[64 * 13], cs[64 * 13];
+    __shared__ int sflag[64];
+    forward_body<false, true, 2>(P, xs, cs, sflag);
+}
+// after the commit kernel: the late rows of the split sweep join the list (k_as_retry and the interior point see them)
+__global__ void k_late_fold(Params P) { gm(P.nipm)[0] += gm(P.nipm)[42]; gm(P.nipm)[42] = 0; }
 __global__ __launch_bounds__(64) void k_cforward(Params P) {
     __shared__ double xs[64 * 13], cs[64 * 13];
     __shared__ int sflag[64];
@@ -1169,6 +1247,7 @@ __global__ __launch_bounds__(256) void k_scatter(Params P) {
             // rows whose head is longer than 16 stages come first in the list (bins are ordered by head class, longest first:
             // full horizon, 32, 24 | 16, 12, 8, 4): their number -- the dense active-set kernel (cfnmpc_asdense.hip) takes the rest
             gm(P.nipm)[41] = P.N > 16 ? base[9] : 0;
+            gm(P.nipm)[43] = P.N > 24 ? base[6] : 0;    // ... of more than 24 stages (full horizon, 32): behind part two of a split sweep
         }
     }
     if (blockIdx.x == 0 && P.ascnt && threadIdx.x < 32) gm(P.ascnt)[threadIdx.x] = 0;   // work lists of the active-set passes
@@ -1356,7 +1435,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     // P.nipm[40]): four fall-back rows per wave instead of one row in each of the waves they were scattered over
     const bool listed = MODE == 2 && P.ipm_listed;   // (small fleets skip k_ipm_list: the rows stay where k_as had them)
     // (MODE 4 beside the dense kernel: only the rows with heads of more than 16 stages, the first P.nipm[41] of the list)
-    const int nipm = gm(P.nipm)[listed ? 40 : ((MODE == 4 && P.as_dense) ? 41 : 0)];
+    const int nipm = gm(P.nipm)[listed ? 40 : ((MODE == 4 && P.as_dense) ? (P.as_range == 2 ? 43 : 41) : 0)];
+    const int slot_lo = (MODE == 4 && P.as_dense && P.as_range == 1) ? gm(P.nipm)[43] : 0;   // (first list slot of this launch)
     // SPARSE (active-set kernels, short lists): ONE list slot per wave (row 0; rows 1..3 idle) while the constrained rows
     // number fewer than the SIMDs -- every row then sweeps its own head, restarts at its own stage and stops after its own
     // last solve instead of following the slowest of four wave-mates, and the kernel lasts as long as its hardest ROW.
@@ -1364,8 +1444,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     // mode read each other's results.
     const bool sparse = (MODE == 1 || MODE == 3 || MODE == 4) && nipm <= P.as_sparse_max && nipm <= (int)gridDim.x;
     const int slot = sparse ? vb : vb * 4 + (threadIdx.x >> 4);
-    if ((sparse ? vb : vb * 4) >= nipm) return;  // wave-uniform: no work for this wave
-    bool has = slot < nipm && (!sparse || (threadIdx.x >> 4) == 0);
+    if ((sparse ? vb : vb * 4) >= nipm || (sparse ? vb : vb * 4 + 3) < slot_lo) return;  // wave-uniform: no work for this wave
+    bool has = slot < nipm && slot >= slot_lo && (!sparse || (threadIdx.x >> 4) == 0);
     const int inst0 = has ? gm(listed ? P.ilist2 : P.ilist)[imin(slot, nipm - 1)] : 0;
     constexpr bool AS_ONLY = MODE == 1 || MODE == 3 || MODE == 4;
     constexpr bool NO_ROLL = MODE == 4;   // solves only: roll-out, tail check and publication are left to k_ascommit
@@ -2815,7 +2895,8 @@ void launch_qp_start(const Params& P, hipStream_t st, hipEvent_t* ev, bool skip_
 #ifdef CFN_DEV
         if (P.forward_half) { hipLaunchKernelGGL(k_forward_half, dim3((P.B + 63) / 64), dim3(64), 0, st, P); } else
 #endif
-        hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
+        if (P.fwd_split) hipLaunchKernelGGL(k_forward_p1, dim3((P.B + 63) / 64), dim3(64), 0, st, P);   // part two: launch_qp_ipm
+        else hipLaunchKernelGGL(k_forward, dim3((P.B + 63) / 64), dim3(64), 0, st, P);
     }
     if (ev) (void)hipEventRecord(ev[1], st);
     hipLaunchKernelGGL(k_compact, dim3(N_BIN), dim3(256), 0, st, P);
@@ -2874,10 +2955,23 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         if (P.as_passes == -2 && P.as_dense) {
             // heads of at most 16 stages: head-condensed dense solves (one row per wavefront, one wavefront per SIMD) on the
             // caller's stream; the rows with longer heads (the first P.nipm[41] of the list: none, or a handful) keep the Riccati
-            // form of the iteration in k_as_solves, forked onto the solver's side stream -- two latency chains side by side
-            hipStream_t side = (hipStream_t)P.as_side;
-            if (side) {
-                (void)hipEventRecord((hipEvent_t)P.as_fork, st);
+            // form of the iteration in k_as_solves, forked onto the solver's side stream -- two latency chains side by side.
+            // Split forward sweep: its second part (stages [24, N) of EVERY instance) runs on a second side stream beside both;
+            // rows with heads of 24 stages read nothing behind stage 24 and stay beside it, the rows with longer heads follow it.
+            hipStream_t side = (hipStream_t)P.as_side, side2 = (hipStream_t)P.as_side2;
+            const bool split = P.fwd_split && !P.lbs && !P.forward_rg && side && side2;
+            if (side) (void)hipEventRecord((hipEvent_t)P.as_fork, st);
+            if (split) {
+                Params PA = P, PB = P;
+                PA.as_range = 1; PB.as_range = 2;
+                (void)hipStreamWaitEvent(side2, (hipEvent_t)P.as_fork, 0);
+                hipLaunchKernelGGL(k_forward_p2, dim3((P.B + 63) / 64), dim3(64), 0, side2, P);
+                hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, side2, PB);
+                (void)hipEventRecord((hipEvent_t)P.as_join2, side2);
+                (void)hipStreamWaitEvent(side, (hipEvent_t)P.as_fork, 0);
+                hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, side, PA);
+                (void)hipEventRecord((hipEvent_t)P.as_join, side);
+            } else if (side) {
                 (void)hipStreamWaitEvent(side, (hipEvent_t)P.as_fork, 0);
                 hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, side, P);
                 (void)hipEventRecord((hipEvent_t)P.as_join, side);
@@ -2886,6 +2980,7 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
             }
             launch_as_dense(P, imax_h(1, imin_h(P.as_grid / 2, P.NW * 4)), st);
             if (side) (void)hipStreamWaitEvent(st, (hipEvent_t)P.as_join, 0);
+            if (split) (void)hipStreamWaitEvent(st, (hipEvent_t)P.as_join2, 0);
         } else if (P.as_passes == -2) {
             hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, P);
         } else if (P.as_passes < 0) {
@@ -2902,6 +2997,7 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         }
         if (P.NW <= 2 * P.as_grid) hipLaunchKernelGGL(k_ascommit1, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
         else hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
+        if (P.fwd_split && P.as_dense && !P.lbs && !P.forward_rg) hipLaunchKernelGGL(k_late_fold, dim3(1), dim3(1), 0, st, P);   // late rows of the split sweep
         hipLaunchKernelGGL(k_as_retry, dim3(P.NW), dim3(64), 0, st, P);
         if (ev) (void)hipEventRecord(ev[0], st);
         if (P.ipm_listed) hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);

@@ -59,7 +59,7 @@ typedef struct cfnmpc_solver cfnmpc_solver;
  *     otherwise, nothing written) -- what C callers and bindings should use; CFNMPC_DEFAULT_OPTS(&o) spells it;
  *   - every cfnmpc_opts starts with its own size (set by cfnmpc_default_opts*), and cfnmpc_create / cfnmpc_fleet_create /
  *     cfnmpc_multi_create* refuse (CFNMPC_EINVAL) an object whose struct_size is not the library's. */
-#define CFNMPC_ABI_VERSION 7
+#define CFNMPC_ABI_VERSION 8
 
 /* Replaces the constants baked into the generated solver by
  * crazyflie_controller/scripts/crazyflie_full_model/generate_c_code.py:41-146. */
@@ -108,8 +108,8 @@ typedef struct cfnmpc_opts {
                             as the directional derivative of the RK4 map: fewest bytes, B / 64 wavefronts);
                             2 = on the stored (A, B, b), four instances per wavefront (16 x more wavefronts, a
                             shorter dependent chain per stage: faster while the fleet is too small to fill the
-                            GPU); 0 (default) = by fleet size in waves per SIMD (2 below 8 S instances, S = the device's
-                            SIMD count, 1024 on MI355X: measured cross-over, profiles/r04_thresholds.md).  Same results to
+                            GPU); 0 (default) = by fleet size in waves per SIMD (2 below 6 S instances, S = the device's
+                            SIMD count, 1024 on MI355X: measured cross-over against the split matrix-free sweep, profiles/r05_forward_split.md).  Same results to
                             rounding.                                                                        */
     int cond_N2;         /* QP: partial condensing (PARTIAL_CONDENSING_HPIPM, generate_c_code.py:140; acados'
                             qp_solver_cond_N, which the generator leaves at its default): 0 or N (default 0) =
@@ -200,6 +200,14 @@ typedef struct cfnmpc_opts {
                             own plan condenses too: PARTIAL_CONDENSING_HPIPM, generate_c_code.py:140).  1 = on (selects the solves +
                             commit structure), -1 = off, 0 (default) = by measurement.  Scalar box only;
                             not with as_warm. */
+    int forward_split;   /* start solve, matrix-free forward sweep inside the as_dense structure: 1 = in TWO launches -- stages [0, 24)
+                            with the classification of the instances over that window, the compaction, and stages [24, N) of every
+                            instance BESIDE the constrained rows' kernels (their heads of at most 24 stages read nothing behind
+                            stage 24; rows with longer heads follow the second part on its stream) -- half of the sweep's 50-stage
+                            latency chain leaves the critical path of a small fleet's step.  An instance that is feasible over the
+                            first window and leaves the box behind it joins the list late and is solved with the retry kernel.
+                            Same results (candidates bitwise; a row's head class is decided from the first window, the tail
+                            verification extends it where that was too short).  -1 = off, 0 (default) = by measurement. */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);   /* unchecked: the caller's struct MUST be this header's */

@@ -96,3 +96,47 @@ def test_dense_solves_match_restatement(oracle, cref):
         x = sim(x, s.get_u(0), T=0.015, steps=1)
     assert n > 100
     s.close()
+
+
+@pytest.mark.parametrize("B,scale,N", [(600, 1.0, 50), (9000, 1.0, 50), (9000, 1.8, 50), (2000, 1.5, 100), (700, 2.5, 40)])
+def test_split_forward_sweep_matches_single_launch(oracle, B, scale, N):
+    """cfnmpc_opts.forward_split: the start solve's forward sweep in two launches (stages [0, 24) + classification | stages [24, N)
+    beside the constrained rows' kernels, late rows appended to the list) against the single launch: statuses equal, the same
+    instances constrained, iterates to rounding -- closed loops whose kicks make rows with heads of 24 / 32 / N stages and rows that
+    first leave the box behind stage 24 (late rows)."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    rng = np.random.default_rng(B + N)
+    x = oracle.sample_hover_x0(rng, B, scale=scale)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    a = BatchSolver(B, default_opts(N=N, as_dense=1, forward_sweep=1, forward_split=1))
+    b = BatchSolver(B, default_opts(N=N, as_dense=1, forward_sweep=1, forward_split=-1))
+    for s in (a, b):
+        s.set_x0(x); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    cohort = max(1, B // 10)
+    steps = 10
+    kicks = oracle.sample_hover_x0(rng, cohort * steps, scale=scale).reshape(steps, cohort, 13)
+    total = long_heads = 0
+    for t in range(steps):
+        c0 = (t * cohort) % max(B - cohort, 1)
+        x[c0:c0 + cohort] = kicks[t]
+        a.set_x0(x); b.set_x0(x)
+        a.solve(1); b.solve(1)
+        sa, ia, _ = a.stats(); sb, ib, _ = b.stats()
+        xa, ua = a.get_iterate(); xb, ub = b.get_iterate()
+        assert np.array_equal(sa, sb), (t, np.nonzero(sa != sb)[0][:10])
+        assert np.array_equal(ia > 0, ib > 0), (t, np.nonzero((ia > 0) != (ib > 0))[0][:10])
+        ok = sa == 0
+        exact = ok & (ia <= 12) & (ib <= 12)
+        # (a row's head comes from the first window only, so a few rows take another path -- a retry over a longer head, or the
+        #  interior point -- to the same solution: exact solves agree to rounding, interior-point rows to its tolerance)
+        assert np.abs(ua[exact] - ub[exact]).max() < 1e-7 and np.abs(xa[exact] - xb[exact]).max() < 1e-7, (t, np.abs(ua[exact] - ub[exact]).max())
+        assert np.abs(ua[ok] - ub[ok]).max() < 5e-4
+        total += int((ia > 0).sum()); long_heads += int((a.heads()[ia > 0] > 24).sum())
+        b.set_iterate(xa, ua)
+        x = sim(x, a.get_u(0), T=0.015, steps=1)
+    assert total > B // 5
+    if scale >= 1.5:
+        assert long_heads > 0
+    a.close(); b.close()
