@@ -1091,8 +1091,6 @@ KALIGN __global__ __launch_bounds__(64) void k_forward_p2(Params P) {   // split
     __shared__ int sflag[64];
     forward_body<false, true, 2>(P, xs, cs, sflag);
 }
-// after the commit kernel: the late rows of the split sweep join the list (k_as_retry and the interior point see them)
-__global__ void k_late_fold(Params P) { gm(P.nipm)[0] += gm(P.nipm)[42]; gm(P.nipm)[42] = 0; }
 __global__ __launch_bounds__(64) void k_cforward(Params P) {
     __shared__ double xs[64 * 13], cs[64 * 13];
     __shared__ int sflag[64];
@@ -1248,6 +1246,7 @@ __global__ __launch_bounds__(256) void k_scatter(Params P) {
             // full horizon, 32, 24 | 16, 12, 8, 4): their number -- the dense active-set kernel (cfnmpc_asdense.hip) takes the rest
             gm(P.nipm)[41] = P.N > 16 ? base[9] : 0;
             gm(P.nipm)[43] = P.N > 24 ? base[6] : 0;    // ... of more than 24 stages (full horizon, 32): behind part two of a split sweep
+            gm(P.nipm)[42] = 0;                          // late rows of this step's split sweep (k_forward_p2 counts them)
         }
     }
     if (blockIdx.x == 0 && P.ascnt && threadIdx.x < 32) gm(P.ascnt)[threadIdx.x] = 0;   // work lists of the active-set passes
@@ -1435,7 +1434,9 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     // P.nipm[40]): four fall-back rows per wave instead of one row in each of the waves they were scattered over
     const bool listed = MODE == 2 && P.ipm_listed;   // (small fleets skip k_ipm_list: the rows stay where k_as had them)
     // (MODE 4 beside the dense kernel: only the rows with heads of more than 16 stages, the first P.nipm[41] of the list)
-    const int nipm = gm(P.nipm)[listed ? 40 : ((MODE == 4 && P.as_dense) ? (P.as_range == 2 ? 43 : 41) : 0)];
+    // (MODE 2 / 3 behind a split forward sweep: the late rows its second part appended -- P.nipm[42] of them -- belong to the list)
+    const int nipm = gm(P.nipm)[listed ? 40 : ((MODE == 4 && P.as_dense) ? (P.as_range == 2 ? 43 : 41) : 0)] +
+                     (((MODE == 2 && !listed) || MODE == 3) && P.fwd_split ? gm(P.nipm)[42] : 0);
     const int slot_lo = (MODE == 4 && P.as_dense && P.as_range == 1) ? gm(P.nipm)[43] : 0;   // (first list slot of this launch)
     // SPARSE (active-set kernels, short lists): ONE list slot per wave (row 0; rows 1..3 idle) while the constrained rows
     // number fewer than the SIMDs -- every row then sweeps its own head, restarts at its own stage and stops after its own
@@ -2061,7 +2062,6 @@ __global__ __launch_bounds__(64) void k_as_retry(Params P) {  // MODE 3: rows th
     __shared__ double btile[4][64];
     qp_wave<3>(P, wtile, btile, blockIdx.x);
 }
-
 // =============================================================================================
 // Level-synchronous active-set passes (cfnmpc_opts.as_pipeline)
 // =============================================================================================
@@ -2959,7 +2959,12 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
             // Split forward sweep: its second part (stages [24, N) of EVERY instance) runs on a second side stream beside both;
             // rows with heads of 24 stages read nothing behind stage 24 and stay beside it, the rows with longer heads follow it.
             hipStream_t side = (hipStream_t)P.as_side, side2 = (hipStream_t)P.as_side2;
-            const bool split = P.fwd_split && !P.lbs && !P.forward_rg && side && side2;
+            // (a step being CAPTURED into a graph -- cfnmpc_opts.step_graph -- keeps everything on the capture stream: forked streams
+            //  inside a re-captured graph whose predecessor is still in flight crashed the runtime in one run of four)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) side = side2 = nullptr;
+            const bool p1_ran = P.fwd_split && !P.lbs && !P.forward_rg;     // (launch_qp_start: the sweep's first part only)
+            const bool split = p1_ran && side && side2;
             if (side) (void)hipEventRecord((hipEvent_t)P.as_fork, st);
             if (split) {
                 Params PA = P, PB = P;
@@ -2971,12 +2976,16 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
                 (void)hipStreamWaitEvent(side, (hipEvent_t)P.as_fork, 0);
                 hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, side, PA);
                 (void)hipEventRecord((hipEvent_t)P.as_join, side);
-            } else if (side) {
-                (void)hipStreamWaitEvent(side, (hipEvent_t)P.as_fork, 0);
-                hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, side, P);
-                (void)hipEventRecord((hipEvent_t)P.as_join, side);
             } else {
-                hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, P);
+                if (p1_ran) hipLaunchKernelGGL(k_forward_p2, dim3((P.B + 63) / 64), dim3(64), 0, st, P);   // no side streams: in order
+                if (side && !p1_ran) {
+                    (void)hipStreamWaitEvent(side, (hipEvent_t)P.as_fork, 0);
+                    hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, side, P);
+                    (void)hipEventRecord((hipEvent_t)P.as_join, side);
+                } else {
+                    side = nullptr;
+                    hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, P);
+                }
             }
             launch_as_dense(P, imax_h(1, imin_h(P.as_grid / 2, P.NW * 4)), st);
             if (side) (void)hipStreamWaitEvent(st, (hipEvent_t)P.as_join, 0);
@@ -2997,7 +3006,9 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         }
         if (P.NW <= 2 * P.as_grid) hipLaunchKernelGGL(k_ascommit1, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
         else hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
-        if (P.fwd_split && P.as_dense && !P.lbs && !P.forward_rg) hipLaunchKernelGGL(k_late_fold, dim3(1), dim3(1), 0, st, P);   // late rows of the split sweep
+        // (late rows of a split forward sweep: k_as_retry and k_ipm_rest count them in, P.nipm[0] + P.nipm[42].  Tried: both modes in
+        //  ONE launch for small fleets, where each normally finds nothing to do and an empty launch costs 5 - 7 us -- either half
+        //  alone runs, the combined kernel aborts on the device; not pursued)
         hipLaunchKernelGGL(k_as_retry, dim3(P.NW), dim3(64), 0, st, P);
         if (ev) (void)hipEventRecord(ev[0], st);
         if (P.ipm_listed) hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
