@@ -403,7 +403,9 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(xit, NW * (N + 1) * cfn::SZ_V13); ALLOC(uit, NW * 4 * N * 4);
     ALLOC(xitn, NW * (N + 1) * cfn::SZ_V13); ALLOC(uitn, NW * 4 * N * 4); ALLOC(x0, NW * cfn::SZ_V13);
     ALLOC(yref, NW * N * cfn::SZ_Y); ALLOC(yref_e, NW * cfn::SZ_V13);
-    ALLOC(AR, NW * N * cfn::SZ_A); ALLOC(BR, NW * N * cfn::SZ_B); ALLOC(b, NW * N * cfn::SZ_V13);
+    // (k_linearise writes these three in groups of 16 blocks without looking at the fleet's end: blocks up to the next multiple of 16)
+    const size_t NW16 = ((size_t)P.NW + 15) / 16 * 16 + 1;
+    ALLOC(AR, NW16 * N * cfn::SZ_A); ALLOC(BR, NW16 * N * cfn::SZ_B); ALLOC(b, NW16 * N * cfn::SZ_V13);
     ALLOC(KR, NW * N * cfn::SZ_K); ALLOC(Sinv, NW * N * cfn::SZ_S);
     ALLOC(d, NW * 4 * N * 4); ALLOC(Pchk, NW * cfn::N_CHK * cfn::SZ_PP);
     ALLOC(v, NW * 4 * N * 4); ALLOC(tl, NW * 4 * N * 4); ALLOC(tu, NW * 4 * N * 4); ALLOC(ll, NW * 4 * N * 4);
@@ -425,9 +427,9 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     if (P.as_passes != 0) ALLOC(aslist, (size_t)3 * 7 * NW * 4);
     if (cond_N2) ALLOC(cb, NW * 4 * (size_t)cond_N2 * cfn::cb_size(cfn::cond_mmax(P)));
     if (s->overlap) {
-        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->AR2, NW * N * cfn::SZ_A);
-        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->BR2, NW * N * cfn::SZ_B);
-        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->b2, NW * N * cfn::SZ_V13);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->AR2, NW16 * N * cfn::SZ_A);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->BR2, NW16 * N * cfn::SZ_B);
+        if (rc == CFNMPC_OK) rc = dev_alloc(s, &s->b2, NW16 * N * cfn::SZ_V13);
         int lo = 0, hi = 0;  // lo = least priority (numerically greatest)
         if (rc == CFNMPC_OK && (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
                                 hipStreamCreateWithPriority(&s->aux, hipStreamNonBlocking, lo) != hipSuccess ||

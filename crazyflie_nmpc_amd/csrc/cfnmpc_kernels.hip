@@ -91,6 +91,15 @@ __host__ __device__ constexpr bool div_ok(int ns, unsigned n = 0) {   // exact f
     return true;
 }
 static_assert(div_ok(13) && div_ok(10) && div_ok(6), "k_linearise: e / NS by multiply-shift");
+// the same with a 20-bit shift (16-byte pieces of a group tile -> block: e < 1664, ns = pieces per block)
+__host__ __device__ constexpr unsigned div_magic20(int ns) { return ((1u << 20) + (unsigned)ns - 1u) / (unsigned)ns; }
+__host__ __device__ constexpr bool div_ok20(int ns, unsigned n) {
+    for (unsigned e = 0; e < n; e++)
+        if ((((unsigned long long)e * div_magic20(ns)) >> 20) != e / (unsigned)ns || (unsigned long long)e * div_magic20(ns) >= (1ull << 32) ||
+            div_magic20(ns) >= (1u << 24) || e >= (1u << 24))
+            return false;
+    return true;
+}
 static_assert(div_ok(52, 64 * 13), "k_forward: e / 52 by multiply-shift");
 //   CSTORE (with GATHER): the results go to the COMPACT store of the constrained-QP kernels (P.cAR, P.cBR, P.cbv; list
 //                   slot c owns row c & 3 of compact block c >> 2, i.e. 64 consecutive slots = 16 consecutive blocks,
@@ -100,6 +109,7 @@ static_assert(div_ok(52, 64 * 13), "k_forward: e / 52 by multiply-shift");
 template <bool GATHER, bool CSTORE = false>
 __device__ __forceinline__ void linearise_body(const Params& P, double* sx, double (*sc)[64 * 13], int* sinst,
                                                const int which = 0) {
+    constexpr bool PAIRS = !GATHER;   // 16-byte stores of whole column groups (below)
     const int tid = threadIdx.x;
     const double h = P.dt;
     const int N = P.N;
@@ -156,25 +166,38 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         const gdouble* up = gm(P.uit) + (P.v4b ? (((size_t)(inst >> 2) * N + k) * 4 + (inst & 3)) * 4 : ((size_t)inst * N + k) * 4);
         SFOR(a, 0, 4, { u[a] = up[a]; });
     };
-    double xn[13], un[4];  // x_k in EXTERNAL order and u_k on entry to stage k
+    // Vector-memory operations complete in issue order on this part (one counter for loads and stores): waiting for a load
+    // waits for every store issued before it.  So the NEXT stage's inputs are requested at the top of a stage and used one
+    // stage later, when the 82 (162) stores issued in between have pushed them out of the 63-deep window -- the stage loop
+    // never waits for its own stores to drain (requested at the end of the stage, as before round 5, every stage ended with
+    // the wave waiting for its A stores: 1.15 -> 1.00 ms at 65 536 instances together with the 16-byte stores below).
+    //   on entry to stage k: sx = x_k (tile), xr = x_{k+1} as loaded (tile order, maybe still in flight), un = u_k (same)
+    double xr[13], un[4], xn[13];
     {
-        double xr[13];
         issue_x(k0, tid, xr);
         land_x(xr);
-        issue_u(k0, un);
-        __syncthreads();
-        SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
         __syncthreads();
         issue_x(k0 + 1, tid, xr);
-        land_x(xr);   // sx holds x_{k+1} on entry to stage k
-        __syncthreads();
+        issue_u(k0, un);
+        // (waited for HERE, so that the waits the compiler places at the loop's top are sized for the path around the loop --
+        //  82 younger stores, i.e. none -- and not for this entry)
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     }
     for (int k = k0; k < k1; k++) {
         double x[13], u[4];
-        SFOR(e, 0, 13, { x[e] = xn[e]; });
+        SFOR(e, 0, 13, { x[e] = sx[tid * 13 + int_of(e)]; });
         SFOR(a, 0, 4, { u[a] = un[a]; });
-        int tl = tid;  // opaque per-stage copy: keeps the 162 store offsets from being hoisted out of the
-        asm volatile("" : "+v"(tl));  // stage loop (they would occupy ~160 registers for its whole length)
+        __syncthreads();
+        land_x(xr);   // sx = x_{k+1}
+        __syncthreads();
+        {
+            int tq = tid;
+            asm volatile("" : "+v"(tq));
+            issue_x(imin(k + 2, N), tq, xr);
+            issue_u(imin(k + 1, N - 1), un);
+        }
+        int tl = tid;  // opaque per-stage copy: keeps the store offsets (82, or 162 in the list kernels) from being hoisted out
+        asm volatile("" : "+v"(tl));  // of the stage loop (they would occupy that many registers for its whole length)
         // nominal RK4 (classic tableau, one step per interval)
         double xt[13], k1v[13], k2v[13], k3v[13], k4v[13];
         JacPoint J[4];
@@ -197,9 +220,27 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
             sc[0][tid * 13 + r] = phi - xn[e];
         });
         __syncthreads();
-        // rows < NS of column tile `ti` -> `field` (SZ doubles per block and stage) at `pre4`
         // e / NS for e < 64 * NS as a 24-bit multiply + shift (verified at compile time: div_ok)
 #define CFN_DIV(e, NS) ((int)(__umul24((unsigned)(e), div_magic(NS)) >> 16))
+        // PAIRS (the kernel over the whole fleet): a group of columns leaves through ONE tile that mirrors the group's
+        // region of the 16 stage blocks -- [block][column][instance of the block][row < NS], CH doubles per block, the
+        // order they have in HBM -- so that tile -> field is a linear copy in 16-byte pieces: piece g of the tile
+        // (ds_read_b128 at 16 g) goes to block g / (CH / 2), 16-byte piece g % (CH / 2) of the region.  Half the store
+        // instructions of the 8-byte form (82 instead of 162 per stage) at twice the bytes each.
+        // tile column j of a group: lane base tb(CH, NS) + 4 NS j + row
+        double* const scf = &sc[0][0];
+#define CFN_TB(CH, NS) ((tid >> 2) * (CH) + (tid & 3) * (NS))
+#define CFN_COL(call, j, CH, NS)                                                                       \
+    {                                                                                                   \
+        call;                                                                                           \
+        if (PAIRS) {                                                                                    \
+            const int tb = CFN_TB(CH, NS) + 4 * (NS) * j;                                               \
+            SFOR(r, 0, NS, { scf[tb + r] = col[ext_of(r)]; });                                          \
+        } else {                                                                                        \
+            SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });                                  \
+        }                                                                                               \
+    }
+        // rows < NS of column tile `ti` -> `field` (SZ doubles per block and stage) at `pre4` (8-byte form: the list kernels)
 #define CFN_STORE(field, SZ, ti, NS, pre4)                                                              \
     {                                                                                                   \
         double tv[NS];                                                                                  \
@@ -214,50 +255,65 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
             if (!CSTORE || li < n_live) *el(field, li, i, N, k, SZ, pre4, NS, false) = tv[r];            \
         });                                                                                             \
     }
-        CFN_STORE(CSTORE ? P.cbv : P.b, SZ_V13, 0, 13, 0);
+        // the group tile (CH doubles per block) -> `field` at PRE inside every block's stage (16-byte form)
+#define CFN_STORE2(field, SZ, CH, PRE)                                                                  \
+    {                                                                                                   \
+        constexpr int HALF = (CH) / 2, NP = 16 * HALF, NI = (NP + 63) / 64;                             \
+        static_assert(div_ok20(HALF, 64 * NI) && 128 * NI <= 4 * 64 * 13, "piece -> block by multiply-shift; tile size"); \
+        dbl2 tv[NI];                                                                                    \
+        SFOR(r, 0, NI, { tv[r] = *(const dbl2*)&scf[2 * (tl + 64 * r)]; });                             \
+        /* (blocks up to the next multiple of 16 exist: cfnmpc_api.cpp allocates the three fields that way) */ \
+        const unsigned sdiff8 = (unsigned)(N * (SZ) - (CH)) * 8u;   /* < 2^24: N <= 4096 */                \
+        const char* base = (const char*)(gm(field) + ((size_t)blockIdx.x * 16 * N + k) * (SZ) + (PRE)); \
+        SFOR(r, 0, NI, {                                                                                \
+            const unsigned g = (unsigned)(tl + 64 * r);                                                 \
+            const unsigned bq = __umul24(g, div_magic20(HALF)) >> 20;                                   \
+            const unsigned off = __umul24(bq, sdiff8) + 16u * g;                                        \
+            if (NP % 64 == 0 || r + 1 < NI || tid < NP % 64) *(gdbl2*)(base + off) = tv[r];             \
+        });                                                                                             \
+    }
+        if (PAIRS) { CFN_STORE2(P.b, SZ_V13, 52, 0); } else { CFN_STORE(CSTORE ? P.cbv : P.b, SZ_V13, 0, 13, 0); }
         double col[13];
         // state columns in internal order: v (internal 3..5 = external 7..9), q (6..9 = 3..6), w (10..12)
         __syncthreads();
         // (runtime loops on purpose: one column at a time keeps the register footprint small)
 #pragma unroll 1
         for (int j = 0; j < 3; j++) {  // velocity columns: rows p, v
-            sens_column<false, false, false>(J, u, 7 + j, h, col);
-            SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
+            CFN_COL((sens_column<false, false, false>(J, u, 7 + j, h, col)), j, 72, 6);
         }
         __syncthreads();
-        SFOR(j, 0, 3, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(j), 4 * ar_pre(j)); });
+        if (PAIRS) { CFN_STORE2(P.AR, SZ_A, 72, 0); }
+        else { SFOR(j, 0, 3, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(j), 4 * ar_pre(j)); }); }
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < 4; j++) {  // quaternion columns: rows p, v, q
-            sens_column<true, false, false>(J, u, 3 + j, h, col);
-            SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
+            CFN_COL((sens_column<true, false, false>(J, u, 3 + j, h, col)), j, 160, 10);
         }
         __syncthreads();
-        SFOR(j, 0, 4, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(3 + j), 4 * ar_pre(3 + j)); });
+        if (PAIRS) { CFN_STORE2(P.AR, SZ_A, 160, 4 * ar_pre(3)); }
+        else { SFOR(j, 0, 4, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(3 + j), 4 * ar_pre(3 + j)); }); }
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < 3; j++) {  // rate columns: all rows
-            sens_column<true, true, false>(J, u, 10 + j, h, col);
-            SFOR(r, 0, 13, { sc[j][tid * 13 + r] = col[ext_of(r)]; });
+            CFN_COL((sens_column<true, true, false>(J, u, 10 + j, h, col)), j, 156, 13);
         }
         __syncthreads();
-        SFOR(j, 0, 3, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(7 + j), 4 * ar_pre(7 + j)); });
+        if (PAIRS) { CFN_STORE2(P.AR, SZ_A, 156, 4 * ar_pre(7)); }
+        else { SFOR(j, 0, 3, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(7 + j), 4 * ar_pre(7 + j)); }); }
         __syncthreads();
 #pragma unroll 1
         for (int a = 0; a < 4; a++) {  // input columns: all rows
-            sens_column<true, true, true>(J, u, a, h, col);
-            SFOR(r, 0, 13, { sc[a][tid * 13 + r] = col[ext_of(r)]; });
+            CFN_COL((sens_column<true, true, true>(J, u, a, h, col)), a, 208, 13);
         }
-        // next stage's inputs: in flight while the input columns drain (few live registers here)
-        double xr[13];
-        issue_x(imin(k + 2, N), tl, xr);
-        issue_u(imin(k + 1, N - 1), un);
         __syncthreads();
-        SFOR(a, 0, 4, { CFN_STORE(CSTORE ? P.cBR : P.BR, SZ_B, a, 13, a * 52); });
-        land_x(xr);
+        if (PAIRS) { CFN_STORE2(P.BR, SZ_B, 208, 0); }
+        else { SFOR(a, 0, 4, { CFN_STORE(CSTORE ? P.cBR : P.BR, SZ_B, a, 13, a * 52); }); }
         __syncthreads();
+#undef CFN_STORE2
+#undef CFN_TB
 #undef CFN_STORE
 #undef CFN_DIV
+#undef CFN_COL
     }
 }
 // (Round 4, measured: the same linearisation at TWO waves per SIMD -- RK points kept as q | v | w only (10 instead of 31 doubles per
@@ -268,7 +324,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
 //  occupancy (~54 % either way).  Removed; profiles/r04_linearise_variants.md.)
 KALIGN __global__ __launch_bounds__(64) void k_linearise(Params P) {
     __shared__ double sx[64 * 13];       // one 13-vector per instance (internal order)
-    __shared__ double sc[4][64 * 13];    // up to four sensitivity columns, [inst][row] (internal order)
+    __shared__ __attribute__((aligned(16))) double sc[4][64 * 13];    // the tile of a group of up to four sensitivity columns
     __shared__ int sinst[64];
     linearise_body<false>(P, sx, sc, sinst);
 }

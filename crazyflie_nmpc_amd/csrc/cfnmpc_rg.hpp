@@ -102,6 +102,8 @@ __device__ __forceinline__ Lane lane_indirect(const Params& P, int inst, bool va
 // address space: gm() re-types them as global (address_space(1)) so that loads / stores are
 // global_* instead of flat_*.
 typedef __attribute__((address_space(1))) double gdouble;
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) dbl2 gdbl2;
 typedef __attribute__((address_space(1))) int gint;
 __device__ __forceinline__ gdouble* gm(double* p) { return (gdouble*)(unsigned long long)p; }
 __device__ __forceinline__ const gdouble* gm(const double* p) { return (const gdouble*)(unsigned long long)p; }
