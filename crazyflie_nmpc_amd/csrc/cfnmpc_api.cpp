@@ -393,6 +393,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.fwd_split = (P.as_dense && P.as_side2 && !P.forward_rg && !cond_N2 && P.fused == 0 && o.N >= 40 && o.forward_split != -1 &&
                    (o.forward_split == 1 || pick.forward_split)) ? 24 : 0;
     P.cond_N2 = cond_N2;
+    P.ab16 = 1;                // home A, B, b grouped by 16 blocks (cfnmpc_rg.hpp: abidx)
     P.v4b = cond_N2 ? 0 : 1;   // home 4-vectors wave-blocked (the condensed kernels index theirs instance-major)
     P.cond_M = cond_N2 ? o.N / cond_N2 : 0;
     P.cond_rem = cond_N2 ? o.N % cond_N2 : 0;
@@ -403,8 +404,8 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(xit, NW * (N + 1) * cfn::SZ_V13); ALLOC(uit, NW * 4 * N * 4);
     ALLOC(xitn, NW * (N + 1) * cfn::SZ_V13); ALLOC(uitn, NW * 4 * N * 4); ALLOC(x0, NW * cfn::SZ_V13);
     ALLOC(yref, NW * N * cfn::SZ_Y); ALLOC(yref_e, NW * cfn::SZ_V13);
-    // (k_linearise writes these three in groups of 16 blocks without looking at the fleet's end: blocks up to the next multiple of 16)
-    const size_t NW16 = ((size_t)P.NW + 15) / 16 * 16 + 1;
+    // (the linearisation's home fields are laid out and written in groups of 16 blocks, P.ab16)
+    const size_t NW16 = ((size_t)P.NW / 16 + 1) * 16;   // whole groups of 16 blocks, the spare block NW included (cfnmpc_rg.hpp: abidx)
     ALLOC(AR, NW16 * N * cfn::SZ_A); ALLOC(BR, NW16 * N * cfn::SZ_B); ALLOC(b, NW16 * N * cfn::SZ_V13);
     ALLOC(KR, NW * N * cfn::SZ_K); ALLOC(Sinv, NW * N * cfn::SZ_S);
     ALLOC(d, NW * 4 * N * 4); ALLOC(Pchk, NW * cfn::N_CHK * cfn::SZ_PP);
@@ -1073,7 +1074,7 @@ int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, double* A, double* Bm, doub
     if (!s || !A || !Bm || !b) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
     const cfn::Params& P = s->P;
-    const size_t NW = P.NW, N = P.N, B = P.B;
+    const size_t NW = ((size_t)P.NW / 16 + 1) * 16, N = P.N, B = P.B;   // (whole groups of 16 blocks)
     std::vector<double> ha(NW * N * cfn::SZ_A), hb(NW * N * cfn::SZ_B), hv(NW * N * cfn::SZ_V13);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(ha.data(), P.AR, ha.size() * 8, hipMemcpyDeviceToHost));
@@ -1082,9 +1083,10 @@ int cfnmpc_debug_get_linearisation(cfnmpc_solver* s, double* A, double* Bm, doub
     for (size_t i = 0; i < B; i++) {
         const size_t w = i / 4, q = i % 4;
         for (size_t k = 0; k < N; k++) {
-            const double* ab = ha.data() + (w * N + k) * cfn::SZ_A;
-            const double* bb = hb.data() + (w * N + k) * cfn::SZ_B;
-            const double* vb = hv.data() + (w * N + k) * cfn::SZ_V13;
+            const size_t bs = ((w / 16) * N + k) * 16 + w % 16;   // [group of 16 blocks][stage][block of the group]
+            const double* ab = ha.data() + bs * cfn::SZ_A;
+            const double* bb = hb.data() + bs * cfn::SZ_B;
+            const double* vb = hv.data() + bs * cfn::SZ_V13;
             double* Ad = A + (i * N + k) * 169;
             double* Bd = Bm + (i * N + k) * 52;
             for (int r = 0; r < 13; r++) {  // internal row / column indices

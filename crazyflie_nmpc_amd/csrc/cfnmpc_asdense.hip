@@ -66,8 +66,8 @@ __host__ __device__ constexpr BuildVisit build_visit(int v) {
 constexpr int AS_MAX_SOLVES_DENSE = 12;   // the iteration cap of qp_wave (AS_MAX_SOLVES)
 
 __device__ __forceinline__ void load_ops(const Params& P, const Lane& t, const int k, StageOps& o) {
-    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, o.ac);
-    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, o.br);
+    ld_ar(blkab(P, P.AR, t, k, SZ_A), t, o.ac);
+    ld_rows4(blkab(P, P.BR, t, k, SZ_B), t, o.br);
 }
 __device__ __forceinline__ void lds_ops(const double* G, const Lane& t, const int k, StageOps& o) {
     const double* b = G + k * ST_BLK + t.L * ST_ROW;

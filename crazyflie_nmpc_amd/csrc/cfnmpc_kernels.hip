@@ -142,7 +142,9 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     auto el = [&](double* field, int li, int i, int stages, int k, int SZ, int pre4, int NS, bool home = true) -> gdouble* {
         if (GATHER && (home || !CSTORE)) {
             const int in = sinst[li];
-            return gm(field) + ((size_t)(in >> 2) * stages + k) * SZ + pre4 + (in & 3) * NS + i;
+            // (loads: the iterate, [block][stage]; stores of the list kernel without CSTORE: the home A, B, b, grouped by 16 blocks)
+            const size_t bs = home ? (size_t)(in >> 2) * stages + k : ((size_t)(in >> 6) * stages + k) * 16 + ((in >> 2) & 15);
+            return gm(field) + bs * SZ + pre4 + (in & 3) * NS + i;
         }
         const int w0 = (int)blockIdx.x * 16;
         // (24-bit multiply: full rate, the 32-bit one takes four issue slots; block index <= 16, stages * SZ < 2^24 for N <= 4096)
@@ -262,9 +264,9 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         static_assert(div_ok20(HALF, 64 * NI) && 128 * NI <= 4 * 64 * 13, "piece -> block by multiply-shift; tile size"); \
         dbl2 tv[NI];                                                                                    \
         SFOR(r, 0, NI, { tv[r] = *(const dbl2*)&scf[2 * (tl + 64 * r)]; });                             \
-        /* (blocks up to the next multiple of 16 exist: cfnmpc_api.cpp allocates the three fields that way) */ \
-        const unsigned sdiff8 = (unsigned)(N * (SZ) - (CH)) * 8u;   /* < 2^24: N <= 4096 */                \
-        const char* base = (const char*)(gm(field) + ((size_t)blockIdx.x * 16 * N + k) * (SZ) + (PRE)); \
+        /* (home layout: the 16 blocks of a group lie side by side per stage, cfnmpc_rg.hpp: abidx; whole groups exist) */ \
+        const unsigned sdiff8 = (unsigned)((SZ) - (CH)) * 8u;                                           \
+        const char* base = (const char*)(gm(field) + ((size_t)blockIdx.x * N + k) * 16 * (SZ) + (PRE)); \
         SFOR(r, 0, NI, {                                                                                \
             const unsigned g = (unsigned)(tl + 64 * r);                                                 \
             const unsigned bq = __umul24(g, div_magic20(HALF)) >> 20;                                   \
@@ -443,10 +445,10 @@ struct FwdIn {
 template <bool WITH_B>
 __device__ __forceinline__ void load_fwd(const Params& P, const Lane& t, const int k, FwdIn<WITH_B>& in) {
     ld_cols4(blk(P.KR, t, P.N, k, SZ_K), t, in.kr);
-    ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
-    ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+    ld_ar(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
+    ld_rows4(blkab(P, P.BR, t, k, SZ_B), t, in.br);
     in.d = gm(P.d)[i4(P, t, k, t.L & 3)];
-    in.bv = WITH_B ? ld13(blk(P.b, t, P.N, k, SZ_V13), t) : 0.0;
+    in.bv = WITH_B ? ld13(blkab(P, P.b, t, k, SZ_V13), t) : 0.0;
 }
 // v = -K x - d in lanes a < 4
 template <bool WITH_B>
@@ -505,8 +507,8 @@ struct ResIn {
     double ar[10], br[4], kr[13], g, sv[4];
 };
 __device__ __forceinline__ void load_res(const Params& P, const Lane& t, const int k, ResIn& in) {
-    ld_ar_raw(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
-    ld_rows4_raw(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+    ld_ar_raw(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
+    ld_rows4_raw(blkab(P, P.BR, t, k, SZ_B), t, in.br);
     ld_cols4_raw(blk(P.KR, t, P.N, k, SZ_K), t, in.kr);
     const int a = t.L & 3;
     in.g = gm(P.g)[i4(P, t, k, a)];
@@ -591,8 +593,8 @@ constexpr double AS_BIG = 1e30;
 #endif
 constexpr int AS_MAX_SOLVES = CFN_AS_MAX;   // observed on the bench workload: 48 % settle after 1 solve, 99 % within 4, all within 8
 __device__ __forceinline__ void load_stage_as(const Params& P, const Lane& t, const int k, StageIn<true>& in) {
-    ld_ar_raw(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
-    ld_rows4_raw(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+    ld_ar_raw(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
+    ld_rows4_raw(blkab(P, P.BR, t, k, SZ_B), t, in.br);
     const int a = t.L & 3;
     const double c = gm(P.tl)[i4(P, t, k, a)];
     const double cls = gm(P.tu)[i4(P, t, k, a)];
@@ -680,8 +682,8 @@ __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, 
         const gdouble* gb = blk(P.cGR, t, P.N, k, SZ_K);
         const gdouble* src = (lo4 ? kb : gb) + t.q * 4 + a;
         SFOR(l, 0, 13, { in.kg[l] = src[l * 16]; });
-        ld_ar(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
-        ld_rows4(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+        ld_ar(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
+        ld_rows4(blkab(P, P.BR, t, k, SZ_B), t, in.br);
         const gdouble* sr = blk(P.cS, t, P.N, k, SZ_S4) + t.q * 4 + a;
         SFOR(c, 0, 4, { in.sr[c] = sr[c * 16]; });
         const size_t idx = i4(P, t, k, a);
@@ -1373,8 +1375,8 @@ __device__ __forceinline__ void sweep_clip_gradient(const Params& P, const Param
     {   // forward: dx_0 = 0, dx_{k+1} = A dx_k + B dv_k
         struct In { double ar[10], br[4], dv; };
         auto load = [&](int k, In& in) {
-            ld_ar(blk(Q.AR, tc, N, k, SZ_A), tc, in.ar);
-            ld_rows4(blk(Q.BR, tc, N, k, SZ_B), tc, in.br);
+            ld_ar(blkab(Q, Q.AR, tc, k, SZ_A), tc, in.ar);
+            ld_rows4(blkab(Q, Q.BR, tc, k, SZ_B), tc, in.br);
             in.dv = gm(Q.dva)[i4(Q, tc, k, a)];
         };
         double x = 0.0;
@@ -1417,8 +1419,8 @@ __device__ __forceinline__ void sweep_clip_gradient(const Params& P, const Param
     }
     struct Bk { double ar[10], br[4], dv, xk[13]; };
     auto loadb = [&](int k, Bk& in) {
-        ld_ar_raw(blk(Q.AR, tc, N, k, SZ_A), tc, in.ar);
-        ld_rows4_raw(blk(Q.BR, tc, N, k, SZ_B), tc, in.br);
+        ld_ar_raw(blkab(Q, Q.AR, tc, k, SZ_A), tc, in.ar);
+        ld_rows4_raw(blkab(Q, Q.BR, tc, k, SZ_B), tc, in.br);
         in.dv = gm(Q.dva)[i4(Q, tc, k, a)];
         SFOR(j, 0, 13, { in.xk[j] = zx[(size_t)k * 13 + j]; });
     };
@@ -1544,6 +1546,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     }
     Params Q = P;
     Q.v4b = 0;   // (compact 4-vectors: instance-major, a row's head contiguous)
+    Q.ab16 = 0;  // (compact A, B: [block][stage])
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
     Q.lbs = P.clbs; Q.ubs = P.cubs;
     const size_t cbase = (size_t)tc.inst * N * 4;  // compact 4-vectors of this row
@@ -1554,8 +1557,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             SFOR(j, 0, 4, {
                 const int k = imin(k0 + j, hd - 1);
                 if (!CST) {
-                    ld_ar(blk(P.AR, t, N, k, SZ_A), t, ar[j]);
-                    ld_rows4(blk(P.BR, t, N, k, SZ_B), t, br[j]);
+                    ld_ar(blkab(P, P.AR, t, k, SZ_A), t, ar[j]);
+                    ld_rows4(blkab(P, P.BR, t, k, SZ_B), t, br[j]);
                 }
                 vv[j] = gm(P.v)[i4(P, t, k, t.L & 3)];
                 uu[j] = gm(P.uit)[i4(P, t, k, t.L & 3)];
@@ -1565,9 +1568,9 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 const int k = k0 + j;
                 if (k < hd) {
                     if (!CST) {
-                        gdouble* ca = blk(Q.AR, tc, N, k, SZ_A);
+                        gdouble* ca = blkab(Q, Q.AR, tc, k, SZ_A);
                         SFOR(sl, 0, 10, { if (t.L < ar_n(sl)) ca[4 * ar_pre(sl) + tc.q * ar_n(sl) + t.L] = ar[j][sl]; });
-                        gdouble* cb = blk(Q.BR, tc, N, k, SZ_B);
+                        gdouble* cb = blkab(Q, Q.BR, tc, k, SZ_B);
                         SFOR(a, 0, 4, { if (t.L < 13) cb[(a * 4 + tc.q) * 13 + t.L] = br[j][a]; });
                     }
                     if (t.L < 4) {
@@ -1913,17 +1916,17 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             // three quarters of every cache line foreign) and need no gain; b and the tail come from the home blocks
             auto load_roll = [&](int k, FwdIn<true>& in) {
                 if (CST) {   // everything but the start solve's gains from the compact copy
-                    ld_ar(blk(Q.AR, tc, N, k, SZ_A), tc, in.ar);
-                    ld_rows4(blk(Q.BR, tc, N, k, SZ_B), tc, in.br);
+                    ld_ar(blkab(Q, Q.AR, tc, k, SZ_A), tc, in.ar);
+                    ld_rows4(blkab(Q, Q.BR, tc, k, SZ_B), tc, in.br);
                     in.bv = ld13(blk(P.cbv, tc, N, k, SZ_V13), tc);
                     if (k >= head) {
                         ld_cols4(blk(P.KR, t, N, k, SZ_K), t, in.kr);
                         in.d = gm(P.d)[i4(P, t, k, t.L & 3)];
                     }
                 } else if (k < head) {
-                    ld_ar(blk(Q.AR, tc, N, k, SZ_A), tc, in.ar);
-                    ld_rows4(blk(Q.BR, tc, N, k, SZ_B), tc, in.br);
-                    in.bv = ld13(blk(P.b, t, N, k, SZ_V13), t);
+                    ld_ar(blkab(Q, Q.AR, tc, k, SZ_A), tc, in.ar);
+                    ld_rows4(blkab(Q, Q.BR, tc, k, SZ_B), tc, in.br);
+                    in.bv = ld13(blkab(P, P.b, t, k, SZ_V13), t);
                 } else {
                     load_fwd<true>(P, t, k, in);
                 }
@@ -2183,8 +2186,8 @@ __device__ __forceinline__ void zload_stage(const Params& P, const Params& Q, co
                                             ZStage& z) {
     const int a = tc.L & 3;
     if (FIRST) {   // from the instance's home blocks (interleaved with its three wave-mates)
-        ld_ar_raw(blk(P.AR, th, P.N, k, SZ_A), th, z.in.ar);
-        ld_rows4_raw(blk(P.BR, th, P.N, k, SZ_B), th, z.in.br);
+        ld_ar_raw(blkab(P, P.AR, th, k, SZ_A), th, z.in.ar);
+        ld_rows4_raw(blkab(P, P.BR, th, k, SZ_B), th, z.in.br);
         z.v0 = gm(P.v)[i4(P, th, k, a)];
         z.uk = gm(P.uit)[i4(P, th, k, a)];
         z.c = 0.0; z.cls = 0.0;
@@ -2347,6 +2350,7 @@ __device__ __forceinline__ int zsweep_forward(const Params& P, const Params& Q, 
 __device__ __forceinline__ Params compact_params(const Params& P) {
     Params Q = P;
     Q.v4b = 0;   // (compact 4-vectors: instance-major, a row's head contiguous)
+    Q.ab16 = 0;  // (compact A, B: [block][stage])
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
     return Q;
 }
@@ -2570,8 +2574,8 @@ __device__ __forceinline__ void ascommit_body(const Params& P) {
         struct In { double kr[13], ar[10], br[4], un, xc, dv, zx; };
         auto load = [&](int k, In& in) {
             ld_cols4(blk(P.KR, t, N, k, SZ_K), t, in.kr);
-            ld_ar(blk(P.AR, t, N, k, SZ_A), t, in.ar);
-            ld_rows4(blk(P.BR, t, N, k, SZ_B), t, in.br);
+            ld_ar(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
+            ld_rows4(blkab(P, P.BR, t, k, SZ_B), t, in.br);
             in.un = gm(P.uitn)[i4(P, t, k, a)];
             in.xc = blk(P.xitn, t, N + 1, k + 1, SZ_V13)[lx];
             in.dv = gm(Q.dva)[cb4 + (size_t)imin(k, imax(head - 1, 0)) * 4];

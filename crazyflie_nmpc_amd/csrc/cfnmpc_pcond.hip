@@ -107,11 +107,11 @@ __device__ __forceinline__ double a_elem(const Params& P, const Grp<LPI>& t, int
     const int s = c - 3;
     const int n = ar_n(s);
     if (r >= n) return 0.0;
-    return gm(P.AR)[(t.wave * P.N + k) * SZ_A + 4 * ar_pre(s) + t.q * n + r];
+    return gm(P.AR)[abidx(P, t.wave, k) * SZ_A + 4 * ar_pre(s) + t.q * n + r];
 }
 template <int LPI>
 __device__ __forceinline__ double b_elem(const Params& P, const Grp<LPI>& t, int k, int r, int a) {
-    return gm(P.BR)[(t.wave * P.N + k) * SZ_B + (a * 4 + t.q) * 13 + r];
+    return gm(P.BR)[abidx(P, t.wave, k) * SZ_B + (a * 4 + t.q) * 13 + r];
 }
 template <int LPI>
 __device__ __forceinline__ double v13(const double* f, const Grp<LPI>& t, int stages, int k, int r) {
@@ -188,12 +188,12 @@ __global__ __launch_bounds__(64) void k_pcond(Params P) {
     const int boff = t.lane < 52 ? ((t.lane & 3) * 4 + t.q) * 13 + (t.lane >> 2) : -1;   // element (row lane >> 2, input lane & 3)
     double sa0, sa1, sb, sbv, sx, sy, su, syu;
     auto load_stage = [&](const int k) {
-        const gdouble* ab = gm(P.AR) + (t.wave * N + k) * SZ_A;
+        const gdouble* ab = gm(P.AR) + abidx(P, t.wave, k) * SZ_A;
         sa0 = ab[max(aoff[0], 0)];
         sa1 = ab[max(aoff[1], 0)];
-        sb = gm(P.BR)[(t.wave * N + k) * SZ_B + max(boff, 0)];
+        sb = gm(P.BR)[abidx(P, t.wave, k) * SZ_B + max(boff, 0)];
         const int l13 = min(t.lane, 12), l4 = t.lane & 3;
-        sbv = v13(P.b, t, N, k, l13);
+        sbv = gm(P.b)[abidx(P, t.wave, k) * SZ_V13 + t.q * 13 + l13];
         sx = v13(P.xit, t, N + 1, k, l13);
         sy = gm(P.yref)[(t.wave * N + k) * SZ_Y + t.q * 17 + l13];
         su = gm(P.uit)[((size_t)t.inst * N + k) * 4 + l4];
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (t.lane < 13) {
                 const double xb = v13(P.xit, t, N + 1, k, t.lane);
                 if (infeasible) gm(P.xitn)[(t.wave * (N + 1) + k) * SZ_V13 + t.q * 13 + t.lane] = xb + (take ? xs[t.lane] : 0.0);
-                xn = v13(P.b, t, N, k, t.lane);
+                xn = gm(P.b)[abidx(P, t.wave, k) * SZ_V13 + t.q * 13 + t.lane];
                 for (int c = 0; c < 13; c++) xn += a_elem(P, t, k, t.lane, c) * xs[c];
                 for (int a = 0; a < 4; a++) xn += b_elem(P, t, k, t.lane, a) * du[a];
             }

@@ -114,6 +114,9 @@ __device__ __forceinline__ gbyte* gm(unsigned char* p) { return (gbyte*)(unsigne
 __device__ __forceinline__ gdouble* blk(double* f, const Lane& t, int nst, int k, int sz) {
     return gm(f) + ((size_t)t.wave * nst + k) * sz;
 }
+__device__ __forceinline__ gdouble* blkab(const Params& P, double* f, const Lane& t, int k, int sz) {
+    return gm(f) + abidx(P, t.wave, k) * sz;
+}
 // hides a value from common-subexpression elimination (keeps broadcast temporaries short-lived)
 __device__ __forceinline__ void opaque(double& x) { asm volatile("" : "+v"(x)); }
 // a value produced by one of the asm primitives of cfnmpc_dpp.hpp is about to be read through
@@ -258,8 +261,8 @@ struct StageIn {
 template <bool ABSOLUTE>
 __device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const int k, const double wq,
                                            StageIn<ABSOLUTE>& in) {
-    ld_ar_raw(blk(P.AR, t, P.N, k, SZ_A), t, in.ar);
-    ld_rows4_raw(blk(P.BR, t, P.N, k, SZ_B), t, in.br);
+    ld_ar_raw(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
+    ld_rows4_raw(blkab(P, P.BR, t, k, SZ_B), t, in.br);
     const int a = t.L & 3;
     if (ABSOLUTE) {
         const double uk = blk(P.uit, t, P.N, k, SZ_V4)[t.q * 4 + a];   // (start solve: home arrays, wave-blocked)
@@ -268,7 +271,7 @@ __device__ __forceinline__ void load_stage(const Params& P, const Lane& t, const
         const double wa = t.wu;
         in.Rh = wa;                 // read in lanes a < 4 only
         in.g = wa * (uk - yr);
-        in.bv = blk(P.b, t, P.N, k, SZ_V13)[t.q * 13 + imin(t.L, 12)];
+        in.bv = blkab(P, P.b, t, k, SZ_V13)[t.q * 13 + imin(t.L, 12)];
         const double xk = blk(P.xit, t, P.N + 1, k, SZ_V13)[t.q * 13 + imin(t.L, 12)];
         const double yk = yb[t.q * 17 + imin(t.L, 12)];
         in.qv = wq * (xk - yk);     // q_k[i] in lane i < 13

@@ -79,6 +79,7 @@ struct Params {
     double *yref;    // N x SZ_Y
     double *yref_e;  // 1 x SZ_V13
     // linearisation
+    int ab16;    // AR, BR, b of THIS parameter set are grouped by 16 blocks: [group][stage][block of the group][SZ] (the home fields; 0: [block][stage][SZ], the compact store)
     double *AR;  // N x SZ_A   A row-distributed (lane i holds A[i][3..12])
     double *BR;  // N x SZ_B   B row-distributed (lane i holds B[i][0..3])
     double *b;        // N x SZ_V13
@@ -156,6 +157,15 @@ struct Params {
     int cond_N2, cond_M, cond_rem;
     double *cb;                  // condensed blocks, [instance][block][cb_size(w_max)] (layout: cfnmpc_pcond.hip)
 };
+
+// The linearisation (AR, BR, b) of the HOME blocks: [group of 16 blocks][stage][block of the group][sz] -- a lane-per-instance wave
+// (64 instances = one group) then writes one 50 / 27 / 7 KB run per stage and field instead of 16 runs 155 KB apart (49 000 concurrent
+// write streams at 65 536 instances: k_linearise then took 1.0 or 1.25 ms from one process to the next on the same box,
+// profiles/r05_linearise_stores.md), and the 16 row-group waves of a group walk the same 50 KB windows.  The compact store keeps
+// [block][stage][sz] (Params.ab16 = 0 in the kernels' compact parameter sets).
+__device__ __forceinline__ size_t abidx(const Params& P, int wave, int k) {
+    return P.ab16 ? ((size_t)(wave >> 4) * P.N + k) * 16 + (wave & 15) : (size_t)wave * P.N + k;
+}
 
 // ---- partial condensing geometry --------------------------------------------------------------
 constexpr int COND_MMAX = 10;   // longest block supported (4 * 10 = 40 condensed inputs)
