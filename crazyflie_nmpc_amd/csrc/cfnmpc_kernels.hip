@@ -592,12 +592,19 @@ constexpr double AS_BIG = 1e30;
 #define CFN_AS_MAX 12
 #endif
 constexpr int AS_MAX_SOLVES = CFN_AS_MAX;   // observed on the bench workload: 48 % settle after 1 solve, 99 % within 4, all within 8
+// (in two parts: the LOADS of a stage, issued one stage ahead, and what is computed from them -- R^ and b_eff -- right before
+//  the stage uses them.  As one function the arithmetic sat behind the loads it had just issued, `s_waitcnt vmcnt(1)`: the
+//  "prefetched" stage was waited for at once, and with it -- vector-memory operations retire in issue order -- the stores of
+//  the stage before.)
 __device__ __forceinline__ void load_stage_as(const Params& P, const Lane& t, const int k, StageIn<true>& in) {
     ld_ar_raw(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
     ld_rows4_raw(blkab(P, P.BR, t, k, SZ_B), t, in.br);
     const int a = t.L & 3;
-    const double c = gm(P.tl)[i4(P, t, k, a)];
-    const double cls = gm(P.tu)[i4(P, t, k, a)];
+    in.bv = gm(P.tl)[i4(P, t, k, a)];   // c   (until finish_stage_as)
+    in.Rh = gm(P.tu)[i4(P, t, k, a)];   // class
+}
+__device__ __forceinline__ void finish_stage_as(const Lane& t, StageIn<true>& in) {
+    const double c = in.bv, cls = in.Rh;
     const double ra = t.wu;
     in.Rh = cls != 0.0 ? AS_BIG * fmax(1.0, ra) : ra;   // read in lanes a < 4 only (the 1e30 is relative to R)
     in.g = 0.0;
@@ -655,10 +662,12 @@ __device__ __forceinline__ bool sweep_factor_as(const Params& P, const Lane& t, 
     int k = kstart;
     while (k >= 0) {
         load_stage_as(P, t, imax(k - 1, 0), bufB);
+        finish_stage_as(t, bufA);
         ok = factor_stage<true, true, false, QT>(P, t, k, Pa, bufA, wq, is13, wt, sb, true, qtab) && ok;
         keep(k);
         if (--k < 0) break;
         load_stage_as(P, t, imax(k - 1, 0), bufA);
+        finish_stage_as(t, bufB);
         ok = factor_stage<true, true, false, QT>(P, t, k, Pa, bufB, wq, is13, wt, sb, true, qtab) && ok;
         keep(k);
         --k;
