@@ -1795,9 +1795,9 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             if (R.act) R.iters++;
             // predictor: factorise (R^, g from the element-wise pass), forward
             PROF_T(1)
-            const bool fok = sweep_factor<false>(Q, tc, head, chk, wt, sb);
+            const bool fok = sweep_factor<false>(Q, lane_opaque(tc), head, chk, wt, sb);
             PROF_T(2)
-            sweep_forward_delta(Q, tc, head, gm(Q.dva));
+            sweep_forward_delta(Q, lane_opaque(tc), head, gm(Q.dva));
             PROF_T(3)
             // affine step length, mu_aff, centering; corrector right-hand side.  Three dependent
             // passes (row reductions in between); a row with at most 64 inputs (head <= 16) keeps
@@ -1850,9 +1850,9 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             }
             // corrector: re-solve, forward
             PROF_T(4)
-            sweep_resolve(Q, tc, head);
+            sweep_resolve(Q, lane_opaque(tc), head);
             PROF_T(5)
-            sweep_forward_delta(Q, tc, head, gm(Q.dvc));
+            sweep_forward_delta(Q, lane_opaque(tc), head, gm(Q.dvc));
             PROF_T(3)
             // step, update, residuals of the new point, next R^ and g (two dependent passes)
             {

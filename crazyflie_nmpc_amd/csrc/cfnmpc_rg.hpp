@@ -74,6 +74,13 @@ struct Lane {
                 // chain at the point of use gets turned into a lookup table in scratch, whose load
                 // then sits in the middle of the prefetch queue of every stage)
 };
+// An opaque copy of the lane indices: addresses formed from it cannot be hoisted above this point (a kernel that calls several
+// sweeps inside an iteration loop otherwise keeps every sweep's loop-invariant addresses and selects live over the whole loop).
+__device__ __forceinline__ Lane lane_opaque(const Lane& t) {
+    Lane o = t;
+    asm volatile("" : "+v"(o.L), "+v"(o.q), "+v"(o.wave), "+v"(o.inst));
+    return o;
+}
 __device__ __forceinline__ Lane lane_id(const Params& P) {
     Lane t;
     t.L = threadIdx.x & 15;
