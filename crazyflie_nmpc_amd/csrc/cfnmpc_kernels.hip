@@ -924,6 +924,10 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
     }
     In cur, nxt;
     load(k_lo, cur);
+    // (waited for HERE: the compiler sizes the wait at the loop's top for the worse of its two entries, and from this side nothing
+    //  younger than the loads is in flight -- it would be vmcnt(0), i.e. every stage would also wait for the 13 state stores the
+    //  stage before issued behind its loads)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     double dxb[13];            // COND: state step at the start of the current block
     int knext = 0, jblk = 0;   // COND: first stage and index of the next block
     for (int k = k_lo; k < k_hi; k++) {
