@@ -444,18 +444,21 @@ struct FwdIn {
 };
 template <bool WITH_B>
 __device__ __forceinline__ void load_fwd(const Params& P, const Lane& t, const int k, FwdIn<WITH_B>& in) {
-    ld_cols4(blk(P.KR, t, P.N, k, SZ_K), t, in.kr);
-    ld_ar(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
-    ld_rows4(blkab(P, P.BR, t, k, SZ_B), t, in.br);
+    // (raw: feedback() / propagate() mask what they read, cfnmpc_rg.hpp: mask_*)
+    ld_cols4_raw(blk(P.KR, t, P.N, k, SZ_K), t, in.kr);
+    ld_ar_raw(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
+    ld_rows4_raw(blkab(P, P.BR, t, k, SZ_B), t, in.br);
     in.d = gm(P.d)[i4(P, t, k, t.L & 3)];
-    in.bv = WITH_B ? ld13(blkab(P, P.b, t, k, SZ_V13), t) : 0.0;
+    in.bv = WITH_B ? ld13_raw(blkab(P, P.b, t, k, SZ_V13), t) : 0.0;
 }
 // v = -K x - d in lanes a < 4
 template <bool WITH_B>
 __device__ __forceinline__ double feedback(const Lane& t, const FwdIn<WITH_B>& in, const double x) {
     double v = t.L < 4 ? -in.d : 0.0;
     double acc = 0.0;
-    dotbc<13, 0>(acc, in.kr, x);
+    double kr[13];
+    mask_cols4(t, in.kr, kr);
+    dotbc<13, 0>(acc, kr, x);
     v -= acc;
     settle(v);
     return v;
@@ -464,9 +467,12 @@ __device__ __forceinline__ double feedback(const Lane& t, const FwdIn<WITH_B>& i
 template <bool WITH_B>
 __device__ __forceinline__ double propagate(const Lane& t, const FwdIn<WITH_B>& in, const double x, const double (&vr)[4]) {
     double xn = t.L < 3 ? x : 0.0;
-    if (WITH_B) xn += in.bv;
-    dotbc<10, 3>(xn, in.ar, x);
-    SFOR(a, 0, 4, { xn += in.br[a] * vr[a]; });
+    if (WITH_B) xn += mask13(t, in.bv);
+    double ar[10], br[4];
+    mask_ar(t, in.ar, ar);
+    mask_rows4(t, in.br, br);
+    dotbc<10, 3>(xn, ar, x);
+    SFOR(a, 0, 4, { xn += br[a] * vr[a]; });
     return xn;
 }
 
@@ -691,8 +697,8 @@ __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, 
         const gdouble* gb = blk(P.cGR, t, P.N, k, SZ_K);
         const gdouble* src = (lo4 ? kb : gb) + t.q * 4 + a;
         SFOR(l, 0, 13, { in.kg[l] = src[l * 16]; });
-        ld_ar(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
-        ld_rows4(blkab(P, P.BR, t, k, SZ_B), t, in.br);
+        ld_ar_raw(blkab(P, P.AR, t, k, SZ_A), t, in.ar);      // (masked in body())
+        ld_rows4_raw(blkab(P, P.BR, t, k, SZ_B), t, in.br);
         const gdouble* sr = blk(P.cS, t, P.N, k, SZ_S4) + t.q * 4 + a;
         SFOR(c, 0, 4, { in.sr[c] = sr[c * 16]; });
         const size_t idx = i4(P, t, k, a);
@@ -731,8 +737,11 @@ __device__ __forceinline__ int sweep_forward_as(const Params& P, const Lane& t, 
             gm(P.tl)[idx] = nc == 1.0 ? lb - cur.v0 : (nc == 2.0 ? ub - cur.v0 : 0.0);
         }
         double xn = t.L < 3 ? x : 0.0;
-        dotbc<10, 3>(xn, cur.ar, x);
-        SFOR(c, 0, 4, { xn += cur.br[c] * vr[c]; });
+        double ar[10], br[4];
+        mask_ar(t, cur.ar, ar);
+        mask_rows4(t, cur.br, br);
+        dotbc<10, 3>(xn, ar, x);
+        SFOR(c, 0, 4, { xn += br[c] * vr[c]; });
         x = xn;
         if (ZDX && t.L < 13) gm(P.czdx)[((size_t)t.inst * (P.N + 1) + k + 1) * 13 + t.L] = x;
     };
@@ -1196,7 +1205,7 @@ __device__ __forceinline__ void forward_rg_body(const Params& P) {
         load_fwd<true>(P, t, k, in.f);
         in.u = gm(P.uit)[i4(P, t, k, a)];
         box_at<SBOX>(P, i4(P, t, k, a), in.lo, in.hi);
-        in.xb = ld13(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);
+        in.xb = ld13_raw(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);   // (stored by st13: lanes < 13 only)
     };
     double xbcur = ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
     double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - xbcur;
@@ -1929,17 +1938,17 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             // three quarters of every cache line foreign) and need no gain; b and the tail come from the home blocks
             auto load_roll = [&](int k, FwdIn<true>& in) {
                 if (CST) {   // everything but the start solve's gains from the compact copy
-                    ld_ar(blkab(Q, Q.AR, tc, k, SZ_A), tc, in.ar);
-                    ld_rows4(blkab(Q, Q.BR, tc, k, SZ_B), tc, in.br);
-                    in.bv = ld13(blk(P.cbv, tc, N, k, SZ_V13), tc);
+                    ld_ar_raw(blkab(Q, Q.AR, tc, k, SZ_A), tc, in.ar);
+                    ld_rows4_raw(blkab(Q, Q.BR, tc, k, SZ_B), tc, in.br);
+                    in.bv = ld13_raw(blk(P.cbv, tc, N, k, SZ_V13), tc);
                     if (k >= head) {
-                        ld_cols4(blk(P.KR, t, N, k, SZ_K), t, in.kr);
+                        ld_cols4_raw(blk(P.KR, t, N, k, SZ_K), t, in.kr);
                         in.d = gm(P.d)[i4(P, t, k, t.L & 3)];
                     }
                 } else if (k < head) {
-                    ld_ar(blkab(Q, Q.AR, tc, k, SZ_A), tc, in.ar);
-                    ld_rows4(blkab(Q, Q.BR, tc, k, SZ_B), tc, in.br);
-                    in.bv = ld13(blkab(P, P.b, t, k, SZ_V13), t);
+                    ld_ar_raw(blkab(Q, Q.AR, tc, k, SZ_A), tc, in.ar);
+                    ld_rows4_raw(blkab(Q, Q.BR, tc, k, SZ_B), tc, in.br);
+                    in.bv = ld13_raw(blkab(P, P.b, t, k, SZ_V13), t);
                 } else {
                     load_fwd<true>(P, t, k, in);
                 }
@@ -1954,7 +1963,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 in.v = gm(Q.v)[i4(Q, tc, imin(k, head - 1), t.L & 3)];
                 in.u = gm(P.uit)[i4(P, t, k, t.L & 3)];
                 box_at<SBOX>(P, i4(P, t, k, t.L & 3), in.blo, in.bhi);
-                in.xb = ld13(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);   // x_{k+1} of the old iterate
+                in.xb = ld13_raw(blk(P.xit, t, N + 1, k + 1, SZ_V13), t);   // x_{k+1} of the old iterate (stored by st13: lanes < 13)
             };
             auto body_roll = [&](const RollIn& cur, int k) {
                 st13(blk(P.xitn, t, N + 1, k, SZ_V13), t, xbcur + x);
@@ -2600,9 +2609,9 @@ __device__ __forceinline__ void ascommit_body(const Params& P) {
         //     delta through the closed loop of the unconstrained feedback law (K, A, B of the home blocks)
         struct In { double kr[13], ar[10], br[4], un, xc, dv, zx; };
         auto load = [&](int k, In& in) {
-            ld_cols4(blk(P.KR, t, N, k, SZ_K), t, in.kr);
-            ld_ar(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
-            ld_rows4(blkab(P, P.BR, t, k, SZ_B), t, in.br);
+            ld_cols4_raw(blk(P.KR, t, N, k, SZ_K), t, in.kr);   // (masked in body())
+            ld_ar_raw(blkab(P, P.AR, t, k, SZ_A), t, in.ar);
+            ld_rows4_raw(blkab(P, P.BR, t, k, SZ_B), t, in.br);
             in.un = gm(P.uitn)[i4(P, t, k, a)];
             in.xc = blk(P.xitn, t, N + 1, k + 1, SZ_V13)[lx];
             in.dv = gm(Q.dva)[cb4 + (size_t)imin(k, imax(head - 1, 0)) * 4];
@@ -2611,7 +2620,11 @@ __device__ __forceinline__ void ascommit_body(const Params& P) {
         auto body = [&](const In& cur, int k) {
             const bool tail = k >= head;
             double acc = 0.0;
-            dotbc<13, 0>(acc, cur.kr, x);
+            double kr[13], ar[10], br[4];
+            mask_cols4(t, cur.kr, kr);
+            mask_ar(t, cur.ar, ar);
+            mask_rows4(t, cur.br, br);
+            dotbc<13, 0>(acc, kr, x);
             double v = lo4 ? -acc : 0.0;
             settle(v);
             v = tail ? v : (lo4 ? cur.dv : 0.0);
@@ -2623,8 +2636,8 @@ __device__ __forceinline__ void ascommit_body(const Params& P) {
             double vr[4];
             SFOR(cc, 0, 4, { vr[cc] = bc<cc>(v); });
             double xn = t.L < 3 ? x : 0.0;
-            dotbc<10, 3>(xn, cur.ar, x);
-            SFOR(cc, 0, 4, { xn += cur.br[cc] * vr[cc]; });
+            dotbc<10, 3>(xn, ar, x);
+            SFOR(cc, 0, 4, { xn += br[cc] * vr[cc]; });
             x = (k + 1 <= head) ? (t.L < 13 ? cur.zx : 0.0) : xn;
             if (t.L < 13 && go) blk(P.xitn, t, N + 1, k + 1, SZ_V13)[lx] = cur.xc + x;
         };

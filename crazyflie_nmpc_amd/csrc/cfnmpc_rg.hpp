@@ -177,6 +177,20 @@ __device__ __forceinline__ void ld_rows4_raw(const gdouble* b, const Lane& t, do
 __device__ __forceinline__ void ld_cols4_raw(const gdouble* b, const Lane& t, double (&c)[13]) {
     SFOR(l, 0, 13, { c[l] = b[(l * 4 + t.q) * 4 + (t.L & 3)]; });
 }
+// Selects of the masked loaders as functions of their own: a stage that is PREFETCHED is loaded raw and masked where it is used --
+// a select placed right behind the load (the compiler does, when registers are tight) waits for the load it belongs to and, vector-
+// memory operations retiring in issue order, for everything requested before it: the whole prefetch queue.
+__device__ __forceinline__ double ld13_raw(const gdouble* b, const Lane& t) { return b[t.q * 13 + imin(t.L, 12)]; }
+__device__ __forceinline__ double mask13(const Lane& t, double v) { return t.L < 13 ? v : 0.0; }
+__device__ __forceinline__ void mask_ar(const Lane& t, const double (&in)[10], double (&ar)[10]) {
+    SFOR(s, 0, 10, { ar[s] = t.L < ar_n(s) ? in[s] : 0.0; });
+}
+__device__ __forceinline__ void mask_rows4(const Lane& t, const double (&in)[4], double (&r)[4]) {
+    SFOR(a, 0, 4, { r[a] = t.L < 13 ? in[a] : 0.0; });
+}
+__device__ __forceinline__ void mask_cols4(const Lane& t, const double (&in)[13], double (&c)[13]) {
+    SFOR(l, 0, 13, { c[l] = t.L < 4 ? in[l] : 0.0; });
+}
 __device__ __forceinline__ void ld_rows4(const gdouble* b, const Lane& t, double (&r)[4]) {  // BR / KP
     SFOR(a, 0, 4, {
         const double v = b[(a * 4 + t.q) * 13 + imin(t.L, 12)];
