@@ -1655,10 +1655,10 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             const bool any_try = __any(try_as);
             for (int it = 1; any_try && it <= AS_MAX_SOLVES; it++) {
                 PROF_T(1)
-                as_ok = sweep_factor_as<QT>(Q, tc, head, chk, kstart, wt, sb, qtab) && as_ok;
+                as_ok = sweep_factor_as<QT>(Q, lane_opaque(tc), head, chk, kstart, wt, sb, qtab) && as_ok;
                 PROF_T(2)
                 PROF_SOLVE(kstart + 1)
-                int jw = sweep_forward_as<SBOX, NO_ROLL>(Q, tc, head);
+                int jw = sweep_forward_as<SBOX, NO_ROLL>(Q, lane_opaque(tc), head);
                 const bool changed = jw >= 0;
                 jw = max(jw, __shfl_xor(jw, 16));
                 jw = max(jw, __shfl_xor(jw, 32));
