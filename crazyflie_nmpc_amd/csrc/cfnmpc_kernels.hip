@@ -597,6 +597,9 @@ constexpr double AS_BIG = 1e30;
 #ifndef CFN_AS_MAX
 #define CFN_AS_MAX 12
 #endif
+#ifndef CFN_ROLL_DEPTH
+#define CFN_ROLL_DEPTH 3   // (4: the same, 5: slower -- measured with the phases on opaque lane copies, 342 registers in k_as)
+#endif
 constexpr int AS_MAX_SOLVES = CFN_AS_MAX;   // observed on the bench workload: 48 % settle after 1 solve, 99 % within 4, all within 8
 // (in two parts: the LOADS of a stage, issued one stage ahead, and what is computed from them -- R^ and b_eff -- right before
 //  the stage uses them.  As one function the arithmetic sat behind the loads it had just issued, `s_waitcnt vmcnt(1)`: the
@@ -1572,7 +1575,9 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     Q.AR = P.cAR; Q.BR = P.cBR; Q.KR = P.cKR; Q.Sinv = P.cSinv; Q.d = P.cd; Q.Pchk = P.cPchk; Q.v = P.cv; Q.uit = P.cuit;
     Q.lbs = P.clbs; Q.ubs = P.cubs;
     const size_t cbase = (size_t)tc.inst * N * 4;  // compact 4-vectors of this row
+    const Lane& t_ = t; const Lane& tc_ = tc;
     auto gather = [&](int hd, int ck) {
+        const Lane t = lane_opaque(t_), tc = lane_opaque(tc_);   // (this phase's addresses stay inside it)
         // four stages per batch, loads first (the source lines are cold: one HBM round trip each)
         for (int k0 = 0; k0 < hd; k0 += 4) {
             double ar[4][10], br[4][4], vv[4], uu[4], blo[4], bhi[4];
@@ -1932,6 +1937,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         {
             // the candidate iterate (old + step) goes straight into the new iterate buffers: a row that
             // is not accepted is overwritten again (retry / interior-point launch) or restored (keep_row)
+            const Lane t = lane_opaque(t_), tc = lane_opaque(tc_);   // (the roll-out's addresses stay inside it)
             double xbcur = ld13(blk(P.xit, t, N + 1, 0, SZ_V13), t);
             double x = ld13(blk(P.x0, t, 1, 0, SZ_V13), t) - xbcur;
             // head stages take A, B from the wave's compact copy (the home blocks are interleaved with the three wave-mates:
@@ -1981,20 +1987,18 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 x = propagate<true>(t, cur.f, x, vr);
                 xbcur = cur.xb;
             };
-            RollIn r0, r1, r2;
-            load_stage_roll(0, r0);
-            load_stage_roll(imin(1, N - 1), r1);
+            constexpr int RD = CFN_ROLL_DEPTH;   // rotating buffers: stage k + RD - 1 is requested before stage k is computed
+            RollIn rb[RD];
+            SFOR(j, 0, RD - 1, { load_stage_roll(imin(j, N - 1), rb[j]); });
             int k = 0;
             while (k < N) {
-                load_stage_roll(imin(k + 2, N - 1), r2);
-                body_roll(r0, k);
-                if (++k >= N) break;
-                load_stage_roll(imin(k + 2, N - 1), r0);
-                body_roll(r1, k);
-                if (++k >= N) break;
-                load_stage_roll(imin(k + 2, N - 1), r1);
-                body_roll(r2, k);
-                ++k;
+                SFOR(j, 0, RD, {
+                    if (k < N) {
+                        load_stage_roll(imin(k + RD - 1, N - 1), rb[(j + RD - 1) % RD]);
+                        body_roll(rb[j], k);
+                        ++k;
+                    }
+                });
             }
             st13(blk(P.xitn, t, N + 1, N, SZ_V13), t, xbcur + x);
             kviol = (int)row_max((double)kviol);
