@@ -292,16 +292,17 @@ KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
         SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
         // every DPP row of the wave addresses the same instance (the stage matrices are broadcast sources inside a row)
         const Lane t = lane_indirect(P, inst, true);
+        const Lane& t_ = t;
         // this lane's input (k_j, a_j): unconstrained minimiser and iterate, in flight during the build
         const size_t e4 = i4(P, t, imin(lane >> 2, head - 1), lane & 3);
         const double v0 = lane < 4 * head ? gm(P.v)[e4] : 0.0;
         const double uk = lane < 4 * head ? gm(P.uit)[e4] : 0.0;
         __syncthreads();
-        dense_stage(P, t, head, chk, S.G, S.pm);
+        dense_stage(P, lane_opaque(t), head, chk, S.G, S.pm);
         __syncthreads();
         DPROF(0)
-        if (head > 8) dense_build<true>(P, t, head, chk, S);
-        else dense_build<false>(P, t, head, chk, S);
+        if (head > 8) dense_build<true>(P, lane_opaque(t), head, chk, S);
+        else dense_build<false>(P, lane_opaque(t), head, chk, S);
         __syncthreads();
         DPROF(1)
         int solves;
@@ -316,6 +317,7 @@ KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
             if (lane < 4 * head) gm(P.dva)[(size_t)slot * N * 4 + lane] = dl;
             // the stage matrices once more (the H store is free again): staged with all loads in flight, then the sequential sweep
             __syncthreads();
+            const Lane t = lane_opaque(t_);   // (the sweep's addresses stay inside it)
             {
                 StageOps o[4];
                 SFOR(b, 0, 4, { load_ops(P, t, imin(4 * b + t.row, head - 1), o[b]); });
