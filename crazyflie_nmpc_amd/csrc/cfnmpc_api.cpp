@@ -329,8 +329,6 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.as_warm = (o.as_warm && o.active_set) ? 1 : 0;
     if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise) ||
         (o.reinit_failed && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
-    // (an explicitly fused start solve stores no stage blocks: the automatic choice then stays with the matrix-free sweep)
-    P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && pick.forward_rg && o.start_solve != 2) ? 1 : 0;
     if (o.as_passes < -3 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
     // internal: 0 = monolithic k_as, -1 = every solve in one launch on the compact z store + commit, -2 = the monolithic
     // kernel's solves + commit, p > 0 = p single-solve passes
@@ -353,10 +351,25 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.as_sparse_max = P.as_grid / 2;   // = the SIMDs of the device: one constrained row per wave while they all fit at once
     P.ipm_listed = pick.ipm_listed ? 1 : 0;
     // head-condensed dense active-set solves (cfnmpc_asdense.hip) beside the solves + commit structure; scalar box, stored blocks
-    if (o.as_dense < -1 || o.as_dense > 1) { delete s; return CFNMPC_EINVAL; }
+    // (every option is validated BEFORE the side streams below are created: the refusals here own nothing but `s`)
+    if (o.as_dense < -1 || o.as_dense > 1 || o.start_solve < 0 || o.start_solve > 3 || o.forward_split < -1 || o.forward_split > 1) { delete s; return CFNMPC_EINVAL; }
     if (o.as_dense == 1 && (P.as_passes != -2 && o.as_passes != 0)) { delete s; return CFNMPC_EINVAL; }
     if (o.as_dense == 1 && o.as_passes == 0 && o.start_solve != 2 && !cond_N2) P.as_passes = -2;   // asked for: the structure it lives in
     P.as_dense = (P.as_passes == -2 && P.active_set && !P.as_warm && o.as_dense != -1 && (o.as_dense == 1 || pick.as_dense)) ? 1 : 0;
+    // an EXPLICIT request that cannot be honoured is refused, not dropped (as_dense = 1 beside start_solve = 2, cond_N2, as_warm or
+    // active_set = 0; forward_split = 1 outside the dense structure, with the row-group sweep, short horizons or the overlapped
+    // preparation -- whose early pass would read the iterate while part two of the sweep is still writing it)
+    if (o.as_dense == 1 && !P.as_dense) { delete s; return CFNMPC_EINVAL; }
+    const bool split_ok = P.as_dense && !cond_N2 && o.start_solve != 2 && o.start_solve != 3 && o.N >= 40 && !o.overlap_linearise &&
+                          o.forward_sweep != 2 && o.forward_split != -1;
+    if (o.forward_split == 1 && !split_ok) { delete s; return CFNMPC_EINVAL; }
+    // forward sweep on the stored blocks (row groups) below 6 S instances where the split matrix-free sweep takes over from there;
+    // where it cannot run (short horizons, no dense structure, ...) the unsplit matrix-free sweep wins from 8 S on only
+    // (an explicitly fused start solve stores no stage blocks: the automatic choice then stays with the matrix-free sweep)
+    {
+        const bool auto_rg = split_ok ? pick.forward_rg : (long)batch < 8L * simds;
+        P.forward_rg = o.forward_sweep == 2 || (o.forward_sweep == 0 && auto_rg && o.start_solve != 2 && !(o.forward_split == 1)) ? 1 : 0;
+    }
     if (P.as_dense) {   // side stream of the rows with long heads (launch_qp_ipm); without it the two kernels simply run one after the other
         hipStream_t side = nullptr;
         hipEvent_t ef = nullptr, ej = nullptr;
@@ -380,18 +393,16 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     // start solve: the fused kernel replaces k_linearise + k_factor where nothing but the constrained instances' QP kernels
     // reads the stage blocks afterwards (matrix-free forward sweep, monolithic active-set kernel, no partial condensing,
     // no overlapped preparation); per-stage boxes (cfnmpc_set_box_stages) switch a solver back at launch time
-    if (o.start_solve < 0 || o.start_solve > 3) { delete s; return CFNMPC_EINVAL; }
     {
         const bool can_fuse = !cond_N2 && !o.overlap_linearise && !P.forward_rg && P.as_passes == 0;
-        if (o.start_solve == 2 && !can_fuse) { delete s; return CFNMPC_EINVAL; }
-        if (o.start_solve == 3 && (cond_N2 || o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
+        if (o.start_solve == 2 && !can_fuse) { cfnmpc_free(s); return CFNMPC_EINVAL; }
+        if (o.start_solve == 3 && (cond_N2 || o.overlap_linearise)) { cfnmpc_free(s); return CFNMPC_EINVAL; }
         P.fused = o.start_solve == 2 ? 1 : (o.start_solve == 3 ? 2 : 0);
         P.clist_chunks = o.N >= 10 ? 10 : o.N;
     }
     // split forward sweep: lives in the dense structure (two side streams), matrix-free sweep, horizons that reach well behind H
-    if (o.forward_split < -1 || o.forward_split > 1) { cfnmpc_free(s); return CFNMPC_EINVAL; }
-    P.fwd_split = (P.as_dense && P.as_side2 && !P.forward_rg && !cond_N2 && P.fused == 0 && o.N >= 40 && o.forward_split != -1 &&
-                   (o.forward_split == 1 || pick.forward_split)) ? 24 : 0;
+    // (without the second side stream -- its creation failed -- the sweep stays in one launch)
+    P.fwd_split = (split_ok && P.as_side2 && !P.forward_rg && P.fused == 0 && (o.forward_split == 1 || pick.forward_split)) ? 24 : 0;
     P.cond_N2 = cond_N2;
     P.ab16 = 1;                // home A, B, b grouped by 16 blocks (cfnmpc_rg.hpp: abidx)
     P.v4b = cond_N2 ? 0 : 1;   // home 4-vectors wave-blocked (the condensed kernels index theirs instance-major)
@@ -1150,6 +1161,19 @@ int cfnmpc_debug_get_head(cfnmpc_solver* s, int* head) {
     DeviceGuard dg(s);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(head, s->P.head, (size_t)s->P.B * sizeof(int), hipMemcpyDeviceToHost));
+    return CFNMPC_OK;
+}
+
+// Work-list counts of the last step's constrained-QP phase (host array of four ints): constrained rows the compaction listed |
+// rows listed for the interior-point fall-back (fleets that compact them: >= 16 S instances; else 0) | listed rows with heads of
+// more than 16 stages | LATE rows of a split forward sweep (first violation behind stage 24, appended to the list by part two).
+int cfnmpc_debug_get_list_counts(cfnmpc_solver* s, int* counts) {
+    if (!s || !counts) return CFNMPC_EINVAL;
+    DeviceGuard dg(s);
+    HIP_TRY(hipDeviceSynchronize());
+    int h[64];
+    HIP_TRY(hipMemcpy(h, s->P.nipm, sizeof h, hipMemcpyDeviceToHost));
+    counts[0] = h[0]; counts[1] = s->P.ipm_listed ? h[40] : 0; counts[2] = h[41]; counts[3] = s->P.fwd_split ? h[42] : 0;
     return CFNMPC_OK;
 }
 

@@ -2063,7 +2063,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
 __global__ __launch_bounds__(1024) void k_ipm_list(Params P) {
     __shared__ int cnt[1024];
     const int tid = threadIdx.x;
-    const int n = gm(P.nipm)[0];
+    const int n = gm(P.nipm)[0] + (P.fwd_split ? gm(P.nipm)[42] : 0);   // (+ the late rows of a split forward sweep)
     const int chunk = (n + 1023) / 1024;
     const int lo = tid * chunk, hi = min(lo + chunk, n);
     int c = 0;
@@ -2106,6 +2106,11 @@ __global__ __launch_bounds__(1024) void k_ipm_list(Params P) {
         }
     }
 }
+// rows the interior-point fall-back has to look at: the compacted fall-back list, or the whole list + the late rows of a
+// split forward sweep (qp_wave<2> counts the same way)
+__device__ __forceinline__ int ipm_rest_rows(const Params& P) {
+    return P.ipm_listed ? gm(P.nipm)[40] : gm(P.nipm)[0] + (P.fwd_split ? gm(P.nipm)[42] : 0);
+}
 __global__ __launch_bounds__(64) void k_ipm(Params P) {       // MODE 0: used when active_set = 0
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
@@ -2122,7 +2127,7 @@ KALIGN __global__ __launch_bounds__(64) void k_as(Params P) {        // active-s
 __global__ __launch_bounds__(64) void k_ipm_rest(Params P) {  // interior point for what k_as left
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[P.ipm_listed ? 40 : 0]; vb += gridDim.x) qp_wave<2>(P, wtile, btile, vb);
+    for (int vb = blockIdx.x; vb * 4 < ipm_rest_rows(P); vb += gridDim.x) qp_wave<2>(P, wtile, btile, vb);
 }
 // the same three for per-stage input boxes (cfnmpc_set_box_stages)
 __global__ __launch_bounds__(64) void k_ipm_sbox(Params P) {
@@ -2138,7 +2143,7 @@ __global__ __launch_bounds__(64) void k_as_sbox(Params P) {
 __global__ __launch_bounds__(64) void k_ipm_rest_sbox(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[P.ipm_listed ? 40 : 0]; vb += gridDim.x) qp_wave<2, true>(P, wtile, btile, vb);
+    for (int vb = blockIdx.x; vb * 4 < ipm_rest_rows(P); vb += gridDim.x) qp_wave<2, true>(P, wtile, btile, vb);
 }
 // the three for the fused start solve (Params.fused = 1: stage blocks only in the compact store)
 __global__ __launch_bounds__(64) void k_ipm_cst(Params P) {
@@ -2154,7 +2159,7 @@ KALIGN __global__ __launch_bounds__(64) void k_as_cst(Params P) {
 __global__ __launch_bounds__(64) void k_ipm_rest_cst(Params P) {
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
     __shared__ double btile[4][64];
-    for (int vb = blockIdx.x; vb * 4 < gm(P.nipm)[P.ipm_listed ? 40 : 0]; vb += gridDim.x) qp_wave<2, false, true>(P, wtile, btile, vb);
+    for (int vb = blockIdx.x; vb * 4 < ipm_rest_rows(P); vb += gridDim.x) qp_wave<2, false, true>(P, wtile, btile, vb);
 }
 __global__ __launch_bounds__(64) void k_as_solves(Params P) {  // MODE 4: active-set solves, no roll-out
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];

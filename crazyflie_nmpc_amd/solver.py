@@ -295,6 +295,13 @@ class BatchSolver:
         return (H.reshape(-1)[:self.B * wj * wj].reshape(self.B, wj, wj).copy(),      # (the library packs with the block's own w)
                 D.reshape(-1)[:self.B * NX * wj].reshape(self.B, NX, wj).copy(), m.value)
 
+    def list_counts(self):
+        """-> (constrained rows listed, rows listed for the interior-point fall-back, listed rows with heads > 16 stages,
+        late rows of a split forward sweep) of the last step"""
+        c = np.zeros(4, dtype=np.int32)
+        _check(self._L.cfnmpc_debug_get_list_counts(self._h, c.ctypes.data_as(C.c_void_p)), "cfnmpc_debug_get_list_counts")
+        return tuple(int(v) for v in c)
+
     def heads(self):
         h = np.empty(self.B, dtype=np.int32)
         _check(self._L.cfnmpc_debug_get_head(self._h, h.ctypes.data_as(C.c_void_p)), "cfnmpc_debug_get_head")

@@ -198,16 +198,24 @@ typedef struct cfnmpc_opts {
                             active set (csrc/cfnmpc_asdense.hip) -- instead of one Riccati factorisation + forward sweep over the
                             head per solve.  Same classification rule, same solve counts, same solutions to rounding (the reference's
                             own plan condenses too: PARTIAL_CONDENSING_HPIPM, generate_c_code.py:140).  1 = on (selects the solves +
-                            commit structure), -1 = off, 0 (default) = by measurement.  Scalar box only;
-                            not with as_warm. */
+                            commit structure), -1 = off, 0 (default) = by measurement.  Scalar box only
+                            (while per-stage boxes are set the monolithic kernels run).  An explicit 1 that cannot be honoured --
+                            together with as_warm, active_set = 0, cond_N2, start_solve = 2 or as_passes other than 0 / -3 -- is
+                            refused (CFNMPC_EINVAL), not dropped. */
     int forward_split;   /* start solve, matrix-free forward sweep inside the as_dense structure: 1 = in TWO launches -- stages [0, 24)
                             with the classification of the instances over that window, the compaction, and stages [24, N) of every
                             instance BESIDE the constrained rows' kernels (their heads of at most 24 stages read nothing behind
                             stage 24; rows with longer heads follow the second part on its stream) -- half of the sweep's 50-stage
                             latency chain leaves the critical path of a small fleet's step.  An instance that is feasible over the
                             first window and leaves the box behind it joins the list late and is solved with the retry kernel.
-                            Same results (candidates bitwise; a row's head class is decided from the first window, the tail
-                            verification extends it where that was too short).  -1 = off, 0 (default) = by measurement. */
+                            Same SOLUTIONS (candidates bitwise; a row's head class and its violation measure -- what as_skip_viol
+                            and ipm_clip_viol compare -- come from the first window only, so a row may take another route than
+                            with the single launch: a retry over a longer head after the tail verification, the active-set
+                            iteration instead of the interior point or the other way round; either route ends at the QP's one
+                            solution, to its own accuracy).  -1 = off, 0 (default) = by measurement.  An explicit 1 that cannot
+                            be honoured -- outside the as_dense structure, N < 40, forward_sweep = 2, cond_N2, start_solve 2 / 3,
+                            overlap_linearise (its early pass would read the iterate part two is still writing) -- is refused
+                            (CFNMPC_EINVAL). */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);   /* unchecked: the caller's struct MUST be this header's */
@@ -348,6 +356,9 @@ int cfnmpc_debug_get_condensed(cfnmpc_solver *s, int block, double *H, double *D
 /* number of leading stages the last QP's interior-point sweeps covered, per instance [B] (host) */
 int cfnmpc_debug_get_viol(cfnmpc_solver *s, double *viol /*[B]*/);
 int cfnmpc_debug_get_head(cfnmpc_solver *s, int *head);
+/* work-list counts of the last step (host, four ints): constrained rows listed | rows listed for the interior-point fall-back
+ * (fleets that compact them; else 0) | listed rows with heads of more than 16 stages | late rows of a split forward sweep */
+int cfnmpc_debug_get_list_counts(cfnmpc_solver *s, int *counts /*[4]*/);
 
 /* ---- mixed-horizon fleets (BASELINE.json config C5: N in {30, 50, 100} side by side) ----------
  * The reference fixes N when the solver is generated (generate_c_code.py:41-42; one process per

@@ -643,6 +643,86 @@ def pdas_dense(qp: StageQP, max_solves=12, warm_cls=None):
     return dict(dx=dx, du=v.reshape(qp.N, NU), solves=solves, converged=converged, cls=cls)
 
 
+def qp_from_blocks(A, B, b, q, r, dx0, Qd, Rd, QNd, lb, ub):
+    """StageQP from given stage blocks (e.g. the engine's or the C restatement's linearisation: cfnmpc_debug_get_linearisation,
+    cref.linearise) and weights other than the generator's defaults."""
+    qp = StageQP(A.shape[0])
+    qp.A[:], qp.B[:], qp.b[:], qp.q[:], qp.r[:] = A, B, b, q, r
+    qp.dx0 = np.asarray(dx0, dtype=np.float64).copy()
+    qp.Qd, qp.Rd, qp.QNd = (np.asarray(v, dtype=np.float64).copy() for v in (Qd, Rd, QNd))
+    qp.lb[:], qp.ub[:] = lb, ub
+    return qp
+
+
+def solve_qp_refined(qp: StageQP, max_solves=80):
+    """REFEREE between two FP64 solvers that disagree above their own tolerances: the exact solution of the (strictly convex,
+    hence unique: generate_c_code.py:140 names one QP, whatever solves it) RTI QP in EXTENDED precision -- the stage data are
+    taken as exact, the condensed H, h are formed in x87 80-bit arithmetic (numpy longdouble, eps 1.1e-19), the primal-dual
+    active-set iteration of pdas_dense runs on them with every linear solve refined against extended-precision residuals
+    (FP64 LU as the preconditioner), and the KKT conditions of the result are checked in extended precision.
+    -> dict(dx, du (FP64 roundings of the extended solution), cls, solves, kkt (max KKT violation), cond (of H_FF), eps)."""
+    LD = np.longdouble
+    N = qp.N
+    nU = N * NU
+    A, B, b = qp.A.astype(LD), qp.B.astype(LD), qp.b.astype(LD)
+    Gam = np.zeros(((N + 1) * NX, nU), dtype=LD)
+    g = np.zeros((N + 1) * NX, dtype=LD)
+    g[:NX] = qp.dx0
+    for k in range(N):
+        r0, r1 = k * NX, (k + 1) * NX
+        Gam[r1:r1 + NX, :] = A[k] @ Gam[r0:r1, :]
+        Gam[r1:r1 + NX, k * NU:(k + 1) * NU] += B[k]
+        g[r1:r1 + NX] = A[k] @ g[r0:r1] + b[k]
+    Qbar = np.concatenate([np.tile(qp.Qd, N), qp.QNd]).astype(LD)
+    H = (Gam.T * Qbar) @ Gam
+    H[np.arange(nU), np.arange(nU)] += np.tile(qp.Rd, N).astype(LD)
+    H = (H + H.T) / LD(2)
+    h = Gam.T @ (Qbar * g + qp.q.reshape(-1).astype(LD)) + qp.r.reshape(-1).astype(LD)
+    lb, ub = qp.lb.reshape(-1).astype(LD), qp.ub.reshape(-1).astype(LD)
+
+    def solve(M, rhs):            # M x = rhs, M extended precision: FP64 factorisation + refinement on extended residuals
+        import scipy.linalg as sla
+        lu = sla.lu_factor(M.astype(np.float64))
+        x = np.zeros(rhs.shape, dtype=LD)
+        for _ in range(40):
+            res = rhs - M @ x
+            dxr = sla.lu_solve(lu, res.astype(np.float64)).astype(LD)
+            x = x + dxr
+            if np.abs(dxr).max() <= LD(4) * np.finfo(LD).eps * max(np.abs(x).max(), LD(1e-300)):
+                break
+        return x
+
+    v = solve(H, -h)
+    eq = ~(lb < ub)
+    lo, up = (v < lb) | eq, (v > ub) & ~eq
+    solves, cond = 0, float(np.linalg.cond(H.astype(np.float64)))
+    while (lo.any() or up.any()) and solves < max_solves:
+        solves += 1
+        act = lo | up
+        free = ~act
+        v = np.where(lo, lb, np.where(up, ub, LD(0)))
+        if free.any():
+            HFF = H[np.ix_(free, free)]
+            v[free] = solve(HFF, -h[free] - H[np.ix_(free, act)] @ v[act])
+            cond = float(np.linalg.cond(HFF.astype(np.float64)))
+        grad = H @ v + h
+        lo2 = (free & (v < lb)) | (lo & (grad > 0)) | eq
+        up2 = ((free & (v > ub)) | (up & (grad < 0))) & ~eq
+        if np.array_equal(lo2, lo) and np.array_equal(up2, up):
+            break
+        lo, up = lo2, up2
+    grad = H @ v + h
+    free = ~(lo | up)
+    kkt = max(float(np.abs(grad[free]).max()) if free.any() else 0.0,
+              float(np.maximum(-grad[lo & ~eq], 0).max()) if (lo & ~eq).any() else 0.0,
+              float(np.maximum(grad[up], 0).max()) if up.any() else 0.0,
+              float(np.maximum(lb - v, 0).max()), float(np.maximum(v - ub, 0).max()))
+    dx = (Gam @ v + g).reshape(N + 1, NX)
+    cls = np.where(lo, 1, np.where(up, 2, 0)).astype(np.uint8).reshape(N, NU)
+    return dict(dx=dx.astype(np.float64), du=v.reshape(N, NU).astype(np.float64), cls=cls, solves=solves, kkt=kkt, cond=cond,
+                eps=float(np.finfo(LD).eps))
+
+
 def _steplen(tl, tu, ll, lu, dtl, dtu, dll, dlu):
     a = 1.0
     for z, dz in ((tl, dtl), (tu, dtu), (ll, dll), (lu, dlu)):

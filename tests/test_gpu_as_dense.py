@@ -140,3 +140,43 @@ def test_split_forward_sweep_matches_single_launch(oracle, B, scale, N):
     if scale >= 1.5:
         assert long_heads > 0
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("B", [9000, 17000])
+def test_late_rows_of_the_split_sweep_reach_the_interior_point(oracle, B):
+    """A LATE row of the split forward sweep (feasible over [0, 24), first violation behind it: appended to the list by part two)
+    that the retry kernel does not settle must reach the interior-point fall-back -- round 5's launch loops stopped at the list's
+    original length and left such a row with status 0 and an iterate outside the box (advisor).  Forced here with a tiny
+    as_skip_viol: every constrained row skips the active-set iteration, so every late row depends on the fall-back.  9000:
+    the fall-back loops over the list itself; 17 000 (>= 16 S instances): over the compacted fall-back list of k_ipm_list."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    N = 50
+    rng = np.random.default_rng(B)
+    x = oracle.sample_hover_x0(rng, B, scale=1.8)
+    yr, ye = oracle.regulation_yref(N, (0.0, 0.0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(ye[None], B, 0).copy()
+    kw = dict(N=N, as_dense=1, forward_sweep=1, as_skip_viol=1e-6, tol=1e-11)
+    a = BatchSolver(B, default_opts(forward_split=1, **kw)); b = BatchSolver(B, default_opts(forward_split=-1, **kw))
+    for s in (a, b):
+        s.set_x0(x); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    cohort = B // 10
+    kicks = oracle.sample_hover_x0(rng, cohort * 6, scale=1.8).reshape(6, cohort, 13)
+    late = 0
+    for t in range(6):
+        x[t * cohort:(t + 1) * cohort] = kicks[t]
+        a.set_x0(x); b.set_x0(x)
+        a.solve(1); b.solve(1)
+        sa, ia, _ = a.stats(); sb, ib, _ = b.stats()
+        xa, ua = a.get_iterate(); xb, ub = b.get_iterate()
+        late += a.list_counts()[3]
+        assert b.list_counts()[3] == 0
+        assert np.array_equal(ia > 0, ib > 0), (t, np.nonzero((ia > 0) != (ib > 0))[0][:10])     # a dropped late row: 0 against > 0
+        ok = (sa == 0) & (sb == 0)
+        assert ok.mean() > 0.99
+        assert ua[ok].min() >= -1e-7 and ua[ok].max() <= 22.0 + 1e-7, (t, ua[ok].min(), ua[ok].max())
+        assert np.abs(ua[ok] - ub[ok]).max() < 5e-5 and np.abs(xa[ok] - xb[ok]).max() < 5e-5     # two interior points at tol 1e-11
+        b.set_iterate(xa, ua)
+        x = sim(x, a.get_u(0), T=0.015, steps=1)
+    assert late > 0, "the workload produced no late rows: the test proves nothing"
+    a.close(); b.close()
