@@ -161,8 +161,8 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
             xr[r] = *el(P.xit, li, i, N + 1, k, SZ_V13, 0, 13);
         });
     };
-    auto land_x = [&](const double (&xr)[13]) {
-        SFOR(r, 0, 13, { sx[tid + 64 * r] = xr[r]; });
+    auto land_x = [&](double* tile, const double (&xr)[13]) {
+        SFOR(r, 0, 13, { tile[tid + 64 * r] = xr[r]; });
     };
     auto issue_u = [&](int k, double (&u)[4]) {
         const gdouble* up = gm(P.uit) + (P.v4b ? (((size_t)(inst >> 2) * N + k) * 4 + (inst & 3)) * 4 : ((size_t)inst * N + k) * 4);
@@ -173,13 +173,20 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     // stage later, when the 82 (162) stores issued in between have pushed them out of the 63-deep window -- the stage loop
     // never waits for its own stores to drain (requested at the end of the stage, as before round 5, every stage ended with
     // the wave waiting for its A stores: 1.15 -> 1.00 ms at 65 536 instances together with the 16-byte stores below).
-    //   on entry to stage k: sx = x_k (tile), xr = x_{k+1} as loaded (tile order, maybe still in flight), un = u_k (same)
+    // Two state tiles (round 6): sxa = x_k, sxb = x_{k+1}.  x_{k+2} is requested at the top of stage k and LANDED in the middle
+    // of the same stage (before the rate columns, into the tile x_k was read from): by then 71 younger stores have pushed it out
+    // of the window, so the wait is free -- and its 26 registers are free during the rate and input columns, where the four
+    // Jacobian points + a column + its temporaries need the whole file (before: carried to the next stage's top, 52 B of
+    // scratch with three spill / reload pairs inside the stage loop).
+    //   on entry to stage k: sxa = x_k, sxb = x_{k+1} (tiles), un = u_k as loaded (maybe still in flight)
     double xr[13], un[4], xn[13];
+    double *sxa = sx, *sxb = sx + 64 * 13;
     {
         issue_x(k0, tid, xr);
-        land_x(xr);
-        __syncthreads();
+        land_x(sxa, xr);
         issue_x(k0 + 1, tid, xr);
+        land_x(sxb, xr);
+        __syncthreads();
         issue_u(k0, un);
         // (waited for HERE, so that the waits the compiler places at the loop's top are sized for the path around the loop --
         //  82 younger stores, i.e. none -- and not for this entry)
@@ -187,11 +194,8 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     }
     for (int k = k0; k < k1; k++) {
         double x[13], u[4];
-        SFOR(e, 0, 13, { x[e] = sx[tid * 13 + int_of(e)]; });
+        SFOR(e, 0, 13, { x[e] = sxa[tid * 13 + int_of(e)]; });
         SFOR(a, 0, 4, { u[a] = un[a]; });
-        __syncthreads();
-        land_x(xr);   // sx = x_{k+1}
-        __syncthreads();
         {
             int tq = tid;
             asm volatile("" : "+v"(tq));
@@ -214,7 +218,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         SFOR(e, 0, 13, { xt[e] = x[e] + h * k3v[e]; });
         f_expl(xt, u, k4v);
         jac_point(xt, J[3]);
-        SFOR(e, 0, 13, { xn[e] = sx[tid * 13 + int_of(e)]; });
+        SFOR(e, 0, 13, { xn[e] = sxb[tid * 13 + int_of(e)]; });
         // b = Phi - x_{k+1} through the tile (internal order)
         SFOR(r, 0, 13, {
             constexpr int e = ext_of(r);
@@ -294,6 +298,9 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
         __syncthreads();
         if (PAIRS) { CFN_STORE2(P.AR, SZ_A, 160, 4 * ar_pre(3)); }
         else { SFOR(j, 0, 4, { CFN_STORE(CSTORE ? P.cAR : P.AR, SZ_A, j, ar_n(3 + j), 4 * ar_pre(3 + j)); }); }
+        // x_{k+2} -> the tile x_k was read from (every lane read it at the stage's top, barriers in between); tiles swap roles
+        land_x(sxa, xr);
+        { double* t_ = sxa; sxa = sxb; sxb = t_; }
         __syncthreads();
 #pragma unroll 1
         for (int j = 0; j < 3; j++) {  // rate columns: all rows
@@ -325,20 +332,20 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
 //  instances (2048 workgroups of 25 stages), 2.05 ms with one workgroup per 64 instances: the second wave did not raise the VALU
 //  occupancy (~54 % either way).  Removed; profiles/r04_linearise_variants.md.)
 KALIGN __global__ __launch_bounds__(64) void k_linearise(Params P) {
-    __shared__ double sx[64 * 13];       // one 13-vector per instance (internal order)
+    __shared__ double sx[2 * 64 * 13];   // two tiles of one 13-vector per instance (internal order): x_k, x_{k+1}
     __shared__ __attribute__((aligned(16))) double sc[4][64 * 13];    // the tile of a group of up to four sensitivity columns
     __shared__ int sinst[64];
     linearise_body<false>(P, sx, sc, sinst);
 }
 __global__ __launch_bounds__(64) void k_linearise_list(Params P) {
-    __shared__ double sx[64 * 13];
+    __shared__ double sx[2 * 64 * 13];
     __shared__ double sc[4][64 * 13];
     __shared__ int sinst[64];
     if ((int)blockIdx.x * 64 >= gm(P.nipm)[0]) return;
     linearise_body<true>(P, sx, sc, sinst);
 }
 __global__ __launch_bounds__(64) void k_linearise_clist(Params P, int which) {
-    __shared__ double sx[64 * 13];
+    __shared__ double sx[2 * 64 * 13];
     __shared__ double sc[4][64 * 13];
     __shared__ int sinst[64];
     if ((int)blockIdx.x * 64 >= gm(P.nipm)[which ? 40 : 0]) return;
