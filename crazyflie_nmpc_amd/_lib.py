@@ -15,7 +15,7 @@ SYMBOLS = [
     "cfnmpc_workspace_bytes", "cfnmpc_set_x0", "cfnmpc_set_yref", "cfnmpc_set_weights", "cfnmpc_set_box", "cfnmpc_get_cmd", "cfnmpc_set_yref_windows", "cfnmpc_init_iterate",
     "cfnmpc_set_iterate", "cfnmpc_get_iterate", "cfnmpc_solve", "cfnmpc_step_host", "cfnmpc_get_u", "cfnmpc_get_x",
     "cfnmpc_get_stats", "cfnmpc_sim", "cfnmpc_estimate", "cfnmpc_debug_get_linearisation", "cfnmpc_debug_linearise", "cfnmpc_debug_start_factor", "cfnmpc_debug_get_factor",
-    "cfnmpc_debug_get_head", "cfnmpc_debug_get_viol", "cfnmpc_debug_get_list_counts", "cfnmpc_debug_get_condensed", "cfnmpc_set_box_stages", "cfnmpc_set_profiling", "cfnmpc_get_profile", "cfnmpc_get_profile_kernels", "cfnmpc_version",
+    "cfnmpc_debug_get_head", "cfnmpc_debug_get_viol", "cfnmpc_debug_get_list_counts", "cfnmpc_debug_get_condensed", "cfnmpc_set_box_stages", "cfnmpc_set_profiling", "cfnmpc_get_profile", "cfnmpc_get_profile_kernels", "cfnmpc_get_profile_steps", "cfnmpc_version",
     "cfnmpc_fleet_create", "cfnmpc_fleet_free", "cfnmpc_fleet_batch", "cfnmpc_fleet_min_horizon", "cfnmpc_fleet_max_horizon",
     "cfnmpc_fleet_num_buckets", "cfnmpc_fleet_bucket", "cfnmpc_fleet_workspace_bytes", "cfnmpc_fleet_set_x0",
     "cfnmpc_fleet_set_yref", "cfnmpc_fleet_set_weights", "cfnmpc_fleet_init_iterate", "cfnmpc_fleet_solve",
@@ -99,6 +99,7 @@ def lib():
     L.cfnmpc_get_profile.argtypes = [vp, vp, vp, vp]
     L.cfnmpc_set_box_stages.argtypes = [vp, vp, vp, i32, vp]
     L.cfnmpc_get_profile_kernels.argtypes = [vp, vp, vp]
+    L.cfnmpc_get_profile_steps.argtypes = [vp, vp, i32, vp]
     L.cfnmpc_debug_linearise.argtypes = [vp, vp]
     for name, at in (("cfnmpc_debug_chunked_pair", [vp, i32, i32, vp, vp]), ("cfnmpc_debug_checksum", [vp, vp]),
                      ("cfnmpc_debug_solve_part", [vp, i32, i32, vp])):   # development builds only (make DEV=1, csrc/cfnmpc_dev.h)

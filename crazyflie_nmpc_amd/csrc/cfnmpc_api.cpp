@@ -865,23 +865,40 @@ int cfnmpc_set_profiling(cfnmpc_solver* s, int enable) {
     return CFNMPC_OK;
 }
 
-int cfnmpc_get_profile_kernels(cfnmpc_solver* s, double* ms, int* n_steps) {
-    if (!s || !ms || !n_steps) return CFNMPC_EINVAL;
+// per timed step: ms_steps [max_steps][6] (the six groups of cfnmpc_get_profile_kernels), *n_steps = steps written (<= max_steps;
+// later timed steps are dropped); resets the count like cfnmpc_get_profile_kernels
+int cfnmpc_get_profile_steps(cfnmpc_solver* s, double* ms_steps, int max_steps, int* n_steps) {
+    if (!s || !ms_steps || max_steps < 0 || !n_steps) return CFNMPC_EINVAL;
     DeviceGuard dg(s);
-    double acc[EV_PER_STEP - 1] = {0, 0, 0, 0, 0, 0};
-    const size_t n = s->ev_used / EV_PER_STEP;
+    size_t n = s->ev_used / EV_PER_STEP;
+    if (n > (size_t)max_steps) n = (size_t)max_steps;
     for (size_t i = 0; i < n; i++) {
         hipEvent_t* e = &s->ev[EV_PER_STEP * i];
         HIP_TRY(hipEventSynchronize(e[EV_PER_STEP - 1]));
         for (size_t j = 0; j + 1 < EV_PER_STEP; j++) {
             float t = 0.f;
             HIP_TRY(hipEventElapsedTime(&t, e[j], e[j + 1]));
-            acc[j] += t;
+            ms_steps[i * (EV_PER_STEP - 1) + j] = t;
         }
     }
-    for (size_t j = 0; j + 1 < EV_PER_STEP; j++) ms[j] = n ? acc[j] / n : 0.0;
     *n_steps = (int)n;
     s->ev_used = 0;
+    return CFNMPC_OK;
+}
+
+int cfnmpc_get_profile_kernels(cfnmpc_solver* s, double* ms, int* n_steps) {
+    if (!s || !ms || !n_steps) return CFNMPC_EINVAL;
+    const size_t n = s->ev_used / EV_PER_STEP;
+    std::vector<double> per(n * (EV_PER_STEP - 1) + 1);
+    int got = 0;
+    const int rc = cfnmpc_get_profile_steps(s, per.data(), (int)n, &got);
+    if (rc != CFNMPC_OK) return rc;
+    for (size_t j = 0; j + 1 < EV_PER_STEP; j++) {
+        double acc = 0.0;
+        for (int i = 0; i < got; i++) acc += per[(size_t)i * (EV_PER_STEP - 1) + j];
+        ms[j] = got ? acc / got : 0.0;
+    }
+    *n_steps = got;
     return CFNMPC_OK;
 }
 

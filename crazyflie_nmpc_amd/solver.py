@@ -211,6 +211,12 @@ class BatchSolver:
         _check(self._L.cfnmpc_get_profile_kernels(self._h, ms, C.byref(n)), "cfnmpc_get_profile_kernels")
         return [float(v) for v in ms], n.value
 
+    def get_profile_steps(self, max_steps=4096):
+        """-> array [n_steps][6]: the six kernel-group durations of every timed step (ms), not averaged."""
+        ms = np.zeros((int(max_steps), 6)); n = C.c_int(0)
+        _check(self._L.cfnmpc_get_profile_steps(self._h, ms.ctypes.data_as(C.c_void_p), int(max_steps), C.byref(n)), "cfnmpc_get_profile_steps")
+        return ms[:n.value].copy()
+
     def linearise_only(self, stream=None):
         _check(self._L.cfnmpc_debug_linearise(self._h, _launch_stream(stream, self._device)), "cfnmpc_debug_linearise")
 

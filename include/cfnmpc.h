@@ -319,6 +319,9 @@ int cfnmpc_get_profile(cfnmpc_solver *s, double *ms_linearise, double *ms_qp, in
  * Partial-condensing and overlapped steps report their phases in ms[0] / ms[5] only.  Resets like cfnmpc_get_profile
  * (call one of the two). */
 int cfnmpc_get_profile_kernels(cfnmpc_solver *s, double *ms, int *n_steps);
+/* ... and per timed step instead of averaged (the active-set kernels of a step in which a tail check fails take four times the
+ * average: a mean hides what a deadline sees): ms_steps [max_steps][6], *n_steps = steps written; resets likewise */
+int cfnmpc_get_profile_steps(cfnmpc_solver *s, double *ms_steps, int max_steps, int *n_steps);
 
 /* crazyflie_acados_sim_solve() equivalent, batched (acados_estimator.cpp:573-593):
  * xn = RK4(x, u) over T seconds in `steps` sub-steps.  Stateless. */

@@ -41,7 +41,10 @@ def test_bench_two_ranks_strong_scaling_line():
     assert d["weak_scaling"]["total_batch"] == 16384 and d["weak_scaling"]["batch_per_gpu"] == 8192
     assert d["qp_stats"]["status_ok_frac"] == 1.0
     assert d["value"] > 0 and abs(d["value"] - 8192 * 3 / (d["ms_per_step"] * 3e-3)) < 1e-6 * d["value"]
-    assert "cpu_baseline" not in d and d["roofline"]["bound"] == "hbm"
+    # N > 1 lines SAY what they leave out instead of dropping the keys
+    assert set(d["cpu_baseline"]) == {"omitted"} and d["roofline"]["bound"] == "hbm"
+    assert d["roofline"]["traffic"] is None and d["roofline"]["traffic_source"].startswith("n/a")
+    assert d["roofline"]["active_set_group_ms_per_step"]["max"] >= d["roofline"]["active_set_group_ms_per_step"]["p50"] > 0
 
 
 def test_bench_two_ranks_weak_scaling_line():

@@ -833,6 +833,7 @@ def test_randomised_options_match_restatement(oracle, cref, seed):
                   f"exact active-set iteration: {ref['solves']} solves, head {s.heads()[i]}")
             assert ref["solves"] > 12, (seed, i, ref["solves"], e_gpu, e_res)   # within the cap both sides solve exactly: 5e-8 or fail
             assert e_gpu < 5e-6 and e_res < 5e-6, (seed, i, e_gpu, e_res)       # interior point, tol 1e-8
+            xr[i] = xg[i]; ur[i] = ug[i]      # one trajectory from here on: the next step's two QPs are the same QP again
         assert (ug[ok] >= u_min - 1e-7).all() and (ug[ok] <= u_max + 1e-7).all()   # (interior point: primal residual <= tol)
         x = xg[:, 1, :].copy()
 
