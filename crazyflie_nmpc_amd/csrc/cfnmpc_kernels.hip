@@ -855,6 +855,19 @@ __device__ __forceinline__ int head_class(const Params& P, int want) {
     return head;
 }
 
+// stages the constrained solve of a row must cover: its tight stages + ah_extra behind the last one -- except that the safety
+// margin alone never pushes a row across the 16-stage class: a row whose tight stages END within 16 stages (last tight stage
+// 12..15: 17..20 stages wanted) gets head 16, not 24.  Heads of at most 16 stages are what the head-condensed dense solves take
+// (k_as_dense: one row per wavefront, ~50 us; the same row in the Riccati form of k_as_solves: 130 - 240 us, and a small fleet's
+// step waits for it -- one step in three at 8192 instances; round 6: +3.3 % there, +2 % at 16 384, +1 % at
+// 4096).  The tail verification (k_ascommit -> k_as_retry, or in-wave in k_as) covers the rare row for which that was too
+// short: exactness does not depend on the margin.  One rule for every kernel structure, so that they keep choosing the same heads.
+__device__ __forceinline__ int head_want(const Params& P, int last_tight) {
+    const int want = last_tight + 1 + P.ah_extra;
+    if (P.N > 16 && last_tight + 1 <= 16 && want > 16) return 16;
+    return want;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Start solve, forward sweep -- lane-per-instance, matrix-free.
 // The forward sweep only needs the PRODUCT  dx+ = A dx + B du + b, never A and B themselves, and
@@ -1080,10 +1093,10 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
             gm(P.status)[inst] = bad ? 4 : 0;
             gm(P.iters)[inst] = 0;
             gm(P.res)[inst] = bad ? nan("") : 0.0;
-            gm(P.head)[inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
+            gm(P.head)[inst] = infeasible ? head_class(P, head_want(P, last_tight)) : 0;
             if (P.as_warm && !infeasible) gm(P.wvalid)[inst] = 0;
         }
-        const int hc = infeasible ? head_cls(P, head_class(P, last_tight + 1 + P.ah_extra)) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
+        const int hc = infeasible ? head_cls(P, head_class(P, head_want(P, last_tight))) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
         const unsigned long long below = (1ull << tid) - 1ull;
         SFOR(c, 0, N_BIN, {
             const unsigned long long m = __ballot(hc == c);
@@ -1105,7 +1118,7 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         if (bad2) { gm(P.status)[inst] = 4; gm(P.res)[inst] = nan(""); }
         if (late) {
             gm(P.viol)[inst] = viol;
-            gm(P.head)[inst] = head_class(P, last_tight + 1 + P.ah_extra);
+            gm(P.head)[inst] = head_class(P, head_want(P, last_tight));
             gm(P.done)[inst] = 2;                                   // k_as_retry solves it (the interior point what that leaves)
             const int pos = atomicAdd(P.nipm + 42, 1);
             gm(P.ilist)[gm(P.nipm)[0] + pos] = inst;
@@ -1128,14 +1141,14 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         gm(P.status)[inst] = bad ? 4 : 0;
         gm(P.iters)[inst] = 0;
         gm(P.res)[inst] = bad ? nan("") : 0.0;
-        gm(P.head)[inst] = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
+        gm(P.head)[inst] = infeasible ? head_class(P, head_want(P, last_tight)) : 0;
         if (P.as_warm && !infeasible) gm(P.wvalid)[inst] = 0;   // an unconstrained step ends the instance's run of constrained ones
     }
     {   // first half of the stable compaction: per-group bin counts and ranks.  Bin = head class
         // (largest first) x difficulty (number of violated inputs of the unconstrained minimiser:
         // >= 4, 2..3, 1 -- the active-set solve needs more passes the more bounds are involved,
         // and a wave lasts as long as the slowest of its four rows)
-        const int hc = infeasible ? head_cls(P, head_class(P, last_tight + 1 + P.ah_extra)) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
+        const int hc = infeasible ? head_cls(P, head_class(P, head_want(P, last_tight))) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
         const unsigned long long below = (1ull << tid) - 1ull;
         SFOR(c, 0, N_BIN, {
             const unsigned long long m = __ballot(hc == c);
@@ -1272,7 +1285,7 @@ __device__ __forceinline__ void forward_rg_body(const Params& P) {
     const bool bad = t.valid && (!okf || !(viol == viol));
     const bool infeasible = t.valid && !bad && (viol > 0.0);
     if (t.L == 0 && t.valid) {
-        const int head = infeasible ? head_class(P, last_tight + 1 + P.ah_extra) : 0;
+        const int head = infeasible ? head_class(P, head_want(P, last_tight)) : 0;
         gm(P.viol)[t.inst] = infeasible ? viol : 0.0;
         gm(P.status)[t.inst] = bad ? 4 : 0;
         gm(P.iters)[t.inst] = 0;
@@ -1541,6 +1554,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     // last solve instead of following the slowest of four wave-mates, and the kernel lasts as long as its hardest ROW.
     // The compact slot of list slot c is c in both modes (row c & 3 of compact block c >> 2), so kernels of either
     // mode read each other's results.
+    // (round 6, measured: the interior-point fall-back gains nothing from one row per wave -- kicks x 2: 5.83 -> 5.75 ms for ~230 rows;
+    //  the launch lasts as long as its slowest ROW, 26 - 31 iterations of 4 sweeps x 50 stages at ~1 us, whoever shares its wave)
     const bool sparse = (MODE == 1 || MODE == 3 || MODE == 4) && nipm <= P.as_sparse_max && nipm <= (int)gridDim.x;
     const int slot = sparse ? vb : vb * 4 + (threadIdx.x >> 4);
     if ((sparse ? vb : vb * 4) >= nipm || (sparse ? vb : vb * 4 + 3) < slot_lo) return;  // wave-uniform: no work for this wave

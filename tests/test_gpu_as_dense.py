@@ -82,11 +82,11 @@ def test_dense_solves_match_restatement(oracle, cref):
     n = 0
     for t in range(10):
         s.set_x0(x); s.solve(1)
-        st, it, _ = s.stats()
-        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        st, it, rs = s.stats()
+        st_r, it_r, rs_r, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
         xg, ug = s.get_iterate()
         assert (st == 0).all() and (st_r == 0).all() and np.array_equal(it > 0, it_r > 0)
-        exact = (it <= 12) & (it_r <= 12)       # settled by active-set solves on both sides (else: interior point at tol 1e-8)
+        exact = (rs == 0.0) & (rs_r == 0.0)     # settled by active-set solves on both sides (residual exactly 0; the interior point reports its own > 0)
         assert exact.mean() > 0.98
         assert np.abs(ug[exact] - ur[exact]).max() < 1e-7 and np.abs(xg[exact] - xr[exact]).max() < 1e-7, (t, np.abs(ug[exact] - ur[exact]).max())
         assert np.abs(ug - ur).max() < 5e-4
@@ -123,12 +123,12 @@ def test_split_forward_sweep_matches_single_launch(oracle, B, scale, N):
         x[c0:c0 + cohort] = kicks[t]
         a.set_x0(x); b.set_x0(x)
         a.solve(1); b.solve(1)
-        sa, ia, _ = a.stats(); sb, ib, _ = b.stats()
+        sa, ia, ra = a.stats(); sb, ib, rb = b.stats()
         xa, ua = a.get_iterate(); xb, ub = b.get_iterate()
         assert np.array_equal(sa, sb), (t, np.nonzero(sa != sb)[0][:10])
         assert np.array_equal(ia > 0, ib > 0), (t, np.nonzero((ia > 0) != (ib > 0))[0][:10])
         ok = sa == 0
-        exact = ok & (ia <= 12) & (ib <= 12)
+        exact = ok & (ra == 0.0) & (rb == 0.0)     # active-set solves on both sides (an interior-point row reports its residual > 0)
         # (a row's head comes from the first window only, so a few rows take another path -- a retry over a longer head, or the
         #  interior point -- to the same solution: exact solves agree to rounding, interior-point rows to its tolerance)
         assert np.abs(ua[exact] - ub[exact]).max() < 1e-7 and np.abs(xa[exact] - xb[exact]).max() < 1e-7, (t, np.abs(ua[exact] - ub[exact]).max())

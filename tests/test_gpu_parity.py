@@ -272,15 +272,16 @@ def test_warm_started_active_set_matches_restatement(oracle, cref, active_horizo
         s.set_x0(x); s.solve(1)
         xc, uc = s.get_iterate()          # the cold engine and the restatement continue from the warm engine's iterate
         c.set_x0(x); c.solve(1)
-        st, it, _ = s.stats(); st_c, it_c, _ = c.stats()
+        st, it, rs = s.stats(); st_c, it_c, rs_c = c.stats()
         warm_rows += int((warm[1] != 0).sum())
-        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0, warm=warm)
+        st_r, it_r, rs_r, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0, warm=warm)
         xg, ug = s.get_iterate()
         xk, uk = c.get_iterate()
         ok = (st == 0) & (st_r == 0) & (st_c == 0)
         assert ok.mean() > 0.97 and np.array_equal(st, st_r)
         assert np.array_equal(it > 0, it_r > 0) and np.array_equal(it > 0, it_c > 0)
-        as_rows = ok & (it <= 12) & (it_r <= 12) & (it_c <= 12)       # settled by active-set solves on every side
+        as_rows = ok & (rs == 0.0) & (rs_r == 0.0) & (rs_c == 0.0)    # settled by active-set solves on every side (an interior-point row reports its residual, > 0,
+        #                                                                whatever its iteration count: twelve iterations are not twelve solves)
         if active_horizon == 0:
             assert np.array_equal(it[as_rows], it_r[as_rows]), (t, it[as_rows], it_r[as_rows])
         assert np.abs(ug[as_rows] - ur[as_rows]).max() < 1e-7 and np.abs(xg[as_rows] - xr[as_rows]).max() < 1e-7, t
