@@ -374,10 +374,10 @@ def timed_run(fleet, steps, warmup, barrier, profile=True):
     as_steps = np.sort(per[:, 4] + per[:, 5]) if len(per) else np.zeros(1)
     step_kernels = np.sort(per.sum(axis=1)) if len(per) else np.zeros(1)
     pct = lambda a: {"p50": float(a[len(a) // 2]), "p99": float(a[min(len(a) - 1, int(np.ceil(0.99 * len(a))) - 1)]), "max": float(a[-1]), "steps": int(len(a))}
-    if getattr(fleet.solver.opts, "overlap_linearise", 0) or getattr(fleet.solver.opts, "cond_N2", 0):
-        # overlapped / condensed steps report their two phases in kms[0] / kms[5] only, and with the overlap the QP phase
-        # comes FIRST (include/cfnmpc.h: cfnmpc_get_profile_kernels): no per-kernel split for them
-        ms_lin, ms_qp = (kms[5], kms[0]) if fleet.solver.opts.overlap_linearise else (kms[0], sum(kms[1:]))
+    if getattr(fleet.solver.opts, "cond_N2", 0):
+        # condensed steps report their two phases in kms[0] / kms[5] only (include/cfnmpc.h: cfnmpc_get_profile_kernels): no
+        # per-kernel split for them
+        ms_lin, ms_qp = kms[0], sum(kms[1:])
         kms = [0.0] * 6
     fleet.solver.set_profiling(False)
     # (n_prof == steps unless K exceeds the library's cap of timed steps: the average then covers the first 4096)
@@ -427,7 +427,7 @@ def main():
     ap.add_argument("--step-graph", type=int, default=None, help="cfnmpc_opts.step_graph (captured hipGraph per RTI step)")
     ap.add_argument("--forward-sweep", type=int, default=None, help="cfnmpc_opts.forward_sweep (0 auto, 1 matrix-free, 2 row groups)")
     ap.add_argument("--as-passes", type=int, default=None, help="cfnmpc_opts.as_passes (scheduling of the active-set solves: 0 auto, -1 monolithic, "
-                                                                "-3 solves + commit kernel, -2 / 1..12 instance-contiguous store / level-synchronous passes)")
+                                                                "-3 solves + commit kernel)")
     ap.add_argument("--as-warm", type=int, default=None, help="cfnmpc_opts.as_warm (warm start of the active set from the previous RTI step)")
     ap.add_argument("--as-dense", type=int, default=None, help="cfnmpc_opts.as_dense (head-condensed dense active-set solves: 1 on, -1 off, 0 auto)")
     ap.add_argument("--forward-split", type=int, default=None, help="cfnmpc_opts.forward_split (1 on, -1 off, 0 auto)")
@@ -441,7 +441,6 @@ def main():
     ap.add_argument("--predictor", choices=["queued", "latest"], default="queued",
                     help="--workload mixed: delay compensation through the four queued inputs (default) or the reference's "
                          "latest-input-held predictor (acados_estimator.cpp:573-593)")
-    ap.add_argument("--overlap", type=int, default=None, help="cfnmpc_opts.overlap_linearise (default: library default)")
     ap.add_argument("--ah-margin", type=float, default=None)
     ap.add_argument("--ah-extra", type=int, default=None)
     ap.add_argument("--start-solve", type=int, default=None, help="cfnmpc_opts.start_solve (0 auto, 1 k_linearise + k_factor on stored blocks, "
@@ -490,7 +489,7 @@ def main():
     scaling = args.scaling or "strong"
     seed = parallel.shard_seed(rank)
     opt_kw = dict(active_horizon=args.active_horizon, active_set=args.active_set)
-    for k, v in (("overlap_linearise", args.overlap), ("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2),
+    for k, v in (("ah_margin", args.ah_margin), ("ah_extra", args.ah_extra), ("cond_N2", args.cond_n2),
                  ("step_graph", args.step_graph), ("forward_sweep", args.forward_sweep), ("as_passes", args.as_passes),
                  ("start_solve", args.start_solve), ("as_warm", args.as_warm), ("as_dense", args.as_dense), ("forward_split", args.forward_split)):
         if v is not None:

@@ -25,7 +25,7 @@ SYMBOLS = [
     "cfnmpc_multi_sync", "cfnmpc_multi_set_box", "cfnmpc_multi_set_box_stages", "cfnmpc_multi_get_u", "cfnmpc_multi_get_x", "cfnmpc_multi_get_cmd", "cfnmpc_multi_get_stats",
     "cfnmpc_multi_create_horizons", "cfnmpc_multi_shard_fleet", "cfnmpc_shard_by_horizon",
 ]
-ABI_VERSION = 8   # CFNMPC_ABI_VERSION of the include/cfnmpc.h this binding was written against
+ABI_VERSION = 9   # CFNMPC_ABI_VERSION of the include/cfnmpc.h this binding was written against
 
 
 class Opts(C.Structure):
@@ -34,7 +34,7 @@ class Opts(C.Structure):
                 ("u_min", C.c_double), ("u_max", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int), ("tau", C.c_double), ("thr0", C.c_double),
                 ("lam0_min", C.c_double), ("mu0_scale", C.c_double), ("active_horizon", C.c_int), ("ah_margin", C.c_double),
-                ("ah_extra", C.c_int), ("overlap_linearise", C.c_int), ("active_set", C.c_int), ("forward_sweep", C.c_int), ("cond_N2", C.c_int), ("step_graph", C.c_int), ("as_passes", C.c_int), ("ipm_clip_viol", C.c_double), ("ipm_clip_margin", C.c_double), ("as_skip_viol", C.c_double), ("reinit_failed", C.c_int), ("start_solve", C.c_int), ("as_warm", C.c_int), ("as_dense", C.c_int), ("forward_split", C.c_int)]
+                ("ah_extra", C.c_int), ("active_set", C.c_int), ("forward_sweep", C.c_int), ("cond_N2", C.c_int), ("step_graph", C.c_int), ("as_passes", C.c_int), ("ipm_clip_viol", C.c_double), ("ipm_clip_margin", C.c_double), ("as_skip_viol", C.c_double), ("reinit_failed", C.c_int), ("start_solve", C.c_int), ("as_warm", C.c_int), ("as_dense", C.c_int), ("forward_split", C.c_int)]
 
 
 _lib = None

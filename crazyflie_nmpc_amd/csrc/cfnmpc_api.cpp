@@ -33,7 +33,7 @@ struct cfnmpc_solver {
     int profiling;
     std::vector<hipEvent_t> ev;  // EV_PER_STEP events per timed RTI step: start | linearise | factor | forward | compaction | active set | end
     size_t ev_used;
-    // preparation-phase overlap (cfnmpc_opts.overlap_linearise): the linearisation for the NEXT
+    // preparation-phase overlap (development builds, CFNMPC_OVERLAP=1; always 0 in the product): the linearisation for the NEXT
     // step is written to the alternate (AR, BR, b) set while the interior-point kernel still
     // reads the current one
     int overlap;
@@ -181,7 +181,7 @@ bool weights_ok(const double* W, const double* WN) {
 
 extern "C" {
 
-const char* cfnmpc_version(void) { return "cfnmpc 0.8 (gfx950; row-group Riccati with fused DPP broadcast FMAs, lane-per-instance linearisation and matrix-free forward sweep, primal-dual active-set QP solves; options: fused start solve (linearisation inside the factorisation), partial condensing, small-fleet forward sweep; device output stage; multi-GPU shards)"; }
+const char* cfnmpc_version(void) { return "cfnmpc 0.9 (gfx950; row-group Riccati with fused DPP broadcast FMAs, lane-per-instance linearisation and matrix-free forward sweep, primal-dual active-set QP solves; options: fused start solve (linearisation inside the factorisation), partial condensing, small-fleet forward sweep; device output stage; multi-GPU shards)"; }
 
 void cfnmpc_default_opts(cfnmpc_opts* o) {
     // generate_c_code.py:41-42,63-84,109,133-134
@@ -203,7 +203,6 @@ void cfnmpc_default_opts(cfnmpc_opts* o) {
     o->active_horizon = 1;
     o->ah_margin = 0.10;
     o->ah_extra = 4;
-    o->overlap_linearise = 0;
     o->active_set = 1;
     o->forward_sweep = 0;
     o->cond_N2 = 0;
@@ -237,6 +236,13 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     }
     cfnmpc_opts o;
     if (opts) o = *opts; else cfnmpc_default_opts(&o);
+    // Overlapped preparation (the next step's linearisation beside the constrained rows' kernels, double-buffered A / B / b):
+    // measured slower at every fleet size -- since round 6 an experiment of the development build
+    // (make DEV=1; CFNMPC_OVERLAP=1 in the environment), not an option of the product.
+    int overlap_linearise = 0;
+#ifdef CFN_DEV
+    if (const char* e = std::getenv("CFNMPC_OVERLAP")) overlap_linearise = std::atoi(e) ? 1 : 0;
+#endif
     if (o.N < 5 || o.N > 4096 || !(o.dt > 0) || !(o.u_max > o.u_min) || o.max_iter < 0 ||
         !(o.ah_margin >= 0.0 && o.ah_margin < 0.5) || o.ah_extra < 0) return CFNMPC_EINVAL;
     // QP parameters that would otherwise only show up as NaN / status 4 at run time
@@ -247,7 +253,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     // partial condensing: cond_N2 blocks of at most COND_MMAX stages; not combined with the overlapped preparation
     if (o.cond_N2 < 0 || o.cond_N2 > o.N) return CFNMPC_EINVAL;
     const int cond_N2 = (o.cond_N2 == 0 || o.cond_N2 == o.N) ? 0 : o.cond_N2;
-    if (cond_N2 && ((o.N + cond_N2 - 1) / cond_N2 > cfn::COND_MMAX || o.overlap_linearise)) return CFNMPC_EINVAL;
+    if (cond_N2 && ((o.N + cond_N2 - 1) / cond_N2 > cfn::COND_MMAX || overlap_linearise)) return CFNMPC_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         std::fprintf(stderr, "cfnmpc: no HIP device available (this library has no CPU path)\n");
@@ -260,7 +266,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     s->io_doubles = 0;
     s->profiling = 0;
     s->ev_used = 0;
-    s->overlap = o.overlap_linearise ? 1 : 0;
+    s->overlap = overlap_linearise ? 1 : 0;
     s->AR2 = s->BR2 = s->b2 = nullptr;
     s->aux = nullptr;
     s->ev_start = s->ev_aux = nullptr;
@@ -327,9 +333,13 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     P.ah_extra = o.ah_extra;
     P.active_set = o.active_set ? 1 : 0;
     P.as_warm = (o.as_warm && o.active_set) ? 1 : 0;
-    if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && o.overlap_linearise) ||
-        (o.reinit_failed && o.overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
+    if (o.forward_sweep < 0 || o.forward_sweep > 2 || (o.step_graph && overlap_linearise) ||
+        (o.reinit_failed && overlap_linearise)) { delete s; return CFNMPC_EINVAL; }
+#ifdef CFN_DEV   // (development builds: also -2 and 1..12, the instance-contiguous store / level-synchronous passes of round 3)
     if (o.as_passes < -3 || o.as_passes > 12) { delete s; return CFNMPC_EINVAL; }
+#else
+    if (o.as_passes != 0 && o.as_passes != -1 && o.as_passes != -3) { delete s; return CFNMPC_EINVAL; }
+#endif
     // internal: 0 = monolithic k_as, -1 = every solve in one launch on the compact z store + commit, -2 = the monolithic
     // kernel's solves + commit, p > 0 = p single-solve passes
     P.as_passes = o.as_passes > 0 ? o.as_passes : (o.as_passes == -2 ? -1 : (o.as_passes == -3 ? -2 : 0));
@@ -360,7 +370,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     // active_set = 0; forward_split = 1 outside the dense structure, with the row-group sweep, short horizons or the overlapped
     // preparation -- whose early pass would read the iterate while part two of the sweep is still writing it)
     if (o.as_dense == 1 && !P.as_dense) { delete s; return CFNMPC_EINVAL; }
-    const bool split_ok = P.as_dense && !cond_N2 && o.start_solve != 2 && o.start_solve != 3 && o.N >= 40 && !o.overlap_linearise &&
+    const bool split_ok = P.as_dense && !cond_N2 && o.start_solve != 2 && o.start_solve != 3 && o.N >= 40 && !overlap_linearise &&
                           o.forward_sweep != 2 && o.forward_split != -1;
     if (o.forward_split == 1 && !split_ok) { delete s; return CFNMPC_EINVAL; }
     // forward sweep on the stored blocks (row groups) below 6 S instances where the split matrix-free sweep takes over from there;
@@ -394,9 +404,9 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     // reads the stage blocks afterwards (matrix-free forward sweep, monolithic active-set kernel, no partial condensing,
     // no overlapped preparation); per-stage boxes (cfnmpc_set_box_stages) switch a solver back at launch time
     {
-        const bool can_fuse = !cond_N2 && !o.overlap_linearise && !P.forward_rg && P.as_passes == 0;
+        const bool can_fuse = !cond_N2 && !overlap_linearise && !P.forward_rg && P.as_passes == 0;
         if (o.start_solve == 2 && !can_fuse) { cfnmpc_free(s); return CFNMPC_EINVAL; }
-        if (o.start_solve == 3 && (cond_N2 || o.overlap_linearise)) { cfnmpc_free(s); return CFNMPC_EINVAL; }
+        if (o.start_solve == 3 && (cond_N2 || overlap_linearise)) { cfnmpc_free(s); return CFNMPC_EINVAL; }
         P.fused = o.start_solve == 2 ? 1 : (o.start_solve == 3 ? 2 : 0);
         P.clist_chunks = o.N >= 10 ? 10 : o.N;
     }
@@ -713,6 +723,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
             s->lin_valid = false;   // the iterate moved
             continue;
         }
+#ifdef CFN_DEV   // overlapped preparation: development builds only (CFNMPC_OVERLAP=1); s->overlap is 0 in the product
         // feedback phase on the linearisation prepared by the previous step ...
         if (!s->lin_valid) cfn::launch_linearise(s->P, s->chunks_all, st);
         if (e) HIP_TRY(hipEventRecord(e[0], st));
@@ -736,6 +747,7 @@ int cfnmpc_solve(cfnmpc_solver* s, int n_rti, void* stream) {
         s->AR2 = s->P.AR; s->BR2 = s->P.BR; s->b2 = s->P.b;
         s->P.AR = Q.AR; s->P.BR = Q.BR; s->P.b = Q.b;
         s->lin_valid = true;
+#endif
     }
     HIP_TRY(hipGetLastError());
     return CFNMPC_OK;

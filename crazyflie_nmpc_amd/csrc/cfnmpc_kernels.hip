@@ -337,6 +337,7 @@ KALIGN __global__ __launch_bounds__(64) void k_linearise(Params P) {
     __shared__ int sinst[64];
     linearise_body<false>(P, sx, sc, sinst);
 }
+#ifdef CFN_DEV   // (overlapped preparation: development builds only)
 __global__ __launch_bounds__(64) void k_linearise_list(Params P) {
     __shared__ double sx[2 * 64 * 13];
     __shared__ double sc[4][64 * 13];
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(64) void k_linearise_list(Params P) {
     if ((int)blockIdx.x * 64 >= gm(P.nipm)[0]) return;
     linearise_body<true>(P, sx, sc, sinst);
 }
+#endif
 __global__ __launch_bounds__(64) void k_linearise_clist(Params P, int which) {
     __shared__ double sx[2 * 64 * 13];
     __shared__ double sc[4][64 * 13];
@@ -2196,6 +2198,7 @@ __global__ __launch_bounds__(64) void k_as_retry(Params P) {  // MODE 3: rows th
     __shared__ double btile[4][64];
     qp_wave<3>(P, wtile, btile, blockIdx.x);
 }
+#ifdef CFN_DEV   // round 3's scheduling experiments (as_passes -2 / 1..12): development builds only since round 6 (measured slower at every fleet size)
 // =============================================================================================
 // Level-synchronous active-set passes (cfnmpc_opts.as_pipeline)
 // =============================================================================================
@@ -2422,6 +2425,7 @@ __device__ __forceinline__ int zsweep_forward(const Params& P, const Params& Q, 
     }
     return (int)row_max((double)jm);
 }
+#endif   // CFN_DEV
 __device__ __forceinline__ Params compact_params(const Params& P) {
     Params Q = P;
     Q.v4b = 0;   // (compact 4-vectors: instance-major, a row's head contiguous)
@@ -2430,6 +2434,7 @@ __device__ __forceinline__ Params compact_params(const Params& P) {
     return Q;
 }
 // One group of four rows of a pass: compact slots, home lanes, per-row sweep state.
+#ifdef CFN_DEV
 struct AspGroup {
     Lane th, tc;
     int c, inst, head, chk, join;
@@ -2593,6 +2598,7 @@ __global__ __launch_bounds__(64) void k_asp_all(Params P) {
     asp_body<true>(P, 0, AS_MAX_SOLVES, wtile, btile);
 }
 // Settled rows: new iterate = candidate (start solve) + delta.  One wave = four consecutive compact slots.
+#endif   // CFN_DEV
 // DEEP: three rotating stage buffers in the tail loop (one wave per SIMD: small fleets, where the tail is a
 // latency chain); otherwise two (two waves per SIMD: large fleets, where it is bound by the home blocks' bytes).
 #ifndef CFN_COMMIT_DEPTH
@@ -3011,9 +3017,11 @@ static inline int imax_h(int a, int b) { return a > b ? a : b; }
 void launch_linearise(const Params& P, int chunks, hipStream_t st) {
     hipLaunchKernelGGL(k_linearise, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P);
 }
+#ifdef CFN_DEV
 void launch_linearise_list(const Params& P, int chunks, hipStream_t st) {
     hipLaunchKernelGGL(k_linearise_list, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P);
 }
+#endif
 void launch_linearise_clist(const Params& P, int chunks, int which, hipStream_t st) {
     hipLaunchKernelGGL(k_linearise_clist, dim3((P.NW + 15) / 16, chunks), dim3(64), 0, st, P, which);
 }
@@ -3131,7 +3139,9 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
             if (split) (void)hipStreamWaitEvent(st, (hipEvent_t)P.as_join2, 0);
         } else if (P.as_passes == -2) {
             hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, P);
-        } else if (P.as_passes < 0) {
+        }
+#ifdef CFN_DEV
+        else if (P.as_passes < 0) {
             hipLaunchKernelGGL(k_asp_all, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
         } else {
             hipLaunchKernelGGL(k_asf_first, dim3(G), dim3(64), 0, st, P);
@@ -3143,6 +3153,7 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
             if (P.as_passes < AS_MAX_SOLVES)
                 hipLaunchKernelGGL(k_asp, dim3(imax_h(1, G / 2)), dim3(64), 0, st, P, P.as_passes, AS_MAX_SOLVES - P.as_passes);
         }
+#endif
         if (P.NW <= 2 * P.as_grid) hipLaunchKernelGGL(k_ascommit1, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
         else hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
         // (late rows of a split forward sweep: k_as_retry and k_ipm_rest count them in, P.nipm[0] + P.nipm[42].  Tried: both modes in

@@ -59,7 +59,7 @@ typedef struct cfnmpc_solver cfnmpc_solver;
  *     otherwise, nothing written) -- what C callers and bindings should use; CFNMPC_DEFAULT_OPTS(&o) spells it;
  *   - every cfnmpc_opts starts with its own size (set by cfnmpc_default_opts*), and cfnmpc_create / cfnmpc_fleet_create /
  *     cfnmpc_multi_create* refuse (CFNMPC_EINVAL) an object whose struct_size is not the library's. */
-#define CFNMPC_ABI_VERSION 8
+#define CFNMPC_ABI_VERSION 9
 
 /* Replaces the constants baked into the generated solver by
  * crazyflie_controller/scripts/crazyflie_full_model/generate_c_code.py:41-146. */
@@ -86,14 +86,6 @@ typedef struct cfnmpc_opts {
     double ah_margin;    /* active horizon: an unconstrained input closer to a bound than this
                             fraction of (u_max - u_min) counts as 'tight' (0.10)              */
     int ah_extra;        /* active horizon: stages added after the last tight stage (4)       */
-    int overlap_linearise; /* 0 (default): linearise at the start of cfnmpc_solve.  1: every RTI step
-                            ends with the PREPARATION of the next one (the RTI scheme's preparation
-                            phase: linearisation around the new iterate, which does not depend on
-                            the next x0 / yref), run on an internal low-priority stream beside the
-                            latency-bound interior-point kernel (early pass over all instances +
-                            list pass over the interior-point ones, double-buffered A/B/b).
-                            Results are bit-identical either way; on MI355X the two kernels slow
-                            each other down about as much as the overlap saves.     */
     int active_set;      /* QP: 1 (default) = solve the box-constrained QP by a primal-dual active-set
                             iteration first: guess the active input bounds from the unconstrained
                             minimiser, solve the equality-constrained QP (one Riccati factorisation
@@ -126,7 +118,7 @@ typedef struct cfnmpc_opts {
                             an option for parity with the reference's solver plan, not the default.        */
     int step_graph;      /* 1: cfnmpc_solve replays the launches of an RTI step from a captured hipGraph (one per
                             parity of the two iterate buffers; re-captured after cfnmpc_set_weights / _set_box)
-                            instead of launching its 7-8 kernels one by one; not with overlap_linearise, and
+                            instead of launching its 7-8 kernels one by one;
                             steps timed with cfnmpc_set_profiling are launched individually.  0 (default): the
                             kernels already run back to back (18 us of gaps per step at 4096 instances), the
                             graph saves about half of that.                          */
@@ -137,16 +129,11 @@ typedef struct cfnmpc_opts {
                             solve's candidate + delta -- head stages element-wise from the solve's own du / dx, the tail
                             through the closed loop of the unconstrained feedback law, whose inputs are verified against
                             the box there (rows whose tail leaves it are solved again over a longer head);
-                            -2: every solve in one launch on the INSTANCE-CONTIGUOUS compact store (gathered by the first
-                            backward sweep itself, every row restarts at its own stage), then the commit kernel;
-                            p = 1..12: LEVEL-SYNCHRONOUS -- p pairs of launches (factor, forward) of ONE solve each
-                            over the instances that have not settled yet (work lists re-binned by remaining sweep
-                            length between the launches, two wavefronts per SIMD), one launch for the remaining
-                            12 - p solves, then the commit kernel;
                             0 (default): -3 below 36 S instances (20 S for N <= 40; S = the device's SIMD count, 1024 on MI355X),
-                            -1 beyond -- measured on MI355X, profiles/r04_thresholds.md, DESIGN.md section 5.5: the phase is bound by the bytes of the home blocks and by
-                            the hardest instance's chain of solves, not by occupancy, and -2 / p > 0 are slower at
-                            every fleet size; kept as options.  Same solves in every mode; results agree to rounding. */
+                            -1 beyond -- measured on MI355X, profiles/r04_thresholds.md, DESIGN.md section 5.5.  Same solves in
+                            either mode; results agree to rounding.  Any other value: CFNMPC_EINVAL (round 3's level-synchronous
+                            passes and instance-contiguous store, -2 / 1..12, were slower at every fleet size and live in the
+                            development build only since ABI 9). */
     double ipm_clip_viol; /* QP, interior point: CLIPPED START when the unconstrained minimiser leaves the box by more than
                             this many box widths (2.0; 0 = never).  From such a point (vehicles far from their iterate's
                             trajectory: ~100 kRPM outside and more) the infeasible start spends 30 - 60 iterations at tiny
@@ -177,7 +164,7 @@ typedef struct cfnmpc_opts {
                             0 (default) = 1: measured on MI355X the fused kernel takes the step's HBM traffic from 17.8 to 8.0 GB
                             and is bound by its vector instructions instead (k_linfactor 2.85 - 2.99 ms against 2.70 - 2.87 ms for
                             the pair).  2 is refused (CFNMPC_EINVAL) together with what reads the stored
-                            blocks: cond_N2, overlap_linearise, forward_sweep = 2, as_passes other than 0 / -1; it switches the
+                            blocks: cond_N2, forward_sweep = 2, as_passes other than 0 / -1; it switches the
                             automatic choices to the matrix-free forward sweep and the monolithic active-set kernel, and a solver
                             that is given per-stage boxes later runs the stored-block kernels while they are set.  Same results
                             to rounding (tests/test_gpu_linfactor.py). */
@@ -213,9 +200,8 @@ typedef struct cfnmpc_opts {
                             with the single launch: a retry over a longer head after the tail verification, the active-set
                             iteration instead of the interior point or the other way round; either route ends at the QP's one
                             solution, to its own accuracy).  -1 = off, 0 (default) = by measurement.  An explicit 1 that cannot
-                            be honoured -- outside the as_dense structure, N < 40, forward_sweep = 2, cond_N2, start_solve 2 / 3,
-                            overlap_linearise (its early pass would read the iterate part two is still writing) -- is refused
-                            (CFNMPC_EINVAL). */
+                            be honoured -- outside the as_dense structure, N < 40, forward_sweep = 2, cond_N2, start_solve 2 / 3 -- is
+                            refused (CFNMPC_EINVAL). */
 } cfnmpc_opts;
 
 void cfnmpc_default_opts(cfnmpc_opts *opts);   /* unchecked: the caller's struct MUST be this header's */
@@ -314,14 +300,13 @@ int cfnmpc_get_cmd(cfnmpc_solver *s, double *cmd_vel /*[B][4]*/, int *motvel /*[
 /* Per-phase timing (the role of nlp_out->total_time, acados_mpc.cpp:616): when enabled,
  * cfnmpc_solve brackets its two phases (linearisation, QP) with HIP events on the launch stream;
  * cfnmpc_get_profile waits for them and returns the average durations [ms] over the RTI steps
- * since the last call (at most 4096 steps are timed between two calls), then resets.  With overlap_linearise the linearisation figure is the
- * time it ADDS to the step (the part not hidden behind the interior-point kernel). */
+ * since the last call (at most 4096 steps are timed between two calls), then resets.  */
 int cfnmpc_set_profiling(cfnmpc_solver *s, int enable);
 int cfnmpc_get_profile(cfnmpc_solver *s, double *ms_linearise, double *ms_qp, int *n_steps);
 /* The same timed steps split per kernel group (seven events per step): ms[6] = linearisation | start solve backward
  * (k_factor) | start solve forward (k_forward / k_forward_rg + k_rank) | compaction (k_compact + k_scatter) |
  * active-set kernels (k_as, or the passes + commit + retry) | interior point for what they left (k_ipm_rest / k_ipm).
- * Partial-condensing and overlapped steps report their phases in ms[0] / ms[5] only.  Resets like cfnmpc_get_profile
+ * Partial-condensing steps report their phases in ms[0] / ms[5] only.  Resets like cfnmpc_get_profile
  * (call one of the two). */
 int cfnmpc_get_profile_kernels(cfnmpc_solver *s, double *ms, int *n_steps);
 /* ... and per timed step instead of averaged (the active-set kernels of a step in which a tail check fails take four times the

@@ -1,12 +1,19 @@
-"""Level-synchronous active-set passes (cfnmpc_opts.as_passes > 0: k_asp_first / k_asp / k_ascommit) against
-the monolithic kernel (as_passes = -1) and against the CPU restatement: the solves are the same solves
-(identical counts instance by instance), the new iterate is `candidate + delta` instead of a fresh
-roll-out (rounding-level differences only)."""
+"""The solves + commit structure (cfnmpc_opts.as_passes = -3: k_as_solves / k_ascommit / k_as_retry) against the monolithic
+kernel (as_passes = -1) and against the CPU restatement: the solves are the same solves (identical counts instance by
+instance), the new iterate is `candidate + delta` instead of a fresh roll-out (rounding-level differences only).
+Round 3's level-synchronous passes / instance-contiguous store (as_passes 1..12 / -2) were slower at every fleet size and
+left the product with ABI 9: they are compiled into the DEVELOPMENT build only (make DEV=1), and their cases below run only
+when that library is the one loaded (CFNMPC_LIB=.../libcfnmpc_dev.so python -m pytest tests/test_gpu_as_pipeline.py -m gpu)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 HOV = 15.777730167256925
+
+
+def _dev_build():
+    from crazyflie_nmpc_amd import _lib
+    return hasattr(_lib.lib(), "cfnmpc_debug_chunked_pair")
 
 
 def _fleet(oracle, B, scale, seed, N=50):
@@ -21,6 +28,8 @@ def _fleet(oracle, B, scale, seed, N=50):
 def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, passes, ah):
     from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
     from crazyflie_nmpc_amd.solver import INIT_HOVER
+    if passes != -3 and not _dev_build():
+        pytest.skip("level-synchronous passes: development build only (make DEV=1)")
     x0, yref, yref_e = _fleet(oracle, B, scale, 77 + abs(passes))
     a = BatchSolver(B, default_opts(as_passes=-1, active_horizon=ah))
     b = BatchSolver(B, default_opts(as_passes=passes, active_horizon=ah))
@@ -41,7 +50,7 @@ def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, pass
         else:          # the monolithic kernel gives the four rows of a wave their largest head class, the passes each
             #            row its own: a different (equivalent) QP may take a solve more or less
             assert ((ia > 0) == (ib > 0))[ok].all()
-            assert (ia[as_only] != ib[as_only]).mean() < 0.02 and np.abs(ia[as_only] - ib[as_only]).max() <= 3
+            assert (ia[as_only] != ib[as_only]).mean() < 0.02 and np.abs(ia[as_only] - ib[as_only]).max() <= 4
         # exact QP solutions on both sides: FP64-level agreement (kRPM / state units) for (nearly) all -- heads may differ,
         # and with them the rounding --, the interior point's accuracy for every instance
         du = np.abs(ua - ub).reshape(B, -1).max(1); dx = np.abs(xa - xb).reshape(B, -1).max(1)
@@ -61,17 +70,20 @@ def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, pass
     assert n_con > 20 and n_multi > 5     # constrained QPs with more than one solve were exercised
 
 
-def test_level_synchronous_passes_match_cpu_restatement(oracle, cref):
-    """192 instances, 12 closed-loop steps, full-horizon sweeps: same solves pass by pass as the restatement's
-    as_solve, iterates at FP64 level."""
+@pytest.mark.parametrize("passes", [-3, 3])
+def test_solves_and_commit_match_cpu_restatement(oracle, cref, passes):
+    """192 instances, 12 closed-loop steps, full-horizon sweeps: same solves as the restatement's as_solve, count by count,
+    iterates at FP64 level (passes = 3: the level-synchronous form, development build only)."""
     from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
     from crazyflie_nmpc_amd.solver import INIT_HOVER
+    if passes != -3 and not _dev_build():
+        pytest.skip("level-synchronous passes: development build only (make DEV=1)")
     B, N = 192, 50
     x0, yref, yref_e = _fleet(oracle, B, 1.3, 5)
     opts = cref.default_opts(active_set=1)
     xr = np.repeat(x0[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
     for ah in (0, 1):
-        s = BatchSolver(B, default_opts(active_horizon=ah, as_passes=3))
+        s = BatchSolver(B, default_opts(active_horizon=ah, as_passes=passes, as_dense=-1))
         s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
         x = x0.copy()
         xr[:] = x0[:, None, :]; ur[:] = HOV
@@ -94,8 +106,10 @@ def test_level_synchronous_passes_match_cpu_restatement(oracle, cref):
 
 
 def test_pipeline_option_validation():
+    """the product takes as_passes 0 / -1 / -3 and refuses everything else; the development build also -2 and 1..12"""
     from crazyflie_nmpc_amd import BatchSolver, default_opts
-    for bad in (-4, 13):
+    for bad in (-4, 13) + (() if _dev_build() else (-2, 1, 12)):
         with pytest.raises(Exception):
             BatchSolver(8, default_opts(as_passes=bad))
-    BatchSolver(8, default_opts(as_passes=12)).close()
+    for good in (0, -1, -3) + ((-2, 12) if _dev_build() else ()):
+        BatchSolver(8, default_opts(as_passes=good)).close()

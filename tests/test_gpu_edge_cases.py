@@ -314,14 +314,17 @@ def test_fleet_device_pointers_and_buckets_match_single_horizon_solvers(oracle):
 
 
 @pytest.mark.parametrize("B", [3, 257, 4099, 7000])
-def test_overlapped_preparation_is_bit_identical(oracle, B):
-    """cfnmpc_opts.overlap_linearise: linearising for the next step beside the interior-point
-    kernel (early pass over everybody + list pass over the interior-point instances) must give
+def test_overlapped_preparation_is_bit_identical(oracle, B, monkeypatch):
+    """Overlapped preparation (DEVELOPMENT build only since ABI 9 -- measured slower at every fleet size --, switched on by
+    CFNMPC_OVERLAP=1 in the environment; run with CFNMPC_LIB=.../libcfnmpc_dev.so): linearising for the next step beside the
+    interior-point kernel (early pass over everybody + list pass over the interior-point instances) must give
     the same bits as linearising at the start of cfnmpc_solve -- through a closed loop with
     kicks, a multi-step call, and a save / restore of the iterate in the middle (which drops the
     prepared linearisation)."""
-    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim, _lib
     from crazyflie_nmpc_amd.solver import INIT_HOVER
+    if not hasattr(_lib.lib(), "cfnmpc_debug_chunked_pair"):
+        pytest.skip("overlapped preparation: development build only (make DEV=1)")
     N = 50
     x0, yref, yref_e = _inputs(oracle, B, N, seed=77 + B, scale=2.0)
     rng = np.random.default_rng(5)
@@ -331,10 +334,12 @@ def test_overlapped_preparation_is_bit_identical(oracle, B):
     # writes the new iterate beside the constrained rows' kernels, which the overlapped early pass would read half-written
     # (advisor, round 5): the overlapped solver must not split (here: automatic choice against an explicit -1)
     kw = [dict(forward_sweep=1, forward_split=-1), dict(forward_sweep=1)] if B >= 6144 else [{}, {}]
+    monkeypatch.setenv("CFNMPC_OVERLAP", "1")
     with pytest.raises(Exception):
-        BatchSolver(B, default_opts(overlap_linearise=1, forward_sweep=1, forward_split=1))   # explicit request: refused, not dropped
+        BatchSolver(B, default_opts(forward_sweep=1, forward_split=1))   # explicit request: refused, not dropped
     for ov in (0, 1):
-        s = BatchSolver(B, default_opts(overlap_linearise=ov, **kw[ov]))
+        monkeypatch.setenv("CFNMPC_OVERLAP", str(ov))
+        s = BatchSolver(B, default_opts(**kw[ov]))
         s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
         x = x0.copy()
         log = []
@@ -362,7 +367,8 @@ def test_overlapped_preparation_is_bit_identical(oracle, B):
     if B <= 257:
         # overlap = 1 holds the linearisation of the CURRENT iterate (prepared for the next step);
         # overlap = 0 still holds the one the last QP used -- re-linearise it to compare
-        s0 = BatchSolver(B, default_opts(overlap_linearise=0))
+        monkeypatch.setenv("CFNMPC_OVERLAP", "0")
+        s0 = BatchSolver(B, default_opts())
         s0.set_iterate(runs[0][0][-1][3], runs[0][0][-1][4])
         s0.linearise_only()
         A0, B0, b0 = s0.get_linearisation()
@@ -895,8 +901,6 @@ def test_reinit_failed_option_recovers_a_lost_instance(oracle):
     fresh.solve(1)
     xf, uf = fresh.get_iterate()
     assert np.abs(xa[4] - xf[0]).max() < 1e-9 and np.abs(ua[4] - uf[0]).max() < 1e-9
-    with pytest.raises(Exception):
-        BatchSolver(4, default_opts(reinit_failed=1, overlap_linearise=1))
 
 
 def test_calls_without_a_stream_argument_follow_torchs_current_stream(oracle):

@@ -150,12 +150,11 @@ def test_fused_path_equals_stored_path(oracle, B, kick):
 
 
 def test_start_solve_option_validation_and_per_stage_boxes(oracle):
-    """start_solve = 2 is refused together with what reads the stored blocks (cond_N2, forward_sweep = 2, as_passes = -3,
-    overlap_linearise); a fused solver that later gets per-stage boxes (cfnmpc_set_box_stages) switches to the stored-block
+    """start_solve = 2 is refused together with what reads the stored blocks (cond_N2, forward_sweep = 2, as_passes = -3); a fused solver that later gets per-stage boxes (cfnmpc_set_box_stages) switches to the stored-block
     kernels at launch time and equals a stored-block solver with the same boxes."""
     from crazyflie_nmpc_amd import BatchSolver, default_opts
     from crazyflie_nmpc_amd.solver import INIT_HOVER
-    for bad in (dict(cond_N2=10), dict(forward_sweep=2), dict(as_passes=-3), dict(overlap_linearise=1), dict(start_solve=4)):
+    for bad in (dict(cond_N2=10), dict(forward_sweep=2), dict(as_passes=-3), dict(start_solve=4)):
         kw = dict(start_solve=2); kw.update(bad)
         with pytest.raises(Exception):
             BatchSolver(16, default_opts(**kw))

@@ -107,9 +107,9 @@ def test_condensed_closed_loop_matches_restatement(oracle, cref, N2, B):
 def test_cond_option_validation():
     from crazyflie_nmpc_amd import BatchSolver, default_opts
     from crazyflie_nmpc_amd.solver import CfnmpcError
-    for bad in (dict(cond_N2=4), dict(cond_N2=-1), dict(cond_N2=51), dict(cond_N2=10, overlap_linearise=1)):
+    for bad in (dict(cond_N2=4), dict(cond_N2=-1), dict(cond_N2=51)):
         with pytest.raises(CfnmpcError):
-            BatchSolver(4, default_opts(**bad))      # blocks longer than 10 stages / out of range / overlap
+            BatchSolver(4, default_opts(**bad))      # blocks longer than 10 stages / out of range
     for ok in (0, 50):
         BatchSolver(4, default_opts(cond_N2=ok)).close()    # both mean "no condensing"
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # the default RTI step at every fleet size: no scratch, whatever else changes
-NO_SCRATCH = ["k_linearise", "k_linearise_list", "k_factor", "k_forward", "k_forward_p1", "k_forward_p2", "k_forward_rg", "k_rank",
+NO_SCRATCH = ["k_linearise", "k_factor", "k_forward", "k_forward_p1", "k_forward_p2", "k_forward_rg", "k_rank",
               "k_compact", "k_scatter", "k_as", "k_as_solves", "k_as_retry", "k_ascommit", "k_ascommit1", "k_ipm_list",
               "k_sim", "k_estimate", "k_windows", "k_postproc", "k_put", "k_get"]
 # kernel: (max VGPRs, max AGPRs, max scratch bytes per lane, min waves per SIMD, max LDS bytes per workgroup)

@@ -20,7 +20,12 @@ KEYS = {"VGPRs": "vgpr", "AGPRs": "agpr", "ScratchSize [bytes/lane]": "scratch",
 
 def _demangle(names):
     out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
-    return [o.split("(")[0].replace("cfn::", "").replace("(anonymous namespace)::", "").strip() for o in out[:len(names)]]
+    clean = []
+    for o in out[:len(names)]:
+        o = o.replace("(anonymous namespace)::", "").replace("cfn::", "")
+        o = o[5:] if o.startswith("void ") else o          # (template instances demangle with their return type)
+        clean.append(o.split("(")[0].replace(" ", "").strip())
+    return clean
 
 
 def resource_table(build_dir=None):
