@@ -292,6 +292,12 @@ class MixedFleetLoop:
             x[c0:c1].copy_(self.kicks[t % KICK_PERIOD, : c1 - c0] + self.offd[c0:c1])
             for q in uq:
                 q[c0:c1] = self.hov
+        if self.predictor == "none":     # no delay at all (isolates what the horizon buckets cost: same loop as config C3's)
+            self.fleet.set_x0(x); self.fleet.solve(1); self.fleet.get_u(0, self.u0)
+            sim(x, self.u0, T=0.015, steps=1, out=self.xn)
+            self.x, self.xn = self.xn, x
+            self.t = t + 1
+            return
         if self.predictor == "latest":   # the reference's predictor: the latest input held over the delay, RK4 with 4 sub-steps (App. D-8)
             sim(x, uq[(t + 3) % 4], T=0.06, steps=4, out=self.xp)
         else:
@@ -636,6 +642,12 @@ def main():
             "x0 = RK4 prediction over the 60 ms delay THROUGH THE FOUR QUEUED INPUTS (oldest first); the reference's estimator holds the "
             "LATEST input over the delay (acados_estimator.cpp:573-593) -- with raw motor speeds as plant inputs that closed loop diverges "
             "(no onboard attitude loop in this plant), hence the departure")
+        # what of C5's distance to the uniform fleet is the BUCKETS and what the workload: the same mixed-horizon fleet in config
+        # C3's loop (no delay, targets as drawn) -- stage-steps/s against the headline's value x 50
+        c5p = mixed_horizon_run(B_rank, dev, np.random.default_rng(seed + 9000), 20, ws, predictor="none")
+        c5p["predictor"] = "none: no delay, x0 = the plant state (config C3's loop on the mixed-horizon fleet)"
+        c5p["stage_steps_vs_uniform_fleet"] = c5p["stage_steps_per_s"] / (main_run["value"] * N)
+        extras["config_C5_mixed_horizons_30_50_100_no_delay (cost of the horizon buckets alone)"] = c5p
         # ... and the reference's own protocol beside it, for as long as it holds on this plant
         c5r = mixed_horizon_run(B_rank, dev, np.random.default_rng(seed + 9000), 20, ws, predictor="latest")
         c5r["predictor"] = ("the reference's: x0 = ONE sim solve over the 60 ms delay with the LATEST input held (acados_estimator.cpp:573-593, "
