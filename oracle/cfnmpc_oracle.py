@@ -17,7 +17,9 @@ and is pinned only by (G1) traj/smooth_step.txt (RK4, dt=0.015 reproduces row k+
 tests/test_oracle_golden.py.  The QP produced by one RTI step is strictly convex, so its
 solution is unique: two independent solvers live here (a dense primal-dual solver on the
 condensed QP, `solve_qp_dense`, and the stage-wise Riccati interior point method that the HIP
-kernels implement, `riccati_ipm`) and are cross-checked through the KKT conditions.
+kernels implement, `riccati_ipm`) and are cross-checked through the KKT conditions; `solve_qp_refined`
+(round 6) is the REFEREE between FP64 solvers that disagree above their tolerances: the same QP solved in
+x87 extended precision with refined linear solves and an extended-precision KKT check.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 """

@@ -860,6 +860,16 @@ def test_profile_kernels_split_adds_up(oracle):
     s.solve(3)
     ms, n = s.get_profile_kernels()
     assert n == 3 and len(ms) == 6 and all(v >= 0.0 for v in ms) and ms[0] > 0 and ms[1] > 0 and ms[2] > 0 and ms[4] > 0
+    # ... and per step, not averaged (cfnmpc_get_profile_steps): the same events, the mean of the rows = the averages
+    s.solve(4)
+    per = s.get_profile_steps()
+    assert per.shape == (4, 6) and (per >= 0.0).all() and (per[:, :3] > 0).all()
+    s.solve(3)
+    per2 = s.get_profile_steps(max_steps=2)            # (later timed steps are dropped, the count resets)
+    assert per2.shape == (2, 6)
+    s.solve(2)
+    ms2, n2b = s.get_profile_kernels()
+    assert n2b == 2
     s.solve(2)
     lin, qp, n2 = s.get_profile()
     assert n2 == 2 and lin > 0 and qp > lin * 0.5

@@ -13,7 +13,6 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 # the default RTI step at every fleet size: no scratch, whatever else changes
 NO_SCRATCH = ["k_linearise", "k_factor", "k_forward", "k_forward_p1", "k_forward_p2", "k_forward_rg", "k_rank",
@@ -43,7 +42,6 @@ BUDGET = {
 
 @pytest.fixture(scope="module")
 def table():
-    import resource as _shadow_guard  # noqa: F401  (the stdlib module of the same name must not be what we import below)
     import importlib.util
     spec = importlib.util.spec_from_file_location("cfn_resource", os.path.join(ROOT, "tools", "resource.py"))
     mod = importlib.util.module_from_spec(spec)

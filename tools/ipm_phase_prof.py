@@ -16,7 +16,7 @@ dev = torch.device("cuda", 0)
 SC = float(os.environ.get("KICK", "1"))
 x = torch.from_numpy(sample_hover_x0(rng, B, scale=SC)).to(dev)
 row = regulation_row()
-s = BatchSolver(B, default_opts(overlap_linearise=int(os.environ.get("OV", "0")), active_set=int(os.environ.get("AS", "1"))))
+s = BatchSolver(B, default_opts(active_set=int(os.environ.get("AS", "1"))))
 s.set_x0(x); s.set_yref(torch.from_numpy(np.tile(row, (B, N, 1))).to(dev), torch.from_numpy(np.tile(row[:13], (B, 1))).to(dev)); s.init_iterate(INIT_HOVER)
 cohort = B // KP
 kicks = torch.from_numpy(sample_hover_x0(rng, cohort * KP, scale=SC).reshape(KP, cohort, 13)).to(dev)
