@@ -147,24 +147,18 @@ int cfnmpc_fleet_create(cfnmpc_fleet** out, int batch, const int* N_per_instance
             hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) { rc = CFNMPC_EHIP; break; }
     }
     // Longest job first: the buckets run concurrently on their own streams, and the step lasts as long as the bucket with the
-    // most work (N x vehicles: the N = 100 third of config C5 carries 55 % of the stage-steps).  Its launches go out first and
-    // its stream gets the highest priority the device offers, the lightest bucket the lowest, so that the dispatcher fills the
-    // heavy bucket's kernels first and the light ones fill the gaps -- instead of the heavy bucket finishing alone on a third
-    // of the machine's width.
+    // most work (N x vehicles: the N = 100 third of config C5 carries 55 % of the stage-steps) -- its launches go out first.
+    // (Round 6 also gave the heavy bucket's stream the device's highest PRIORITY and the light one the lowest: +1.3 % in a fresh
+    //  process, but -17 % inside bench.py's full run, where a dozen solvers' streams have been created and destroyed before --
+    //  9.5 against 11.4 M RTI steps/s, A/B on one box, profiles/r06_notes.md section 7.  Plain streams.)
     if (rc == CFNMPC_OK) {
         f->order.resize(f->bk.size());
         for (size_t i = 0; i < f->bk.size(); i++) f->order[i] = (int)i;
         std::stable_sort(f->order.begin(), f->order.end(), [&](int a, int b) {
             return (long)f->bk[a].N * f->bk[a].count > (long)f->bk[b].N * f->bk[b].count;
         });
-        int lo = 0, hi = 0;   // lo = least priority (numerically greatest)
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = hi = 0; (void)hipGetLastError(); }
-        const int nb = (int)f->bk.size(), levels = lo - hi + 1;
-        for (int r = 0; r < nb && rc == CFNMPC_OK; r++) {
-            // rank r of nb over the available levels: heaviest -> hi, lightest -> lo
-            const int pr = (nb > 1 && levels > 1) ? hi + (int)((long)r * (levels - 1) / (nb - 1)) : hi;
-            if (hipStreamCreateWithPriority(&f->bk[f->order[r]].st, hipStreamNonBlocking, pr) != hipSuccess) rc = CFNMPC_EHIP;
-        }
+        for (Bucket& b : f->bk)
+            if (rc == CFNMPC_OK && hipStreamCreateWithFlags(&b.st, hipStreamNonBlocking) != hipSuccess) rc = CFNMPC_EHIP;
     }
     if (rc != CFNMPC_OK) { cfnmpc_fleet_free(f); return rc; }
     *out = f;
