@@ -1518,6 +1518,11 @@ __device__ __forceinline__ void sweep_clip_gradient(const Params& P, const Param
 __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave, [8] its total, [9] sum of totals, [10] waves, [16..23] phase sums
 #define PROF_T(i) { const unsigned long long now_ = wall_clock64(); pacc[i] += now_ - plast; plast = now_; }
 #define PROF_SOLVE(h) { psolves++; pstages += (h); }
+#ifdef CFN_PROF_MODE
+#define CFN_PROF_MODE_OR(m) CFN_PROF_MODE
+#else
+#define CFN_PROF_MODE_OR(m) (m)
+#endif
 #else
 #define PROF_T(i)
 #define PROF_SOLVE(h)
@@ -1535,6 +1540,11 @@ __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave
 // CST (fused start solve, Params.fused = 1): the instance's (A, B, b) of ALL stages are already in the wave's compact blocks
 // (k_linearise_clist wrote them there; the home blocks hold none) -- nothing to gather but the 4-vectors and the
 // checkpoint, and the roll-out reads the compact copy over the whole horizon.
+// Fall-back rows start on the full horizon when their classified head is at least this long (1: always; 0: never -- the
+// behaviour up to round 5; A/B builds: -DCFN_REST_FULL_HEAD=...)
+#ifndef CFN_REST_FULL_HEAD
+#define CFN_REST_FULL_HEAD 1
+#endif
 template <int MODE, bool SBOX = false, bool CST = false, bool QT = false>
 __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE], double (*btile)[64], const int vb,
                                         const double* qtab = nullptr) {
@@ -1577,6 +1587,12 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     int head = t.valid ? gm(P.head)[t.inst] : 0;
     head = max(head, __shfl_xor(head, 16));
     head = max(head, __shfl_xor(head, 32));
+    // Fall-back rows (MODE 2: the active set did not settle, or was skipped) run their interior point on the FULL horizon -- the
+    // restatement's own algorithm: 99 % of them end there anyway, after a first run over the classified head whose tail
+    // check fails (16 of the 36 iterations of the launch's longest wave at kicks x 2, and the launch lasts as long as that
+    // wave: 5.7 -> 4.7 ms there, 7.2 -> 6.1 ms at kicks x 3; a small fleet's step with one such row 5.0 -> 3.6 ms;
+    // profiles/r06_notes.md section 12).  No tail, hence no tail check and no second attempt.
+    if (MODE == 2 && CFN_REST_FULL_HEAD > 0 && head >= CFN_REST_FULL_HEAD) head = N;
     int chk = -1;
     SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
     const double viol = t.valid ? gm(P.viol)[t.inst] : 0.0;
@@ -1845,6 +1861,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             if (R.act) R.iters++;
             // predictor: factorise (R^, g from the element-wise pass), forward
             PROF_T(1)
+            PROF_SOLVE(head)   // (profiling builds: interior-point iterations count like active-set solves)
             const bool fok = sweep_factor<false>(Q, lane_opaque(tc), head, chk, wt, sb);
             PROF_T(2)
             sweep_forward_delta(Q, lane_opaque(tc), head, gm(Q.dva));
@@ -2043,6 +2060,9 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         const bool redo = AS_ONLY ? (t.valid && as_done && kviol >= 0 && head < N)
                                     : (t.valid && R.status != 4 && kviol >= 0 && head < N);
         if (!__any(redo)) break;
+#ifdef CFN_PROF
+        if (threadIdx.x == 0 && MODE == CFN_PROF_MODE_OR(MODE)) atomicAdd(&g_prof[15], 1ull);   // (waves that go round again)
+#endif
         // rare: a tail input left the box -> solve again (whole wave) over the smallest head class
         // that covers the offending stage (+4), the full horizon as the last resort.  Nothing of
         // the start solve was touched (the sweeps work on the compact copy), so just re-gather.

@@ -214,7 +214,10 @@ def test_active_set_under_heavy_saturation(oracle, cref, scale, init):
     """Stress of the default QP method: large perturbations (many inputs at both bounds over long
     heads) and the cold acados start (iterate far from the measurement: the active-set iteration
     does not always settle and hands over to the interior point).  Whatever route an instance
-    takes, it must end at the restatement's solution, inside the box, with status 0."""
+    takes, it must end at the restatement's solution, inside the box, with status 0.
+    Rows that fall back to the interior point run it over the FULL horizon (round 6: the restatement's own algorithm, one
+    attempt instead of a run over the classified head + another after its tail check failed): head = N, and the iteration
+    counts are the restatement's up to borderline exits."""
     from crazyflie_nmpc_amd import BatchSolver, sim, default_opts
     from crazyflie_nmpc_amd.solver import INIT_ACADOS, INIT_HOVER
     B, N, tol = 256, 50, 1e-10
@@ -231,17 +234,65 @@ def test_active_set_under_heavy_saturation(oracle, cref, scale, init):
     n_con = 0
     for t in range(4):
         s.set_x0(x); s.solve(1)
-        st, it, _ = s.stats()
-        st_r, it_r, _, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        st, it, rs = s.stats()
+        st_r, it_r, rs_r, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
         xg, ug = s.get_iterate()
         assert (st == 0).all() and (st_r == 0).all(), (t, np.bincount(st), np.bincount(st_r))
         assert ((it > 0) == (it_r > 0)).all()
         assert ug.min() > -1e-9 and ug.max() < 22.0 + 1e-9
         assert np.abs(ug - ur).max() < 2e-5 and np.abs(xg - xr).max() < 2e-5, (t, np.abs(ug - ur).max())
+        fb = (it > 0) & (rs > 0)                       # interior-point rows (active-set rows report res = 0 exactly)
+        assert (s.heads()[fb] == N).all(), (t, s.heads()[fb])
+        both = fb & (rs_r > 0)
+        assert (np.abs(it[both] - it_r[both]) <= 1).all(), (t, it[both], it_r[both])
         n_con += int((it > 0).sum())
         x = sim(x, s.get_u(0), T=0.015, steps=1)
         ur[:] = ug; xr[:] = xg
     assert n_con > B // 2
+
+
+def test_fallback_rows_run_the_full_horizon(oracle, cref):
+    """Heavily disturbed closed loop (3 x the bench's kicks, a cohort re-kicked every step): about one row in a hundred falls back
+    to the interior point -- its active set does not settle within the cap, or it skips the iteration (as_skip_viol).  Those rows
+    run the interior point over the FULL horizon in one attempt (head = N; up to round 5: over the classified head first and
+    over the full horizon after its tail check had failed -- 99 % of them), which is the restatement's own algorithm: the SAME
+    iteration counts, iterates at FP64 level times the conditioning (measured: <= 1e-6 at equal residuals)."""
+    from crazyflie_nmpc_amd import BatchSolver, sim, default_opts
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B, N, KP = 768, 50, 8
+    rng = np.random.default_rng(606)
+    x = oracle.sample_hover_x0(rng, B, scale=3.0)
+    yr, yre = oracle.regulation_yref(N, (0, 0, 0.4))
+    yref = np.repeat(yr[None], B, 0).copy(); yref_e = np.repeat(yre[None], B, 0).copy()
+    xr = np.repeat(x[:, None, :], N + 1, 1).copy(); ur = np.full((B, N, 4), HOV)
+    opts = cref.default_opts(active_set=1)
+    s = BatchSolver(B, default_opts())
+    s.set_x0(x); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    n_fb = n_same = n_mixed = n_con = 0
+    for t in range(6):
+        c0 = (t % KP) * (B // KP)
+        x[c0:c0 + B // KP] = oracle.sample_hover_x0(rng, B // KP, scale=3.0)
+        s.set_x0(x); s.solve(1)
+        st, it, rs = s.stats()
+        st_r, it_r, rs_r, _ = cref.rti_step(opts, xr, ur, x.copy(), yref, yref_e, nthreads=0)
+        xg, ug = s.get_iterate()
+        ok = (st == 0) & (st_r == 0)
+        assert ok.mean() > 0.98, (t, np.bincount(st), np.bincount(st_r))
+        assert ((it > 0) == (it_r > 0))[ok].all()
+        fb = ok & (it > 0) & (rs > 0)                  # interior-point rows (active-set rows report res = 0 exactly)
+        assert (s.heads()[fb] == N).all(), (t, s.heads()[fb])
+        both = fb & (rs_r > 0)
+        same = both & (it == it_r)
+        err = np.maximum(np.abs(ug - ur).reshape(B, -1).max(1), np.abs(xg - xr).reshape(B, -1).max(1))
+        assert err[same].max(initial=0.0) < 5e-6, (t, err[same].max())
+        assert err[ok].max() < 5e-4, (t, err[ok].max())        # (a row that took the other route, a borderline exit: tolerance level)
+        n_fb += int(both.sum()); n_same += int(same.sum()); n_con += int((ok & (it > 0)).sum())
+        n_mixed += int((ok & (it > 0) & ((rs > 0) != (rs_r > 0))).sum())
+        x = sim(x, s.get_u(0), T=0.015, steps=1)
+        ur[:] = ug; xr[:] = xg
+    assert n_fb >= 10, n_fb              # the fall-back was exercised ...
+    assert n_same >= 0.9 * n_fb, (n_same, n_fb)   # ... with the restatement's iteration counts
+    assert n_mixed <= 0.01 * n_con, (n_mixed, n_con)
 
 
 @pytest.mark.parametrize("active_horizon", [0, 1])

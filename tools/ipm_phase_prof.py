@@ -32,6 +32,6 @@ for t in range(30):
         L.cfnmpc_debug_prof(out, 0)
         v = np.array(list(out), dtype=np.float64) / 100.0  # wall_clock64: 100 MHz -> us
         print(f"step {t}: longest wave {v[8]:.0f} us, mean wave {v[9] / max(out[10], 1):.0f} us over {out[10]} waves")
-        print(f"   longest wave: {out[11]} active-set solves over {out[12]} stages; all waves: {out[13]} solves, {out[14]} stages")
+        print(f"   longest wave: {out[11]} solves / interior-point iterations over {out[12]} stages; all waves: {out[13]} over {out[14]} stages; {out[15]} further attempts (longer head after a failed tail check)")
         print("   longest: " + "  ".join(f"{n} {v[i]:.0f}" for i, n in enumerate(names)))
         print("   mean   : " + "  ".join(f"{n} {v[16 + i] / max(out[10], 1):.0f}" for i, n in enumerate(names)))
