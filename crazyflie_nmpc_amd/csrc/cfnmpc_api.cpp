@@ -441,7 +441,7 @@ int cfnmpc_create(cfnmpc_solver** out, int batch, const cfnmpc_opts* opts) {
     ALLOC(cPs, NW * 32 * cfn::SZ_PA);
     ALLOC(status, NW * 4); ALLOC(iters, NW * 4); ALLOC(head, NW * 4); ALLOC(res, NW * 4); ALLOC(viol, NW * 4);
     ALLOC(ilist, NW * 4); ALLOC(ilist2, NW * 4); ALLOC(nipm, 64);
-    ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * 32); ALLOC(rank, NW * 4); ALLOC(done, NW * 4);
+    ALLOC(blkcnt, ((size_t)(batch + 63) / 64) * cfn::BIN_STRIDE); ALLOC(rank, NW * 4); ALLOC(done, NW * 4);
     ALLOC(ascnt, 32); ALLOC(askst, NW * 4); ALLOC(asst, NW * 4); ALLOC(asok, NW * 4);
     ALLOC(czdx, NW * 4 * (N + 1) * 13);
     if (P.as_warm) { ALLOC(wcls, NW * 4 * N * 4); ALLOC(wvalid, NW * 4); }
@@ -1202,7 +1202,7 @@ int cfnmpc_debug_get_list_counts(cfnmpc_solver* s, int* counts) {
     HIP_TRY(hipDeviceSynchronize());
     int h[64];
     HIP_TRY(hipMemcpy(h, s->P.nipm, sizeof h, hipMemcpyDeviceToHost));
-    counts[0] = h[0]; counts[1] = s->P.ipm_listed ? h[40] : 0; counts[2] = h[41]; counts[3] = s->P.fwd_split ? h[42] : 0;
+    counts[0] = h[0]; counts[1] = s->P.ipm_listed ? h[cfn::NI_LISTED] : 0; counts[2] = h[cfn::NI_LONG16]; counts[3] = s->P.fwd_split ? h[cfn::NI_LATE] : 0;
     return CFNMPC_OK;
 }
 

@@ -25,7 +25,7 @@
 //   4. dx of the head by one forward sweep; du / dx / settled flag / solve count handed to k_ascommit exactly as k_as_solves
 //      does (roll-out, tail verification, retries and the interior-point fall-back are unchanged).
 //
-// One wavefront = one row; rows with longer heads stay with k_as_solves (the compaction lists them first: P.nipm[41] rows).
+// One wavefront = one row; rows with longer heads stay with k_as_solves (the compaction lists them first: P.nipm[NI_LONG16] rows).
 // LDS: 32 KB (staged stage matrices, then H) + 2 KB per wavefront -> four per compute unit.  Scalar input box only.
 #include <hip/hip_runtime.h>
 
@@ -273,7 +273,7 @@ KALIGN __global__ __launch_bounds__(64) void k_as_dense(Params P) {
     __shared__ DenseLds S;
     const int lane = threadIdx.x;
     const int N = P.N;
-    const int nipm = gm(P.nipm)[0], nbig = gm(P.nipm)[41];
+    const int nipm = gm(P.nipm)[0], nbig = gm(P.nipm)[NI_LONG16];
     for (int slot = nbig + (int)blockIdx.x; slot < nipm; slot += (int)gridDim.x) {
 #ifdef CFN_PROF
         unsigned long long dacc[6] = {0, 0, 0, 0, 0, 0}, dlast = wall_clock64();

@@ -105,7 +105,7 @@ static_assert(div_ok(52, 64 * 13), "k_forward: e / 52 by multiply-shift");
 //                   slot c owns row c & 3 of compact block c >> 2, i.e. 64 consecutive slots = 16 consecutive blocks,
 //                   written in the same contiguous runs as the home blocks) -- the fused start solve never stores
 //                   (A, B, b), so the instances whose QP needs them again get them here (k_linearise_clist);
-//                   which = 0: P.ilist (count P.nipm[0]), 1: P.ilist2 (P.nipm[40], the interior-point fall-back rows).
+//                   which = 0: P.ilist (count P.nipm[0]), 1: P.ilist2 (P.nipm[NI_LISTED], the interior-point fall-back rows).
 template <bool GATHER, bool CSTORE = false>
 __device__ __forceinline__ void linearise_body(const Params& P, double* sx, double (*sc)[64 * 13], int* sinst,
                                                const int which = 0) {
@@ -116,7 +116,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     {
         const int li = blockIdx.x * 64 + tid;
         int inst;
-        if (GATHER) inst = li < gm(P.nipm)[which ? 40 : 0] ? gm(which ? P.ilist2 : P.ilist)[li] : P.NW * 4 + (tid & 3);
+        if (GATHER) inst = li < gm(P.nipm)[which ? NI_LISTED : 0] ? gm(which ? P.ilist2 : P.ilist)[li] : P.NW * 4 + (tid & 3);
         else inst = li < P.NW * 4 ? li : P.NW * 4 + (tid & 3);
         sinst[tid] = inst;
     }
@@ -132,7 +132,7 @@ __device__ __forceinline__ void linearise_body(const Params& P, double* sx, doub
     if (k0 >= k1) return;
     // CSTORE: list slots of this group that own a row (the lanes behind the list's end linearise the spare instance; their
     // results must not land in real compact slots -- for which = 1 those belong to rows of the FIRST list)
-    const int n_live = CSTORE ? gm(P.nipm)[which ? 40 : 0] - (int)blockIdx.x * 64 : 64;
+    const int n_live = CSTORE ? gm(P.nipm)[which ? NI_LISTED : 0] - (int)blockIdx.x * 64 : 64;
 
     // address of element (local instance li, lane i) of a field with `stages` stages per block, SZ
     // doubles per (block, stage), NS lanes per instance starting at `pre4` inside the block.
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64) void k_linearise_clist(Params P, int which) {
     __shared__ double sx[2 * 64 * 13];
     __shared__ double sc[4][64 * 13];
     __shared__ int sinst[64];
-    if ((int)blockIdx.x * 64 >= gm(P.nipm)[which ? 40 : 0]) return;
+    if ((int)blockIdx.x * 64 >= gm(P.nipm)[which ? NI_LISTED : 0]) return;
     linearise_body<true, true>(P, sx, sc, sinst, which);
 }
 
@@ -837,7 +837,7 @@ __device__ __forceinline__ void keep_row(const Params& P, const Lane& t, const b
     }
 }
 
-constexpr int N_BIN = (N_CHK + 1) * 3, BIN_STRIDE = 32;   // compaction bins: head class x difficulty
+// (compaction bins: head class x difficulty -- N_BIN, BIN_STRIDE, diff_bin in cfnmpc_ws.hpp)
 // class index of a head (0: full horizon, 1..N_CHK: checkpoint stages from large to small)
 __device__ __forceinline__ int head_cls(const Params& P, int h) {
     int r = 0;
@@ -898,7 +898,7 @@ __device__ __forceinline__ int head_want(const Params& P, int last_tight) {
 // classification over that window (violations, tight stages, head class, compaction ranks), hand-over of dx_H and the
 // classification state in P.fs_dx / P.fs_st; 2: stages [H, N) for every instance, run BESIDE the constrained rows' QP kernels
 // (whose heads of at most H stages read nothing behind H).  An instance that is feasible over [0, H) and violates a bound
-// behind H is a LATE row: part 2 appends it to the compacted list behind its end (P.nipm[42] counts them) with the head its
+// behind H is a LATE row: part 2 appends it to the compacted list behind its end (P.nipm[NI_LATE] counts them) with the head its
 // tight stages ask for and the flag k_as_retry picks up (P.done = 2).
 template <bool COND, bool FUSED_PT = false, int SPLIT = 0>
 __device__ __forceinline__ void forward_body(const Params& P, double* xs, double* cs, int* sflag) {
@@ -1098,7 +1098,7 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
             gm(P.head)[inst] = infeasible ? head_class(P, head_want(P, last_tight)) : 0;
             if (P.as_warm && !infeasible) gm(P.wvalid)[inst] = 0;
         }
-        const int hc = infeasible ? head_cls(P, head_class(P, head_want(P, last_tight))) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
+        const int hc = infeasible ? head_cls(P, head_class(P, head_want(P, last_tight))) * N_DIFF + diff_bin(nviol, P.as_passes == 0 && P.active_set) : -1;
         const unsigned long long below = (1ull << tid) - 1ull;
         SFOR(c, 0, N_BIN, {
             const unsigned long long m = __ballot(hc == c);
@@ -1122,7 +1122,7 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
             gm(P.viol)[inst] = viol;
             gm(P.head)[inst] = head_class(P, head_want(P, last_tight));
             gm(P.done)[inst] = 2;                                   // k_as_retry solves it (the interior point what that leaves)
-            const int pos = atomicAdd(P.nipm + 42, 1);
+            const int pos = atomicAdd(P.nipm + NI_LATE, 1);
             gm(P.ilist)[gm(P.nipm)[0] + pos] = inst;
         }
     } else {
@@ -1147,10 +1147,10 @@ __device__ __forceinline__ void forward_body(const Params& P, double* xs, double
         if (P.as_warm && !infeasible) gm(P.wvalid)[inst] = 0;   // an unconstrained step ends the instance's run of constrained ones
     }
     {   // first half of the stable compaction: per-group bin counts and ranks.  Bin = head class
-        // (largest first) x difficulty (number of violated inputs of the unconstrained minimiser:
-        // >= 4, 2..3, 1 -- the active-set solve needs more passes the more bounds are involved,
+        // (largest first) x difficulty (number of violated inputs of the unconstrained minimiser in
+        // N_DIFF classes, diff_bin -- the active-set solve needs more passes the more bounds are involved,
         // and a wave lasts as long as the slowest of its four rows)
-        const int hc = infeasible ? head_cls(P, head_class(P, head_want(P, last_tight))) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
+        const int hc = infeasible ? head_cls(P, head_class(P, head_want(P, last_tight))) * N_DIFF + diff_bin(nviol, P.as_passes == 0 && P.active_set) : -1;
         const unsigned long long below = (1ull << tid) - 1ull;
         SFOR(c, 0, N_BIN, {
             const unsigned long long m = __ballot(hc == c);
@@ -1295,7 +1295,7 @@ __device__ __forceinline__ void forward_rg_body(const Params& P) {
         gm(P.head)[t.inst] = head;
         if (P.as_warm && !infeasible) gm(P.wvalid)[t.inst] = 0;
         // compaction bin (head class x difficulty), ranked per 64-instance group by k_rank
-        gm(P.rank)[t.inst] = infeasible ? head_cls(P, head) * 3 + (nviol >= 4 ? 0 : (nviol >= 2 ? 1 : 2)) : -1;
+        gm(P.rank)[t.inst] = infeasible ? head_cls(P, head) * N_DIFF + diff_bin(nviol, P.as_passes == 0 && P.active_set) : -1;
     }
     keep_row(P, t, bad);   // a failed row keeps its iterate: old -> new
 }
@@ -1357,9 +1357,9 @@ __global__ __launch_bounds__(256) void k_scatter(Params P) {
             gm(P.nipm)[0] = acc;
             // rows whose head is longer than 16 stages come first in the list (bins are ordered by head class, longest first:
             // full horizon, 32, 24 | 16, 12, 8, 4): their number -- the dense active-set kernel (cfnmpc_asdense.hip) takes the rest
-            gm(P.nipm)[41] = P.N > 16 ? base[9] : 0;
-            gm(P.nipm)[43] = P.N > 24 ? base[6] : 0;    // ... of more than 24 stages (full horizon, 32): behind part two of a split sweep
-            gm(P.nipm)[42] = 0;                          // late rows of this step's split sweep (k_forward_p2 counts them)
+            gm(P.nipm)[NI_LONG16] = P.N > 16 ? base[3 * N_DIFF] : 0;
+            gm(P.nipm)[NI_LONG24] = P.N > 24 ? base[2 * N_DIFF] : 0;    // ... of more than 24 stages (full horizon, 32): behind part two of a split sweep
+            gm(P.nipm)[NI_LATE] = 0;                                    // late rows of this step's split sweep (k_forward_p2 counts them)
         }
     }
     if (blockIdx.x == 0 && P.ascnt && threadIdx.x < 32) gm(P.ascnt)[threadIdx.x] = 0;   // work lists of the active-set passes
@@ -1554,13 +1554,13 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     unsigned long long psolves = 0, pstages = 0;
 #endif
     // MODE 2 works on the list k_ipm_list compacted from the rows the active-set kernels left (P.ilist2, count in
-    // P.nipm[40]): four fall-back rows per wave instead of one row in each of the waves they were scattered over
+    // P.nipm[NI_LISTED]): four fall-back rows per wave instead of one row in each of the waves they were scattered over
     const bool listed = MODE == 2 && P.ipm_listed;   // (small fleets skip k_ipm_list: the rows stay where k_as had them)
-    // (MODE 4 beside the dense kernel: only the rows with heads of more than 16 stages, the first P.nipm[41] of the list)
-    // (MODE 2 / 3 behind a split forward sweep: the late rows its second part appended -- P.nipm[42] of them -- belong to the list)
-    const int nipm = gm(P.nipm)[listed ? 40 : ((MODE == 4 && P.as_dense) ? (P.as_range == 2 ? 43 : 41) : 0)] +
-                     (((MODE == 2 && !listed) || MODE == 3) && P.fwd_split ? gm(P.nipm)[42] : 0);
-    const int slot_lo = (MODE == 4 && P.as_dense && P.as_range == 1) ? gm(P.nipm)[43] : 0;   // (first list slot of this launch)
+    // (MODE 4 beside the dense kernel: only the rows with heads of more than 16 stages, the first P.nipm[NI_LONG16] of the list)
+    // (MODE 2 / 3 behind a split forward sweep: the late rows its second part appended -- P.nipm[NI_LATE] of them -- belong to the list)
+    const int nipm = gm(P.nipm)[listed ? NI_LISTED : ((MODE == 4 && P.as_dense) ? (P.as_range == 2 ? NI_LONG24 : NI_LONG16) : 0)] +
+                     (((MODE == 2 && !listed) || MODE == 3) && P.fwd_split ? gm(P.nipm)[NI_LATE] : 0);
+    const int slot_lo = (MODE == 4 && P.as_dense && P.as_range == 1) ? gm(P.nipm)[NI_LONG24] : 0;   // (first list slot of this launch)
     // SPARSE (active-set kernels, short lists): ONE list slot per wave (row 0; rows 1..3 idle) while the constrained rows
     // number fewer than the SIMDs -- every row then sweeps its own head, restarts at its own stage and stops after its own
     // last solve instead of following the slowest of four wave-mates, and the kernel lasts as long as its hardest ROW.
@@ -2107,7 +2107,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
 __global__ __launch_bounds__(1024) void k_ipm_list(Params P) {
     __shared__ int cnt[1024];
     const int tid = threadIdx.x;
-    const int n = gm(P.nipm)[0] + (P.fwd_split ? gm(P.nipm)[42] : 0);   // (+ the late rows of a split forward sweep)
+    const int n = gm(P.nipm)[0] + (P.fwd_split ? gm(P.nipm)[NI_LATE] : 0);   // (+ the late rows of a split forward sweep)
     const int chunk = (n + 1023) / 1024;
     const int lo = tid * chunk, hi = min(lo + chunk, n);
     int c = 0;
@@ -2138,7 +2138,7 @@ __global__ __launch_bounds__(1024) void k_ipm_list(Params P) {
     }
     __syncthreads();
     const int wbase = (tid >> 6) > 0 ? cnt[16 + (tid >> 6) - 1] : 0;
-    if (tid == 1023) gm(P.nipm)[40] = wbase + incl;
+    if (tid == 1023) gm(P.nipm)[NI_LISTED] = wbase + incl;
     int pos = wbase + incl - c;
     if (c == 0) return;
     if (chunk <= 8) {
@@ -2153,7 +2153,7 @@ __global__ __launch_bounds__(1024) void k_ipm_list(Params P) {
 // rows the interior-point fall-back has to look at: the compacted fall-back list, or the whole list + the late rows of a
 // split forward sweep (qp_wave<2> counts the same way)
 __device__ __forceinline__ int ipm_rest_rows(const Params& P) {
-    return P.ipm_listed ? gm(P.nipm)[40] : gm(P.nipm)[0] + (P.fwd_split ? gm(P.nipm)[42] : 0);
+    return P.ipm_listed ? gm(P.nipm)[NI_LISTED] : gm(P.nipm)[0] + (P.fwd_split ? gm(P.nipm)[NI_LATE] : 0);
 }
 __global__ __launch_bounds__(64) void k_ipm(Params P) {       // MODE 0: used when active_set = 0
     __shared__ __attribute__((aligned(16))) double wtile[4][WT_TILE];
@@ -3121,7 +3121,7 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         const int G = imax_h(1, imin_h(P.as_grid, P.NW));
         if (P.as_passes == -2 && P.as_dense) {
             // heads of at most 16 stages: head-condensed dense solves (one row per wavefront, one wavefront per SIMD) on the
-            // caller's stream; the rows with longer heads (the first P.nipm[41] of the list: none, or a handful) keep the Riccati
+            // caller's stream; the rows with longer heads (the first P.nipm[NI_LONG16] of the list: none, or a handful) keep the Riccati
             // form of the iteration in k_as_solves, forked onto the solver's side stream -- two latency chains side by side.
             // Split forward sweep: its second part (stages [24, N) of EVERY instance) runs on a second side stream beside both;
             // rows with heads of 24 stages read nothing behind stage 24 and stay beside it, the rows with longer heads follow it.
@@ -3176,7 +3176,7 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
 #endif
         if (P.NW <= 2 * P.as_grid) hipLaunchKernelGGL(k_ascommit1, dim3(imax_h(1, imin_h(P.as_grid / 2, P.NW))), dim3(64), 0, st, P);
         else hipLaunchKernelGGL(k_ascommit, dim3(G), dim3(64), 0, st, P);
-        // (late rows of a split forward sweep: k_as_retry and k_ipm_rest count them in, P.nipm[0] + P.nipm[42].  Tried: both modes in
+        // (late rows of a split forward sweep: k_as_retry and k_ipm_rest count them in, P.nipm[0] + P.nipm[NI_LATE].  Tried: both modes in
         //  ONE launch for small fleets, where each normally finds nothing to do and an empty launch costs 5 - 7 us -- either half
         //  alone runs, the combined kernel aborts on the device; not pursued)
         hipLaunchKernelGGL(k_as_retry, dim3(P.NW), dim3(64), 0, st, P);

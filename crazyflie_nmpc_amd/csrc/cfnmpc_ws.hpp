@@ -57,6 +57,29 @@ __host__ __device__ inline int pchk_at(int j, int q, int r) {                   
 constexpr int SZ_PA = 4 * 13 * 14; // ... with the affine row (lane 13): [col j][inst][14]
 
 constexpr int N_CHK = 6;  // Riccati checkpoints for the active-horizon QP (stage indices below)
+// Compaction of the constrained rows: bins = head class (7: full horizon, 32, 24, 16, 12, 8, 4 -- longest first) x difficulty
+// (N_DIFF classes of the number of violated inputs of the unconstrained minimiser, hardest first).  The four rows of a wave
+// run their active-set solves in lock-step until the slowest has settled, so rows of similar difficulty should share a wave.
+// Rounds 2 - 5 knew three classes (>= 4 | 2..3 | 1 violated inputs); round 6 splits the first (>= 20 | 9..19 | 4..8: mean
+// solve counts 5.7 | 3.1 - 4.1 | 2.0 - 2.5 on the restatement's closed loop) for the MONOLITHIC active-set kernel (not the interior-point-only one: +1 %), i.e. where
+// the constrained rows outnumber the SIMDs and the kernel is bound by the waves' work: under heavy disturbances most rows
+// sit in that class (kicks x 2: 78 % of them; a wave spends 84 solve-stages where its rows need 58 -- 76 with the split) and
+// k_as gets 8 % shorter (6.9 -> 6.3 ms; x 3: 17.9 -> 17.0 ms; bench workload: 0.636 -> 0.630 ms).  The solves + commit
+// structure of the smaller fleets keeps the three classes: there every wave is resident at once, the kernel lasts as long as
+// its hardest wave, and four hard rows in one wave restart their factorisations at the farthest stage ANY of them changed
+// (+2 - 3 % at 32 768 / 40 960 instances with the split).  The violation count explains that much of the solve count and no
+// more (correlation 0.74 - 0.78; eight classes: the same to 1 %); profiles/r06_notes.md section 13.
+constexpr int N_DIFF = 5;
+constexpr int N_BIN = (N_CHK + 1) * N_DIFF, BIN_STRIDE = 64;   // (bins per 64-instance group of the forward sweep, padded)
+__host__ __device__ constexpr int diff_bin(int nviol, bool fine) {        // 0 = hardest
+    return (fine && nviol >= 20) ? 0 : ((fine && nviol >= 9) ? 1 : (nviol >= 4 ? 2 : (nviol >= 2 ? 3 : 4)));
+}
+// Params.nipm: [0] length of the list, [1 + bin] rows per bin, and behind the bins:
+constexpr int NI_LISTED = 60;   // rows k_ipm_list compacted for the interior-point fall-back (ilist2)
+constexpr int NI_LONG16 = 61;   // listed rows with heads of more than 16 stages (first in the list)
+constexpr int NI_LATE = 62;     // late rows of a split forward sweep (appended behind the list)
+constexpr int NI_LONG24 = 63;   // listed rows with heads of more than 24 stages
+static_assert(1 + N_BIN <= NI_LISTED && N_BIN <= BIN_STRIDE, "bin counts fit in front of the named slots of Params.nipm (64 ints)");
 __host__ __device__ constexpr int chk_stage(int c) { return c == 0 ? 4 : (c == 1 ? 8 : (c == 2 ? 12 : (c == 3 ? 16 : (c == 4 ? 24 : 32)))); }
 
 struct Params {
@@ -120,10 +143,10 @@ struct Params {
     int *status, *iters, *head;  // per instance (head: stages the interior-point sweeps cover, 0 = none)
     double *res, *viol;          // per instance
     int ipm_listed;              // 1: k_ipm_rest works on ilist2 (fleets whose fall-back rows may exceed one wave per SIMD); 0: on ilist, filtered
-    int *ilist2;                 // the rows of ilist the active-set kernels left for the interior point (k_ipm_list; count in nipm[40])
+    int *ilist2;                 // the rows of ilist the active-set kernels left for the interior point (k_ipm_list; count in nipm[NI_LISTED])
     int *ilist;                  // compacted list of the instances that need the interior-point method
     int *nipm;                   // [0] its length, [1 + bin] instances per compaction bin
-    int *blkcnt;                 // per 64-instance group of k_forward: instances per compaction bin [group][32]
+    int *blkcnt;                 // per 64-instance group of k_forward: instances per compaction bin [group][BIN_STRIDE]
     int *done;                   // per instance: 1 = finished by the active-set kernel (k_as), 0 = left for k_ipm_rest
     int *rank;                   // per instance: (bin << 8) | rank among the same-bin instances of its group
     // partial condensing (cfnmpc_opts.cond_N2 < N): the N stages are regrouped into cond_N2 blocks,
