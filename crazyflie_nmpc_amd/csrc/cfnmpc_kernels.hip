@@ -1542,6 +1542,9 @@ __device__ unsigned long long g_prof[32];   // [0..7] phases of the longest wave
 // checkpoint, and the roll-out reads the compact copy over the whole horizon.
 // Fall-back rows start on the full horizon when their classified head is at least this long (1: always; 0: never -- the
 // behaviour up to round 5; A/B builds: -DCFN_REST_FULL_HEAD=...)
+#ifndef CFN_REDO_WARM
+#define CFN_REDO_WARM 1
+#endif
 #ifndef CFN_REST_FULL_HEAD
 #define CFN_REST_FULL_HEAD 1
 #endif
@@ -1667,6 +1670,8 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     RowIPM R;
     bool accepted = !AS_ONLY;   // MODE 1: only rows finished by the active-set solve are final
 
+    int prev_n = 0;   // inputs of the previous attempt's head (their final classes are still in the compact Q.tu)
+    int as_total = 0; // active-set solves of this row over all attempts (what cfnmpc_get_stats reports: the solves it cost)
     for (int attempt = 0; attempt < 3; attempt++) {
         R.iters = 0; R.status = 0; R.res = 0.0; R.mu = 0.0; R.act = false;
         gather(head, chk);
@@ -1679,10 +1684,15 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
             // ended in a settled active-set solve starts from the union of that solve's final set and today's violations (the
             // reference never shifts its iterate, acados_mpc.cpp:581-611, so the classes are taken stage for stage).  Any start
             // ends in the same place: a stationary classification is the exact solution.
+            // AGAIN (a further attempt of the active-set kernels: the settled solution's tail left the box, the head got longer): the
+            // stages of the previous head start from the classes that attempt ENDED with -- the stationary set of the shorter
+            // problem, all but identical to the longer one's -- instead of from the unconstrained minimiser's violations: one or
+            // two solves instead of the row's four or five all over again (CFN_REDO_WARM; profiles/r06_notes.md section 14).
             const bool warm = P.as_warm && t.valid && gm(P.wvalid)[t.inst] != 0;
             const gbyte* wc = gm(P.wcls) + (size_t)(warm ? t.inst : 0) * N * 4;
+            const int n_again = (CFN_REDO_WARM && AS_ONLY && attempt > 0) ? prev_n : 0;
             for (int e0 = t.L; e0 < head * 4; e0 += 64) {
-                double uk[4], vv[4], blo[4], bhi[4];
+                double uk[4], vv[4], blo[4], bhi[4], pcl[4];
                 int wprev[4];
                 SFOR(j, 0, 4, {
                     const size_t idx = cbase + imin(e0 + 16 * j, head * 4 - 1);
@@ -1690,6 +1700,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                     vv[j] = gm(Q.v)[idx];
                     box_at<SBOX>(Q, idx, blo[j], bhi[j]);
                     wprev[j] = warm ? (int)wc[imin(e0 + 16 * j, head * 4 - 1)] : 0;
+                    pcl[j] = n_again > 0 ? gm(Q.tu)[cbase + imin(e0 + 16 * j, n_again - 1)] : 0.0;
                 });
                 SFOR(j, 0, 4, {
                     const int e = e0 + 16 * j;
@@ -1697,6 +1708,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                         const double lb = blo[j] - uk[j], ub = bhi[j] - uk[j];
                         double cls = vv[j] < lb ? 1.0 : (vv[j] > ub ? 2.0 : 0.0);
                         if (cls == 0.0 && wprev[j] != 0) cls = (double)wprev[j];
+                        if (e < n_again) cls = pcl[j];
                         if (SBOX && !(blo[j] < bhi[j])) cls = 1.0;   // lb = ub: fixed from the start
                         gm(Q.tu)[cbase + e] = cls;
                         gm(Q.tl)[cbase + e] = cls == 1.0 ? lb - vv[j] : (cls == 2.0 ? ub - vv[j] : 0.0);
@@ -1752,7 +1764,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
                 }
             }
         }
-        if (as_done) { R.status = 0; R.iters = as_iters; }
+        if (as_done) { as_total += as_iters; R.status = 0; R.iters = as_total; }
         if constexpr (!AS_ONLY) {
         const bool start_ipm = infeasible && !as_done;
         // Clipped start for rows whose unconstrained minimiser lies more than clip_viol box widths outside the box
@@ -2069,6 +2081,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         int want = redo ? kviol + 5 : 0;
         want = max(want, __shfl_xor(want, 16));
         want = max(want, __shfl_xor(want, 32));
+        prev_n = head * 4;
         head = attempt == 0 ? max(head_class(P, want), head) : N;
         chk = -1;
         SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });

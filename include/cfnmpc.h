@@ -278,9 +278,11 @@ int cfnmpc_get_u(cfnmpc_solver *s, int stage, double *u /*[B][4]*/, int on_devic
 int cfnmpc_get_x(cfnmpc_solver *s, int stage, double *x /*[B][13]*/, int on_device, void *stream);
 /* status (acados_solve() return value), QP iteration count, nlp_out->inf_norm_res stand-in
  * (max-norm residual of the last QP).  Any pointer may be NULL.
- * qp_iter: 0 = the unconstrained minimiser was feasible; otherwise the number of active-set solves of a row they settled, or
- * the interior-point ITERATIONS of a row that fell back (after 12 unsettled solves, or skipped by as_skip_viol) -- the two
- * ranges overlap (twelve iterations are not twelve solves).  res tells them apart: exactly 0.0 for a row settled by active-set
+ * qp_iter: 0 = the unconstrained minimiser was feasible; otherwise the number of active-set solves of a row they settled (a row
+ * of the large fleets' kernel that was solved AGAIN over a longer head -- its own or a wave-mate's tail had left the box -- counts
+ * the solves of all attempts; the later ones start from the previous attempt's final set and take one or two), or
+ * the interior-point ITERATIONS of a row that fell back (after 12 unsettled solves, or skipped by as_skip_viol; such a row runs
+ * the interior point over all N stages) -- the two ranges overlap (twelve iterations are not twelve solves).  res tells them apart: exactly 0.0 for a row settled by active-set
  * solves (a stationary classification IS the KKT system), the interior point's final residual (> 0, <= tol at status 0)
  * for a row it solved. */
 int cfnmpc_get_stats(cfnmpc_solver *s, int *status /*[B]*/, int *qp_iter /*[B]*/, double *res /*[B]*/, int on_device, void *stream);

@@ -70,6 +70,41 @@ def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, pass
     assert n_con > 20 and n_multi > 5     # constrained QPs with more than one solve were exercised
 
 
+def test_rows_solved_again_start_from_their_previous_set(oracle):
+    """Heavy saturation (2.5 x the bench's perturbations), active horizon: in the monolithic kernel (as_passes = -1) a wave whose
+    settled solution leaves the box behind its head solves its four rows AGAIN over a longer head, starting from the first
+    attempt's final sets (round 6) -- one or two solves instead of all of them again; the solves + commit structure (-3) sends
+    such a row to the retry kernel, which starts cold.  Same QP either way: the same statuses, FP64-level agreement of the
+    iterates on every row both settle; the monolithic kernel counts the solves of all attempts, hence never (but for a
+    borderline row) fewer than the other structure."""
+    from crazyflie_nmpc_amd import BatchSolver, default_opts, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    B = 1027
+    x0, yref, yref_e = _fleet(oracle, B, 2.5, 99)
+    a = BatchSolver(B, default_opts(as_passes=-1))
+    b = BatchSolver(B, default_opts(as_passes=-3, as_dense=-1))
+    for s in (a, b):
+        s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    x = x0.copy()
+    n_more = n_rows = 0
+    for t in range(5):
+        for s in (a, b):
+            s.set_x0(x); s.solve(1)
+        sa, ia, ra = a.stats(); sb, ib, rb = b.stats()
+        xa, ua = a.get_iterate(); xb, ub = b.get_iterate()
+        assert np.array_equal(sa, sb), (t, np.nonzero(sa != sb)[0][:10])
+        both = (sa == 0) & (ra == 0.0) & (rb == 0.0) & (ia > 0)      # settled by active-set solves on both sides
+        assert ((ia > 0) == (ib > 0))[sa == 0].all()
+        du = np.abs(ua - ub).reshape(B, -1).max(1); dx = np.abs(xa - xb).reshape(B, -1).max(1)
+        assert du[both].max() < 1e-8 and dx[both].max() < 1e-8, (t, du[both].max(), dx[both].max())
+        d = ia[both] - ib[both]
+        assert d.min() >= -1 and (d < 0).mean() < 0.01, (t, d.min(), (d < 0).mean())
+        n_more += int((d > 0).sum()); n_rows += int(both.sum())
+        x = sim(x, a.get_u(0), T=0.015, steps=1)
+        b.set_iterate(xa, ua)
+    assert n_rows > 2000 and n_more > 100, (n_rows, n_more)     # waves did go round again
+
+
 @pytest.mark.parametrize("passes", [-3, 3])
 def test_solves_and_commit_match_cpu_restatement(oracle, cref, passes):
     """192 instances, 12 closed-loop steps, full-horizon sweeps: same solves as the restatement's as_solve, count by count,

@@ -77,7 +77,10 @@ def test_fused_closed_loop_matches_restatement(oracle, cref, start_solve, active
         assert (st == 0).all() and (st_r == 0).all()
         assert np.abs(ug - ur).max() < 1e-8 and np.abs(xg - xr).max() < 1e-8, t
         if active_set:
-            assert (it == it_r).all()
+            # same solves row by row -- except the rows of a wave that went round AGAIN (a settled solution's tail left the box: the
+            # monolithic kernel solves its four rows once more over a longer head, starting from the first attempt's final sets --
+            # round 6 -- and a row reports the solves of all its attempts: a few more than the restatement's single run)
+            assert (it >= it_r).all() and (it == it_r).mean() > 0.8, (t, it[it != it_r], it_r[it != it_r])
         nqp += int((it > 0).sum())
         x = sim(x, s.get_u(0), T=0.015, steps=1)
         ur[:] = ug; xr[:] = xg
