@@ -1360,6 +1360,7 @@ __global__ __launch_bounds__(256) void k_scatter(Params P) {
             gm(P.nipm)[NI_LONG16] = P.N > 16 ? base[3 * N_DIFF] : 0;
             gm(P.nipm)[NI_LONG24] = P.N > 24 ? base[2 * N_DIFF] : 0;    // ... of more than 24 stages (full horizon, 32): behind part two of a split sweep
             gm(P.nipm)[NI_LATE] = 0;                                    // late rows of this step's split sweep (k_forward_p2 counts them)
+            gm(P.nipm)[NI_LISTED] = 0;                                  // fall-back rows (the monolithic active-set kernel appends them; k_ipm_list overwrites)
         }
     }
     if (blockIdx.x == 0 && P.ascnt && threadIdx.x < 32) gm(P.ascnt)[threadIdx.x] = 0;   // work lists of the active-set passes
@@ -2087,6 +2088,10 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
         SFOR(c, 0, N_CHK, { if (head == chk_stage(c) && head < N) chk = c; });
     }
     if (AS_ONLY && t.L == 0 && t.valid) gm(P.done)[t.inst] = accepted ? 1 : 0;
+    // the monolithic kernel lists the rows it leaves for the interior point itself (k_scatter zeroed the count): no k_ipm_list
+    // launch between the two kernels (12 - 50 us on the step's critical path at 65 536 instances).  The order of the list is
+    // that of the waves' completion; a row's result does not depend on its slot or its wave-mates.
+    if (MODE == 1 && P.ipm_listed && t.L == 0 && t.valid && !accepted) gm(P.ilist2)[atomicAdd(P.nipm + NI_LISTED, 1)] = t.inst;
     if (t.L == 0 && infeasible && accepted) {
         gm(P.status)[t.inst] = R.status;
         gm(P.iters)[t.inst] = R.iters;
@@ -3104,12 +3109,9 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         // store first (and the interior-point fall-back rows once more after k_ipm_list has moved them to new slots)
         launch_linearise_clist(P, P.clist_chunks, 0, st);
         if (P.active_set) {
-            hipLaunchKernelGGL(k_as_cst, dim3(P.NW), dim3(64), 0, st, P);
+            hipLaunchKernelGGL(k_as_cst, dim3(P.NW), dim3(64), 0, st, P);   // (lists its fall-back rows itself)
             if (ev) (void)hipEventRecord(ev[0], st);
-            if (P.ipm_listed) {
-                hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
-                launch_linearise_clist(P, P.clist_chunks, 1, st);
-            }
+            if (P.ipm_listed) launch_linearise_clist(P, P.clist_chunks, 1, st);
             hipLaunchKernelGGL(k_ipm_rest_cst, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
         } else {
             if (ev) (void)hipEventRecord(ev[0], st);
@@ -3119,9 +3121,8 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
     }
     if (P.lbs) {   // per-stage boxes: monolithic kernels instantiated for them
         if (P.active_set) {
-            hipLaunchKernelGGL(k_as_sbox, dim3(P.NW), dim3(64), 0, st, P);
+            hipLaunchKernelGGL(k_as_sbox, dim3(P.NW), dim3(64), 0, st, P);   // (lists its fall-back rows itself)
             if (ev) (void)hipEventRecord(ev[0], st);
-            if (P.ipm_listed) hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
             hipLaunchKernelGGL(k_ipm_rest_sbox, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
         } else {
             if (ev) (void)hipEventRecord(ev[0], st);
@@ -3197,9 +3198,8 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
         if (P.ipm_listed) hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
         hipLaunchKernelGGL(k_ipm_rest, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
     } else if (P.active_set) {
-        hipLaunchKernelGGL(k_as, dim3(P.NW), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_as, dim3(P.NW), dim3(64), 0, st, P);   // (lists its fall-back rows itself)
         if (ev) (void)hipEventRecord(ev[0], st);
-        if (P.ipm_listed) hipLaunchKernelGGL(k_ipm_list, dim3(1), dim3(1024), 0, st, P);
         hipLaunchKernelGGL(k_ipm_rest, dim3(imax_h(1, imin_h(P.NW, P.as_grid / 2))), dim3(64), 0, st, P);
     } else {
         if (ev) (void)hipEventRecord(ev[0], st);
