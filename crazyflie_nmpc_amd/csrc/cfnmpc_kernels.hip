@@ -1369,7 +1369,12 @@ __global__ __launch_bounds__(256) void k_scatter(Params P) {
     if (i >= P.B) return;
     if (gm(P.head)[i] > 0) {
         const int r = gm(P.rank)[i];
-        gm(P.ilist)[base[r >> 8] + gm(P.blkcnt)[(i >> 6) * BIN_STRIDE + (r >> 8)] + (r & 255)] = i;
+        const int pos = base[r >> 8] + gm(P.blkcnt)[(i >> 6) * BIN_STRIDE + (r >> 8)] + (r & 255);
+        gm(P.ilist)[pos] = i;
+        // split forward sweep: a row whose head reaches behind the split point (classes 32 / N: less than one per step at these
+        // fleet sizes) cannot be solved beside part two of the sweep -- it goes to the retry kernel, which runs behind the commit
+        // kernel anyway (P.asst = 2: "not tried"; a launch that does solve it, k_as_solves over the whole list, overwrites the flag)
+        if (P.fwd_split && P.N > 24 && (r >> 8) < 2 * N_DIFF) gm(P.asst)[pos] = 2;
     }
 }
 
@@ -2653,8 +2658,9 @@ __device__ __forceinline__ void ascommit_body(const Params& P) {
         const bool has = c < nipm;
         const int inst = has ? gm(P.ilist)[c] : 0;
         const bool go = has && gm(P.asst)[imin(c, nipm - 1)] == 1;
+        const int untried = has && gm(P.asst)[imin(c, nipm - 1)] == 2;   // (k_scatter: head behind the split point -> retry kernel)
         if (!__any(go)) {
-            if (has && (threadIdx.x & 15) == 0) gm(P.done)[inst] = 0;
+            if (has && (threadIdx.x & 15) == 0) gm(P.done)[inst] = untried ? 2 : 0;
             continue;
         }
         const Lane t = lane_indirect(P, inst, go);
@@ -2758,7 +2764,7 @@ __device__ __forceinline__ void ascommit_body(const Params& P) {
         kviol = (int)row_max((double)kviol);
         if (has && t.L == 0) {
             if (!go) {
-                gm(P.done)[inst] = 0;          // did not settle: interior point
+                gm(P.done)[inst] = untried ? 2 : 0;   // did not settle: interior point (not tried yet: retry kernel)
             } else if (kviol < 0) {
                 gm(P.done)[inst] = 1;
                 gm(P.status)[inst] = 0;
@@ -3148,11 +3154,12 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
             const bool split = p1_ran && side && side2;
             if (side) (void)hipEventRecord((hipEvent_t)P.as_fork, st);
             if (split) {
-                Params PA = P, PB = P;
-                PA.as_range = 1; PB.as_range = 2;
+                Params PA = P;
+                PA.as_range = 1;
                 (void)hipStreamWaitEvent(side2, (hipEvent_t)P.as_fork, 0);
                 hipLaunchKernelGGL(k_forward_p2, dim3((P.B + 63) / 64), dim3(64), 0, side2, P);
-                hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, side2, PB);
+                // (the rows with heads behind the split point -- PB's range: rare -- are left to k_as_retry below: a launch behind
+                //  part two, which is the longest chain of this group, cost 5 + 8 us per step whether it had work or not)
                 (void)hipEventRecord((hipEvent_t)P.as_join2, side2);
                 (void)hipStreamWaitEvent(side, (hipEvent_t)P.as_fork, 0);
                 hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, side, PA);
@@ -3165,7 +3172,9 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
                     (void)hipEventRecord((hipEvent_t)P.as_join, side);
                 } else {
                     side = nullptr;
-                    hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, P);
+                    Params PA = P;
+                    PA.as_range = p1_ran ? 1 : 0;   // (behind a split sweep the same rows as with the side streams: bit-identical steps)
+                    hipLaunchKernelGGL(k_as_solves, dim3(P.NW), dim3(64), 0, st, PA);
                 }
             }
             launch_as_dense(P, imax_h(1, imin_h(P.as_grid / 2, P.NW * 4)), st);
