@@ -1567,7 +1567,7 @@ __device__ __forceinline__ void qp_wave(const Params& P, double (*wtile)[WT_TILE
     const bool listed = MODE == 2 && P.ipm_listed;   // (small fleets skip k_ipm_list: the rows stay where k_as had them)
     // (MODE 4 beside the dense kernel: only the rows with heads of more than 16 stages, the first P.nipm[NI_LONG16] of the list)
     // (MODE 2 / 3 behind a split forward sweep: the late rows its second part appended -- P.nipm[NI_LATE] of them -- belong to the list)
-    const int nipm = gm(P.nipm)[listed ? NI_LISTED : ((MODE == 4 && P.as_dense) ? (P.as_range == 2 ? NI_LONG24 : NI_LONG16) : 0)] +
+    const int nipm = gm(P.nipm)[listed ? NI_LISTED : ((MODE == 4 && P.as_dense) ? NI_LONG16 : 0)] +
                      (((MODE == 2 && !listed) || MODE == 3) && P.fwd_split ? gm(P.nipm)[NI_LATE] : 0);
     const int slot_lo = (MODE == 4 && P.as_dense && P.as_range == 1) ? gm(P.nipm)[NI_LONG24] : 0;   // (first list slot of this launch)
     // SPARSE (active-set kernels, short lists): ONE list slot per wave (row 0; rows 1..3 idle) while the constrained rows
@@ -3144,7 +3144,8 @@ void launch_qp_ipm(const Params& P, hipStream_t st, hipEvent_t* ev) {
             // caller's stream; the rows with longer heads (the first P.nipm[NI_LONG16] of the list: none, or a handful) keep the Riccati
             // form of the iteration in k_as_solves, forked onto the solver's side stream -- two latency chains side by side.
             // Split forward sweep: its second part (stages [24, N) of EVERY instance) runs on a second side stream beside both;
-            // rows with heads of 24 stages read nothing behind stage 24 and stay beside it, the rows with longer heads follow it.
+            // rows with heads of 24 stages read nothing behind stage 24 and stay beside it, the rows with longer heads (rare) are
+            // left to the retry kernel.
             hipStream_t side = (hipStream_t)P.as_side, side2 = (hipStream_t)P.as_side2;
             // (a step being CAPTURED into a graph -- cfnmpc_opts.step_graph -- keeps everything on the capture stream: forked streams
             //  inside a re-captured graph whose predecessor is still in flight crashed the runtime in one run of four)

@@ -128,10 +128,10 @@ struct Params {
     // host-only (never read on the device): side stream + fork / join events on which k_as_solves -- the few rows with longer
     // heads, a latency chain of its own -- runs BESIDE k_as_dense (hipStream_t / hipEvent_t, owned by the solver)
     void *as_side, *as_fork, *as_join;
-    void *as_side2, *as_join2;   // ... and the second part of the split forward sweep (+ the rows it must precede) beside both
-    int as_range;                // k_as_solves beside the dense kernel and the split sweep: 0 = every row with a head of more than 16 stages;
-                                 // 1 = heads of 24 stages only (they read nothing behind stage 24: beside part two of the sweep);
-                                 // 2 = heads of more than 24 stages (behind part two, on its stream)
+    void *as_side2, *as_join2;   // ... and the second part of the split forward sweep beside both
+    int as_range;                // k_as_solves beside the dense kernel: 0 = every row with a head of more than 16 stages; 1 (behind a split
+                                 // sweep) = heads of 24 stages only -- they read nothing behind stage 24 and run beside part two of the
+                                 // sweep; the rows with longer heads (classes 32 / N) are left to the retry kernel (k_scatter flags them)
     // split forward sweep (cfnmpc_opts.forward_split): 0 = one launch; H = 24: k_forward_p1 over [0, H) -> compaction -> k_forward_p2 over
     // [H, N) beside the constrained rows' kernels; hand-over [group of 64][13 | 4][64]
     int fwd_split;
