@@ -48,9 +48,12 @@ def test_level_synchronous_passes_match_monolithic_kernel(oracle, B, scale, pass
         if ah == 0:    # same head (the whole horizon) on both sides: the same solves, count by count
             assert np.array_equal(ia[as_only], ib[as_only]), (t, ia[as_only & (ia != ib)][:10], ib[as_only & (ia != ib)][:10])
         else:          # the monolithic kernel gives the four rows of a wave their largest head class, the passes each
-            #            row its own: a different (equivalent) QP may take a solve more or less
+            #            row its own: a different (equivalent) QP may take a solve more or less -- and a wave of the monolithic
+            #            kernel that goes round again over a longer head counts the solves of all its attempts (round 6)
             assert ((ia > 0) == (ib > 0))[ok].all()
-            assert (ia[as_only] != ib[as_only]).mean() < 0.02 and np.abs(ia[as_only] - ib[as_only]).max() <= 4
+            d = ia[as_only] - ib[as_only]
+            assert (d < 0).mean() < 0.02 and d.min() >= -4 and d.max() <= 24, (t, (d < 0).mean(), d.min(), d.max())   # (up to three attempts of up to twelve solves)
+            assert (d != 0).mean() < (0.02 if scale <= 1.5 else 0.30), (t, (d != 0).mean())
         # exact QP solutions on both sides: FP64-level agreement (kRPM / state units) for (nearly) all -- heads may differ,
         # and with them the rounding --, the interior point's accuracy for every instance
         du = np.abs(ua - ub).reshape(B, -1).max(1); dx = np.abs(xa - xb).reshape(B, -1).max(1)
