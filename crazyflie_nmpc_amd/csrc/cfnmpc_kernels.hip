@@ -1413,12 +1413,28 @@ __device__ __forceinline__ Elem ld_elem(const Params& P, size_t idx) {
 // One pass over the n elements of a row, in batches of four per lane with all loads of a batch
 // issued before any arithmetic (these passes run with one wave per SIMD: a plain loop would pay
 // one memory round trip per element).
+#ifndef CFN_ELEM_PIPE
+#define CFN_ELEM_PIPE 1
+#endif
 template <int NSTEP, bool SBOX, class BODY>
 __device__ __forceinline__ void elem_pass(const Params& P, size_t base, int n, int L, BODY&& body) {
+    if constexpr (CFN_ELEM_PIPE && !SBOX) {   // (per-stage boxes load two more values per element: that variant keeps the plain batches, +36 B of scratch otherwise)
+    // two half-batches in flight (the same four elements' worth of registers): the loads of the next two elements are issued before
+    // the arithmetic of the current two, so that a pass over a long row (200 inputs at N = 50: 13 elements per lane) pays about
+    // one memory round trip instead of one per batch of four -- the fall-back's five passes per iteration were 25 of its 194 us
+    Elem cur[2], nxt[2];
+    SFOR(j, 0, 2, { cur[j] = ld_elem<NSTEP, SBOX>(P, base + imin(L + 16 * j, n - 1)); });
+    for (int e0 = L; e0 < n; e0 += 32) {
+        SFOR(j, 0, 2, { nxt[j] = ld_elem<NSTEP, SBOX>(P, base + imin(e0 + 32 + 16 * j, n - 1)); });
+        SFOR(j, 0, 2, { if (e0 + 16 * j < n) body(e0 + 16 * j, cur[j]); });
+        SFOR(j, 0, 2, { cur[j] = nxt[j]; });
+    }
+    } else {
     for (int e0 = L; e0 < n; e0 += 64) {
         Elem d[4];
         SFOR(j, 0, 4, { d[j] = ld_elem<NSTEP, SBOX>(P, base + imin(e0 + 16 * j, n - 1)); });
         SFOR(j, 0, 4, { if (e0 + 16 * j < n) body(e0 + 16 * j, d[j]); });
+    }
     }
 }
 
