@@ -48,6 +48,55 @@ def test_full_size_properties_and_spot_parity(oracle, cref, B):
         x = sim(x, ug[:, 0, :].copy(), T=0.015, steps=1)
 
 
+def test_full_size_heavy_disturbances_fall_back_list(oracle, cref):
+    """65 536 instances in the bench's closed loop at twice its disturbances (a twentieth of the fleet kicked every step): half of
+    the fleet is constrained, the monolithic active-set kernel leaves a few hundred rows to the interior point and lists them
+    ITSELF (round 6: no scan of the list between the two kernels; the order of the fall-back list is that of the waves'
+    completion).  Every listed row must come back solved over the full horizon: the rows the interior point reports are the
+    listed ones, each with head N, inside the box -- and a sample of them against the CPU restatement, whose algorithm this
+    now is: the same iteration counts, iterates to 5e-5 (the interior point's tolerance times the conditioning of these rows)."""
+    from crazyflie_nmpc_amd import BatchSolver, sim
+    from crazyflie_nmpc_amd.solver import INIT_HOVER
+    x0, yref, yref_e = _fleet(oracle, seed=4711, scale=2.0)
+    rng = np.random.default_rng(4712)
+    s = BatchSolver(B)
+    s.set_x0(x0); s.set_yref(yref, yref_e); s.init_iterate(INIT_HOVER)
+    x = x0.copy()
+    opts = cref.default_opts(tol=1e-8, active_set=1)
+    KP = 20
+    n_checked = n_listed = 0
+    for t in range(24):
+        c0 = (t % KP) * (B // KP)
+        x[c0:c0 + B // KP] = oracle.sample_hover_x0(rng, B // KP, scale=2.0)
+        check = t >= 21
+        if check: xp, up = s.get_iterate()
+        s.set_x0(x); s.solve(1)
+        u0 = s.get_u(0)
+        if check:
+            st, it, rs = s.stats()
+            cnt = s.list_counts()              # constrained rows | rows listed for the fall-back | long heads | late rows
+            xg, ug = s.get_iterate()
+            ok = st == 0
+            assert ok.mean() > 0.99, np.bincount(st)
+            assert ug[ok].min() >= -1e-8 and ug[ok].max() <= 22.0 + 1e-8
+            fb = (it > 0) & (rs > 0)           # rows the interior point solved (active-set rows report res = 0 exactly)
+            assert cnt[1] > 50, cnt            # the fall-back list was used ...
+            assert int((fb & ok).sum()) <= cnt[1], (cnt, int((fb & ok).sum()))   # ... and holds every row the interior point solved
+            assert (s.heads()[fb & ok] == N).all()
+            idx = np.nonzero(fb & ok)[0][:40]
+            xr = xp[idx].copy(); ur = up[idx].copy()
+            st_r, it_r, rs_r, _ = cref.rti_step(opts, xr, ur, x[idx].copy(), yref[idx].copy(), yref_e[idx].copy(), nthreads=0)
+            both = (st_r == 0) & (rs_r > 0)
+            assert both.mean() > 0.8, (t, both.mean())
+            assert (it[idx][both] == it_r[both]).mean() > 0.9, (t, it[idx][both], it_r[both])
+            same = both & (it[idx] == it_r)
+            assert np.abs(ug[idx][same] - ur[same]).max() < 5e-5 and np.abs(xg[idx][same] - xr[same]).max() < 5e-5   # (same iterations; measured 7e-6 on the worst-conditioned rows)
+            n_checked += int(same.sum()); n_listed += cnt[1]
+        x = sim(x, u0, T=0.015, steps=1)
+    assert n_checked >= 60 and n_listed > 150, (n_checked, n_listed)
+    s.close()
+
+
 @pytest.mark.parametrize("active_horizon", [0, 1])
 def test_instances_are_independent_under_permutation(oracle, active_horizon):
     """Solving a permuted fleet gives the permuted result: no cross-talk between the four rows of
